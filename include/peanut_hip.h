@@ -1,0 +1,125 @@
+/* peanut_hip -- C ABI of the MI355X-native PEANUT perception hot path (libpeanut_hip.so).
+ *
+ * The reference (ajzhai/PEANUT) has no plugin/FFI layer: its boundary for this path is three
+ * Python call surfaces.  Each entry point below states the reference interface it replaces
+ * (paths relative to the reference checkout).  Conventions:
+ *   - every `const float* dev` / `float* dev` is a DEVICE pointer (e.g. torch.Tensor.data_ptr());
+ *     the caller owns every buffer; `host` pointers are marked as such;
+ *   - functions enqueue on the given hipStream_t (passed as void*; NULL = default stream) and do
+ *     not synchronise unless stated;
+ *   - return 0 on success, a negative PEANUT_E* code otherwise; peanut_last_error() returns a
+ *     thread-local message for the last failure;
+ *   - a handle is not thread-safe, distinct handles are.
+ */
+#ifndef PEANUT_HIP_H_
+#define PEANUT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEANUT_OK 0
+#define PEANUT_EINVAL (-2)   /* bad argument / unsupported configuration */
+#define PEANUT_EHIP (-3)     /* HIP runtime error */
+#define PEANUT_EWEIGHTS (-4) /* missing or mis-shaped tensor in the state dict */
+
+const char* peanut_last_error(void);
+/* library / ABI version and the arch it was compiled for ("gfx950") */
+int peanut_abi_version(void);
+const char* peanut_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 3 -- map-completion forward (PSPNet: ResNet-50-V1c-D8 + PSP head)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Fields of nav/pred_model_cfg.py:2-42 that the inference path reads. */
+typedef struct peanut_pred_cfg {
+  int in_channels;       /* backbone.in_channels (14) */
+  int num_classes;       /* decode_head.num_classes (6) */
+  int strides[4];        /* backbone.strides (1,2,1,1) */
+  int dilations[4];      /* backbone.dilations (1,1,2,4) */
+  int contract_dilation; /* backbone.contract_dilation (True) */
+  int pool_scales[8];    /* decode_head.pool_scales (1,2,3,6) */
+  int n_pool_scales;
+  int head_channels;     /* decode_head.channels (512) */
+  int align_corners;     /* decode_head.align_corners (False) */
+  float bn_eps;          /* nn.BatchNorm2d default 1e-5 */
+} peanut_pred_cfg;
+
+/* One entry of an mmcv/PyTorch state dict (HOST memory, fp32, contiguous, OIHW for convs). */
+typedef struct peanut_tensor {
+  const char* name;  /* e.g. "backbone.layer1.0.conv1.weight" */
+  const float* data; /* host */
+  int ndim;
+  int64_t shape[4];
+} peanut_tensor;
+
+typedef struct peanut_pred peanut_pred_t;
+
+/* Replaces init_segmentor (prediction/mmseg/apis/inference.py:12-40) as called from
+ * PEANUT_Prediction_Model.__init__ (nav/agent/prediction.py:142-152): builds the layer table
+ * from cfg, looks every tensor up BY NAME in the mmcv state-dict key schema
+ * (auxiliary_head.* and num_batches_tracked entries are ignored), folds BatchNorm into a
+ * per-channel scale/shift, repacks conv weights into the kernel tile layout and uploads them.
+ * Synchronous. */
+int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors,
+                       int n_tensors);
+void peanut_pred_destroy(peanut_pred_t* h);
+
+/* Replaces run_inference + model(return_loss=False, rescale=True) + (optionally) expit:
+ * nav/agent/prediction.py:112-137,155-158 -> prediction/mmseg/models/segmentors/
+ * encoder_decoder.py:70-80,203-271.  in_dev: [B, in_channels, H, W] NCHW fp32;
+ * out_dev: [B, num_classes, H, W] NCHW fp32 raw logits (apply_sigmoid=0, what simple_test
+ * returns in the fork) or probabilities (apply_sigmoid=1, what get_prediction returns).
+ * The activation workspace for a (B,H,W) shape is allocated on first use and cached. */
+int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W,
+                        int apply_sigmoid, void* stream);
+
+/* Bytes of activation workspace a (B,H,W) forward needs (0 on error). */
+size_t peanut_pred_workspace_bytes(peanut_pred_t* h, int B, int H, int W);
+
+/* Conv FLOPs (2 x MACs over the 61 convolutions) of one HxW map. */
+double peanut_pred_flops_per_map(peanut_pred_t* h, int H, int W);
+
+/* Test/bisect hook: keep every intermediate of subsequent forwards in its own buffer
+ * (keep=1) and fetch one by name after a forward.  Names: "stem0","stem1","stem2","pool",
+ * "layer1".."layer4","ppm_table","bottleneck","logits_lowres".  *dev_out points into the
+ * handle's workspace (NHWC; dims = {B,H,W,C}; "ppm_table" is {B,1,nbins,C}). */
+int peanut_pred_debug_keep(peanut_pred_t* h, int keep);
+int peanut_pred_debug_tensor(peanut_pred_t* h, const char* name, const float** dev_out, int dims[4]);
+/* Same lookup, but copies the tensor into dst_dev (device, >= max_floats capacity) on `stream`;
+ * dst_dev == NULL only reports dims. */
+int peanut_pred_debug_read(peanut_pred_t* h, const char* name, float* dst_dev, size_t max_floats, int dims[4],
+                           void* stream);
+
+/* Per-op timing of the last-planned shape: runs every launch of one forward bracketed by HIP
+ * events on `stream` (synchronises).  Writes up to max_ops entries; returns the op count.
+ * names[i] points to storage owned by the handle. */
+int peanut_pred_profile(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W,
+                        void* stream, const char** names, float* ms, double* flops, int max_ops);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level export: one fused conv (+BN scale/shift, +residual, +ReLU) on NHWC fp32.
+ * Mirrors mmcv ConvModule / build_conv_layer+build_norm_layer call sites
+ * (prediction/mmseg/models/backbones/resnet.py:164-209, decode_heads/psp_head.py:39-46,86-93).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct peanut_conv peanut_conv_t;
+/* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
+ * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
+ * which the packer guarantees). */
+int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
+                       const float* shift_host, int cout, int cin, int cin_pad, int kh, int kw, int stride,
+                       int pad, int dil, int relu);
+void peanut_conv_destroy(peanut_conv_t* c);
+/* x_dev [B,H,W,cin_pad] (or split x_dev [..,c1] ++ x2_dev [..,cin_pad-c1] when x2_dev != NULL),
+ * res_dev optional [B,Ho,Wo,cout], y_dev [B,Ho,Wo,cout]. */
+int peanut_conv_forward(peanut_conv_t* c, const float* x_dev, const float* x2_dev, int c1, const float* res_dev,
+                        float* y_dev, int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEANUT_HIP_H_ */

@@ -1,0 +1,91 @@
+"""ORACLE support (test infrastructure): generate the committed golden vectors under tests/golden/
+by running THE REFERENCE'S OWN SOURCES from /root/reference (see oracle/ref_import.py), and assert
+that the oracle restatements (oracle/pspnet_ref.py, oracle/mapping_ref.py) reproduce them.
+
+Run in the build container only (needs /root/reference):   python -m oracle.gen_golden
+Nothing here travels to or runs on the GPU box; only the .npz outputs do.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import pspnet_ref, ref_import  # noqa: E402
+from peanut_amd.weights import PredCfg, make_seeded_state_dict  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# (case name, c_in, weight seed, B, H, W, input seed)
+PSP_CASES = [
+    ("cfg1_240", 14, 0, 1, 240, 240, 0),      # BASELINE.json configs[0]
+    ("b2_96", 14, 0, 2, 96, 96, 1),
+    ("odd_100", 14, 0, 1, 100, 100, 2),       # ceil-mode arithmetic, non-integer bilinear scale
+    ("rect_72x104", 14, 0, 2, 72, 104, 3),
+    ("cin25_64", 25, 1, 1, 64, 64, 4),        # config 5's channel count, different weights
+]
+
+
+def psp_input(b, c, h, w, seed):
+    """SURVEY.md sec. 8d config-1 style: binary sparse map, x = (rand > 0.7)."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand((b, c, h, w), generator=g) > 0.7).float()
+
+
+def gen_pspnet(report):
+    out = {}
+    models = {}
+    for name, c_in, wseed, b, h, w, iseed in PSP_CASES:
+        cfg = PredCfg(in_channels=c_in)
+        key = (c_in, wseed)
+        if key not in models:
+            m = ref_import.build_reference_model(in_channels=c_in)
+            sd = make_seeded_state_dict(cfg, wseed, with_aux=True)
+            m.load_state_dict(sd, strict=True)
+            models[key] = (m, sd)
+        m, sd = models[key]
+        x = psp_input(b, c_in, h, w, iseed)
+        t0 = time.time()
+        ref = np.stack(ref_import.reference_forward(m, x))          # list of [6,H,W] -> [B,6,H,W]
+        dt = time.time() - t0
+        mine = pspnet_ref.forward_batch(sd, x, cfg).numpy()
+        err = float(np.abs(ref - mine).max())
+        assert err <= 1e-5, f"{name}: oracle restatement deviates from the reference by {err}"
+        # single-map API path (run_inference / get_prediction) for the first map
+        one = pspnet_ref.run_inference(sd, x[0].numpy(), cfg)[0]
+        assert float(np.abs(one - ref_import.reference_forward(m, x[:1])[0]).max()) <= 1e-5
+        out[f"{name}/input"] = x.numpy().astype(np.uint8)
+        out[f"{name}/logits"] = ref.astype(np.float32)
+        out[f"{name}/c_in"] = np.int64(c_in)
+        out[f"{name}/weight_seed"] = np.int64(wseed)
+        report["pspnet"][name] = dict(shape=[b, c_in, h, w], restatement_max_abs=err,
+                                      logits_absmax=float(np.abs(ref).max()), ref_seconds=round(dt, 3))
+        print(f"[pspnet] {name}: ref vs restatement max-abs {err:.2e}, |logit|max {np.abs(ref).max():.2f}")
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_golden.npz"), **out)
+
+
+def main():
+    assert ref_import.reference_available(), "needs /root/reference"
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    report = {"pspnet": {}, "mapping": {}, "torch": torch.__version__}
+    gen_pspnet(report)
+    try:
+        from oracle import gen_golden_mapping
+        gen_golden_mapping.generate(report)
+    except ImportError:
+        pass
+    with open(os.path.join(GOLDEN, "golden_report.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

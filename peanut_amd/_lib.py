@@ -1,0 +1,100 @@
+"""ctypes binding of libpeanut_hip.so (the C ABI declared in include/peanut_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every product
+entry point raises.  ``import torch`` happens before the dlopen so that the library binds to the
+HIP runtime torch already loaded (same ``libamdhip64.so.7`` soname -> one runtime per process,
+torch device pointers and streams are directly usable).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+from . import build as _build
+
+_LOCK = threading.Lock()
+_LIB = None
+
+
+class PeanutHipError(RuntimeError):
+    pass
+
+
+class PredCfgC(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("num_classes", C.c_int),
+        ("strides", C.c_int * 4), ("dilations", C.c_int * 4), ("contract_dilation", C.c_int),
+        ("pool_scales", C.c_int * 8), ("n_pool_scales", C.c_int),
+        ("head_channels", C.c_int), ("align_corners", C.c_int), ("bn_eps", C.c_float),
+    ]
+
+
+class TensorC(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
+
+
+# every symbol include/peanut_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "peanut_last_error": (C.c_char_p, []),
+    "peanut_abi_version": (C.c_int, []),
+    "peanut_build_arch": (C.c_char_p, []),
+    "peanut_pred_create": (C.c_int, [C.POINTER(_P), C.POINTER(PredCfgC), C.POINTER(TensorC), C.c_int]),
+    "peanut_pred_destroy": (None, [_P]),
+    "peanut_pred_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "peanut_pred_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
+    "peanut_pred_flops_per_map": (C.c_double, [_P, C.c_int, C.c_int]),
+    "peanut_pred_debug_keep": (C.c_int, [_P, C.c_int]),
+    "peanut_pred_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int * 4)]),
+    "peanut_pred_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int * 4), _P]),
+    "peanut_pred_profile": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_char_p),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int]),
+    "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 9),
+    "peanut_conv_destroy": (None, [_P]),
+    "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+}
+
+
+def lib_path() -> str:
+    return os.environ.get("PEANUT_HIP_LIB", _build.LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """dlopen libpeanut_hip.so and attach signatures; raises PeanutHipError if it is absent."""
+    global _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        path = lib_path()
+        if not os.path.exists(path):
+            raise PeanutHipError(
+                f"HIP extension not built: {path} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m peanut_amd.build`). "
+                "peanut_amd has no CPU fallback.")
+        try:
+            lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        except OSError as e:  # pragma: no cover - environment specific
+            raise PeanutHipError(f"failed to load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise PeanutHipError(f"{path} does not export {name}; rebuild the extension") from e
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+        return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().peanut_last_error()
+        raise PeanutHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream_ptr(device=None) -> int:
+    """Raw hipStream_t of torch's current stream on ``device`` (kernels are enqueued there)."""
+    return int(torch.cuda.current_stream(device).cuda_stream)

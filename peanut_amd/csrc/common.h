@@ -1,0 +1,70 @@
+// Shared declarations for the peanut_hip library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace peanut {
+
+// ---- error plumbing (thread-local message, negative codes; include/peanut_hip.h) ----
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define PEANUT_HIP_CHECK(expr)                                                            \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return ::peanut::fail(-3, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+// ---- fused conv (implicit GEMM on fp32 MFMA) ----
+// Activations are NHWC fp32 with the channel count padded to a multiple of 16.
+// Weights are pre-packed per (n-tile, k-tile) into contiguous [BN][BK] blocks, k-tiles ordered
+// channel-chunk outer / filter-tap inner (see pack_conv_weights).
+struct ConvDesc {
+  int cin;        // padded input channels of the (possibly concatenated) input
+  int cout;       // real output channels
+  int kh, kw, stride, pad, dil;
+  int relu;
+  int bn_tile;    // BN used for packing (32/64/128)
+  int bk;         // BK used for packing (16/32)
+  int cout_pad;   // cout rounded up to bn_tile
+  const float* w_packed;   // device
+  const float* scale;      // device [cout_pad]
+  const float* shift;      // device [cout_pad]
+};
+
+struct ConvArgs {
+  const float* x;     // [B,H,W,c1]
+  const float* x2;    // optional second source, channels [c1, c1+c2) of the logical input
+  const float* res;   // optional residual [B,Ho,Wo,cout]
+  float* y;           // [B,Ho,Wo,cout]
+  int B, H, W;
+  int c1, c2;         // c1 + c2 == desc.cin
+  int Ho, Wo;
+};
+
+inline int conv_out_dim(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+// choose (bn_tile, bk) for a layer
+void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk);
+// host-side packing: w is OIHW [cout][cin_real][kh][kw]; returns floats written
+size_t conv_packed_floats(int cin_pad, int cout, int kh, int kw, int bn_tile);
+void pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw,
+                       int bn_tile, int bk, float* out);
+int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
+
+// ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----
+int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s);
+int launch_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+// adaptive average pooling of [B,H,W,C] into all pyramid bins: out [B,nbins_total,C]
+int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, const int* scales, int nscales,
+                    hipStream_t s);
+// bilinear (align_corners=False) upsample of the pooled pyramid + channel concat: out [B,H,W,nscales*Cp]
+int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int W, int Cp, const int* scales,
+                               int nscales, int align_corners, hipStream_t s);
+// bilinear resize of NHWC logits [B,h,w,K] to NCHW [B,K,H,W], optional sigmoid
+int launch_upsample_logits(const float* lo, float* out, int B, int h, int w, int K, int H, int W,
+                           int align_corners, int sigmoid, hipStream_t s);
+
+}  // namespace peanut

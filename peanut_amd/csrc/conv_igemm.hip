@@ -1,0 +1,314 @@
+// Fused convolution (1x1 / 3x3, any stride / dilation) + BatchNorm(eval) + residual + ReLU as an
+// im2col-free implicit GEMM on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// one rounding per product, bit-identical to an fmaf chain -- the arithmetic class of the
+// reference's fp32 PyTorch path).
+//
+// Replaces the reference's conv -> BN -> ReLU module chains:
+//   prediction/mmseg/models/backbones/resnet.py:267-307 (Bottleneck), :591-624 (deep stem),
+//   prediction/mmseg/models/utils/res_layer.py:55-64 (downsample),
+//   prediction/mmseg/models/decode_heads/psp_head.py:39-46,86-93 (PPM 1x1, 3x3 bottleneck),
+//   prediction/mmseg/models/decode_heads/decode_head.py:225-230 (conv_seg).
+//
+// GEMM view:  Y[m][n] = sum_k A[m][k] * Wt[n][k],  m = (b, oy, ox) output pixel, n = out channel,
+// k = (channel chunk, filter tap, channel-in-chunk).  Activations are NHWC so a k-tile of A is, per
+// output pixel, one contiguous BK*4-byte segment of the (shifted) input pixel; out-of-image taps
+// are zero-filled while staging, so nothing like an im2col buffer ever exists in HBM.
+//
+// Tiling (wave64, 4 waves / workgroup):
+//   block tile BM x BN (128 x {128,64,32}), k-tile BK (32; 16 for the 14->16-channel stem conv).
+//   LDS holds A[BM][BK+4] and W[BN][BK+4] (row pad = one 16-B slot -> conflict-free ds_read_b128),
+//   double-buffered; the next k-tile travels HBM/L2 -> VGPR while the current one feeds the MFMAs,
+//   and is written to the other LDS buffer after one barrier per k-tile.
+//   Each lane fetches 4 consecutive k of its row with ONE ds_read_b128 (lanes 0-31 take k 0..3 of
+//   an 8-k group, lanes 32-63 take k 4..7), which feeds 4 MFMA k-steps: the k order inside the
+//   sum is permuted, A and B consistently, which fp32 addition order tolerance covers.
+//   Accumulator map (guide sec. 3): col = lane&31 -> out channel (contiguous in NHWC -> 128-B store
+//   segments), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel.
+//   Workgroup -> tile map is XCD-aware: each XCD (private 4 MiB L2) owns a contiguous run of
+//   tiles, n-tile fastest, so the co-resident workgroups of an XCD share A panels.
+#include "common.h"
+
+namespace peanut {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: no struct memcpy, stays in VGPRs
+
+struct ConvKParams {
+  const float* x;
+  const float* x2;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  int H, W, c1, c2, Ho, Wo, cout;
+  int kw, ntaps, stride, pad, dil, relu;
+  int M, nkt, ntiles, HoWo;
+};
+
+template <int I>
+struct IC { static constexpr int value = I; };
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+struct KIter {
+  int tap, ky, kx, cbase;
+  const float* wtile;
+};
+
+// Issue the global loads of one k-tile (A gathered from the shifted input pixels, W linear) into
+// registers and advance the k-tile iterator.
+template <int BN, int BK, int A_PER, int B_PER>
+__device__ __forceinline__ void load_tiles(const ConvKParams& p, KIter& it, const int (&a_iy0)[A_PER],
+                                           const int (&a_ix0)[A_PER], const int (&a_pix)[A_PER], int a_c4,
+                                           int tid, f32x4 (&ra)[A_PER], f32x4 (&rb)[B_PER]) {
+  constexpr int B_F4 = BN * (BK / 4);
+  const float* src = p.x;
+  int C = p.c1, cb = it.cbase;
+  if (cb >= p.c1) { src = p.x2; cb -= p.c1; C = p.c2; }
+  const int dy = it.ky * p.dil, dx = it.kx * p.dil;
+  static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
+    const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const float* ptr = src + (size_t)(a_pix[j] + iy * p.W + ix) * C + cb + a_c4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4*>(ptr);
+    ra[j] = v;
+  });
+  static_for<B_PER>([&](auto J) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
+    const int idx = tid + 256 * j;
+    if constexpr (B_F4 % 256 == 0) {
+      rb[j] = *reinterpret_cast<const f32x4*>(it.wtile + idx * 4);
+    } else {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < B_F4) v = *reinterpret_cast<const f32x4*>(it.wtile + idx * 4);
+      rb[j] = v;
+    }
+  });
+  it.wtile += BN * BK;
+  if (++it.tap == p.ntaps) { it.tap = 0; it.ky = 0; it.kx = 0; it.cbase += BK; }
+  else if (++it.kx == p.kw) { it.kx = 0; ++it.ky; }
+}
+
+template <int BM, int BN, int BK, int A_PER, int B_PER>
+__device__ __forceinline__ void store_tiles(float* stage, int tid, const f32x4 (&ra)[A_PER],
+                                            const f32x4 (&rb)[B_PER]) {
+  constexpr int KV = BK / 4, LS = BK + 4, A_F4 = BM * KV, B_F4 = BN * KV;
+  static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
+    const int idx = tid + 256 * j;
+    if (A_F4 % 256 == 0 || idx < A_F4)
+      *reinterpret_cast<f32x4*>(stage + (idx / KV) * LS + (idx % KV) * 4) = ra[j];
+  });
+  static_for<B_PER>([&](auto J) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
+    const int idx = tid + 256 * j;
+    if (B_F4 % 256 == 0 || idx < B_F4)
+      *reinterpret_cast<f32x4*>(stage + BM * LS + (idx / KV) * LS + (idx % KV) * 4) = rb[j];
+  });
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
+  constexpr int KV = BK / 4;            // f32x4 per tile row
+  constexpr int LS = BK + 4;            // LDS row stride (floats)
+  constexpr int A_F4 = BM * KV, B_F4 = BN * KV;
+  constexpr int A_PER = (A_F4 + 255) / 256, B_PER = (B_F4 + 255) / 256;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int STAGE = (BM + BN) * LS;  // floats per LDS stage
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is a multiple of the 32x32 MFMA");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  // ---- XCD-aware tile assignment (bijective for any grid size; guide T1) ----
+  int mt, nt;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    mt = L / p.ntiles;
+    nt = L - mt * p.ntiles;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread staging coordinates ----
+  int a_iy0[A_PER], a_ix0[A_PER], a_pix[A_PER];
+  const int a_c4 = (tid % KV) * 4;
+#pragma unroll
+  for (int j = 0; j < A_PER; ++j) {
+    const int idx = tid + 256 * j;
+    const int row = idx / KV;
+    const int m = m0 + row;
+    if (row < BM && m < p.M) {
+      const int b = m / p.HoWo;
+      const int rem = m - b * p.HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[j] = oy * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad;
+      a_pix[j] = b * p.H * p.W;
+    } else {
+      a_iy0[j] = -(1 << 28);  // fails every bounds test -> zero row
+      a_ix0[j] = 0;
+      a_pix[j] = 0;
+    }
+  }
+
+  f32x4 ra[A_PER], rb[B_PER];
+  KIter it;
+  it.tap = 0; it.ky = 0; it.kx = 0; it.cbase = 0;  // channel chunk outer, filter tap inner
+  it.wtile = p.w + (size_t)nt * p.nkt * (BN * BK);
+
+#define PEANUT_LOAD_TILES() load_tiles<BN, BK, A_PER, B_PER>(p, it, a_iy0, a_ix0, a_pix, a_c4, tid, ra, rb)
+#define PEANUT_STORE_TILES(stage) store_tiles<BM, BN, BK, A_PER, B_PER>(stage, tid, ra, rb)
+
+  // ---- MFMA fragment coordinates ----
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  const int a_off = (wm * TM + li) * LS + hi * 4;
+  const int b_off = BM * LS + (wn * TN + li) * LS + hi * 4;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int t = 0; t < MI; ++t)
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  // ---- pipeline prologue ----
+  PEANUT_LOAD_TILES();
+  PEANUT_STORE_TILES(smem);
+  if (p.nkt > 1) PEANUT_LOAD_TILES();
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nkt; ++kt) {
+    const float* cur = smem + (kt & 1) * STAGE;
+    if (kt + 1 < p.nkt) {
+      PEANUT_STORE_TILES(smem + ((kt + 1) & 1) * STAGE);   // k-tile kt+1 (loaded one iteration ago)
+      if (kt + 2 < p.nkt) PEANUT_LOAD_TILES();             // k-tile kt+2 flies during the MFMAs below
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 8; ++ks) {
+      f32x4 af[MI], bf[NI];
+#pragma unroll
+      for (int t = 0; t < MI; ++t) af[t] = *reinterpret_cast<const f32x4*>(cur + a_off + t * 32 * LS + ks * 8);
+#pragma unroll
+      for (int u = 0; u < NI; ++u) bf[u] = *reinterpret_cast<const f32x4*>(cur + b_off + u * 32 * LS + ks * 8);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int t = 0; t < MI; ++t)
+#pragma unroll
+          for (int u = 0; u < NI; ++u) {
+            const float av = kk == 0 ? af[t].x : kk == 1 ? af[t].y : kk == 2 ? af[t].z : af[t].w;
+            const float bv = kk == 0 ? bf[u].x : kk == 1 ? bf[u].y : kk == 2 ? bf[u].z : bf[u].w;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][u], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: y = relu(acc * scale[n] + shift[n] + res) ----
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int n = n0 + wn * TN + u * 32 + li;
+    const float sc = p.scale[n], sh = p.shift[n];
+    const bool nok = n < p.cout;
+#pragma unroll
+    for (int t = 0; t < MI; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (nok && m < p.M) {
+          const size_t o = (size_t)m * p.cout + n;
+          float v = acc[t][u][r] * sc + sh;
+          if (p.res) v += p.res[o];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk) {
+  *bk = (cin_pad % 32 == 0) ? 32 : 16;
+  *bn_tile = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
+}
+
+size_t conv_packed_floats(int cin_pad, int cout, int kh, int kw, int bn_tile) {
+  const int cout_pad = (cout + bn_tile - 1) / bn_tile * bn_tile;
+  return (size_t)cout_pad * kh * kw * cin_pad;
+}
+
+// w_oihw [cout][cin_real][kh][kw]  ->  [ntile][ktile][BN][BK], ktile = chunk * ntaps + tap
+void pack_conv_weights(const float* w, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile,
+                       int bk, float* out) {
+  const int ntaps = kh * kw;
+  const int cout_pad = (cout + bn_tile - 1) / bn_tile * bn_tile;
+  const int nchunks = cin_pad / bk;
+  const int nkt = nchunks * ntaps;
+  for (int n = 0; n < cout_pad; ++n) {
+    const int nt = n / bn_tile, nn = n % bn_tile;
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int tap = 0; tap < ntaps; ++tap) {
+        float* dst = out + (((size_t)nt * nkt + (size_t)ch * ntaps + tap) * bn_tile + nn) * bk;
+        for (int c = 0; c < bk; ++c) {
+          const int ci = ch * bk + c;
+          dst[c] = (n < cout && ci < cin_real) ? w[((size_t)n * cin_real + ci) * ntaps + tap] : 0.f;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_t(const ConvKParams& p, hipStream_t stream) {
+  const int mtiles = (p.M + BM - 1) / BM;
+  const dim3 grid((unsigned)(mtiles * p.ntiles));
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
+  if (a.c1 + a.c2 != d.cin) return fail(-2, "launch_conv: c1 + c2 != cin");
+  if (a.c1 % d.bk != 0 || (a.c2 % d.bk) != 0) return fail(-2, "launch_conv: channel split not a multiple of BK");
+  ConvKParams p;
+  p.x = a.x; p.x2 = a.x2 ? a.x2 : a.x; p.w = d.w_packed; p.scale = d.scale; p.shift = d.shift;
+  p.res = a.res; p.y = a.y;
+  p.H = a.H; p.W = a.W; p.c1 = a.c1; p.c2 = a.c2; p.Ho = a.Ho; p.Wo = a.Wo; p.cout = d.cout;
+  p.kw = d.kw; p.ntaps = d.kh * d.kw; p.stride = d.stride; p.pad = d.pad; p.dil = d.dil; p.relu = d.relu;
+  p.HoWo = a.Ho * a.Wo;
+  const long long M = (long long)a.B * p.HoWo;
+  if (M <= 0 || M > 0x7fffffffLL || (long long)a.B * a.H * a.W > 0x7fffffffLL)
+    return fail(-2, "launch_conv: problem size out of range");
+  p.M = (int)M;
+  p.nkt = (d.cin / d.bk) * p.ntaps;
+  p.ntiles = d.cout_pad / d.bn_tile;
+  if (d.bk == 32) {
+    if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, stream);
+    if (d.bn_tile == 64) return launch_t<128, 64, 32, 2, 2>(p, stream);
+    if (d.bn_tile == 32) return launch_t<128, 32, 32, 4, 1>(p, stream);
+  } else if (d.bk == 16) {
+    if (d.bn_tile == 128) return launch_t<128, 128, 16, 2, 2>(p, stream);
+    if (d.bn_tile == 64) return launch_t<128, 64, 16, 2, 2>(p, stream);
+    if (d.bn_tile == 32) return launch_t<128, 32, 16, 4, 1>(p, stream);
+  }
+  return fail(-2, "launch_conv: unsupported tile configuration");
+}
+
+}  // namespace peanut

@@ -1,0 +1,585 @@
+// C-ABI entry points of the map-prediction forward (see include/peanut_hip.h) and the host-side
+// planner that turns the reference's module graph into one static launch sequence per (B,H,W).
+//
+// Graph followed (reference files under prediction/mmseg/models):
+//   backbones/resnet.py:659-674   stem -> maxpool -> layer1..4
+//   backbones/resnet.py:267-307   Bottleneck: 1x1 -> 3x3(stride,dilation) -> 1x1, (+downsample), add, ReLU
+//   utils/res_layer.py:43-95      first block of a stage: stride + 1x1 downsample, contracted dilation
+//   decode_heads/psp_head.py:48-59,95-117   PPM, concat, 3x3 bottleneck, cls_seg
+//   segmentors/encoder_decoder.py:70-80     final bilinear resize to the input size
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/peanut_hip.h"
+#include "common.h"
+
+namespace peanut {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int ensure(size_t n) {
+    if (n <= bytes) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
+    bytes = n;
+    return 0;
+  }
+};
+
+// A conv layer resident on the device.
+struct ConvLayer {
+  std::string name;
+  ConvDesc d{};
+  int cin_real = 0;
+  DevBuf w, ss;  // packed weights; scale||shift
+};
+
+int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
+                int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu) {
+  if (cin_pad % 16 != 0 || cin_pad < cin) return fail(PEANUT_EINVAL, L.name + ": cin_pad must be a multiple of 16 and >= cin");
+  ConvDesc& d = L.d;
+  d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
+  conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
+  d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
+  L.cin_real = cin;
+  const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);
+  std::vector<float> packed(nw);
+  pack_conv_weights(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.bk, packed.data());
+  std::vector<float> ss(2 * (size_t)d.cout_pad, 0.f);
+  for (int n = 0; n < cout; ++n) {
+    ss[n] = scale ? scale[n] : 1.f;
+    ss[d.cout_pad + n] = shift ? shift[n] : 0.f;
+  }
+  int rc;
+  if ((rc = L.w.ensure(nw * sizeof(float)))) return rc;
+  if ((rc = L.ss.ensure(ss.size() * sizeof(float)))) return rc;
+  PEANUT_HIP_CHECK(hipMemcpy(L.w.p, packed.data(), nw * sizeof(float), hipMemcpyHostToDevice));
+  PEANUT_HIP_CHECK(hipMemcpy(L.ss.p, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
+  d.w_packed = (const float*)L.w.p;
+  d.scale = (const float*)L.ss.p;
+  d.shift = (const float*)L.ss.p + d.cout_pad;
+  return 0;
+}
+
+// ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----
+struct Arena {
+  size_t top = 0;
+  bool keep_all = false;
+  std::vector<std::pair<size_t, size_t>> free_list;  // (offset, size)
+  static size_t round_up(size_t n) { return (n + 255) & ~(size_t)255; }
+  size_t alloc(size_t bytes) {
+    bytes = round_up(bytes);
+    int best = -1;
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = (int)i;
+    if (best >= 0) {
+      const size_t off = free_list[best].first, sz = free_list[best].second;
+      free_list.erase(free_list.begin() + best);
+      if (sz > bytes) free_list.push_back({off + bytes, sz - bytes});
+      return off;
+    }
+    const size_t off = top;
+    top += bytes;
+    return off;
+  }
+  void release(size_t off, size_t bytes) {
+    if (keep_all) return;
+    bytes = round_up(bytes);
+    // coalesce with neighbours so the big stem buffers can be recycled for later stages
+    for (bool merged = true; merged;) {
+      merged = false;
+      for (size_t i = 0; i < free_list.size(); ++i) {
+        if (free_list[i].first + free_list[i].second == off) {
+          off = free_list[i].first; bytes += free_list[i].second;
+          free_list.erase(free_list.begin() + i); merged = true; break;
+        }
+        if (off + bytes == free_list[i].first) {
+          bytes += free_list[i].second;
+          free_list.erase(free_list.begin() + i); merged = true; break;
+        }
+      }
+    }
+    if (off + bytes == top) { top = off; return; }
+    free_list.push_back({off, bytes});
+  }
+};
+
+struct Act {  // an NHWC activation inside the workspace
+  size_t off = 0, bytes = 0;
+  int B = 0, H = 0, W = 0, C = 0;
+};
+
+enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_UPSAMPLE };
+
+struct Op {
+  OpKind kind;
+  std::string name;
+  const ConvLayer* conv = nullptr;
+  Act in, in2, res, out;
+  bool has_in2 = false, has_res = false;
+  double flops = 0;
+};
+
+struct Plan {
+  int B = 0, H = 0, W = 0;
+  bool keep_all = false;
+  size_t bytes = 0;
+  std::vector<Op> ops;
+  std::map<std::string, Act> named;
+};
+
+}  // namespace
+}  // namespace peanut
+
+using namespace peanut;
+
+struct peanut_conv {
+  ConvLayer L;
+};
+
+struct peanut_pred {
+  peanut_pred_cfg cfg{};
+  int cin_pad = 0;
+  std::vector<std::unique_ptr<ConvLayer>> convs;
+  // structure
+  ConvLayer* stem[3] = {nullptr, nullptr, nullptr};
+  struct Block { ConvLayer *c1, *c2, *c3, *down; };
+  std::vector<std::vector<Block>> layers;
+  std::vector<ConvLayer*> ppm;
+  ConvLayer* bottleneck = nullptr;
+  ConvLayer* conv_seg = nullptr;
+  int feat_channels = 0;
+  // runtime
+  bool keep_all = false;
+  std::map<std::string, std::unique_ptr<Plan>> plans;
+  Plan* last_plan = nullptr;
+  DevBuf ws;
+  std::vector<std::string> prof_names;
+};
+
+namespace {
+
+struct TensorMap {
+  std::map<std::string, const peanut_tensor*> m;
+  const peanut_tensor* get(const std::string& k, int ndim, const int64_t* shape, int* rc) const {
+    auto it = m.find(k);
+    if (it == m.end()) { *rc = fail(PEANUT_EWEIGHTS, "state dict is missing '" + k + "'"); return nullptr; }
+    const peanut_tensor* t = it->second;
+    bool ok = t->ndim == ndim && t->data != nullptr;
+    for (int i = 0; ok && i < ndim; ++i) ok = t->shape[i] == shape[i];
+    if (!ok) { *rc = fail(PEANUT_EWEIGHTS, "'" + k + "' has an unexpected shape"); return nullptr; }
+    return t;
+  }
+};
+
+// conv weight + (BatchNorm | bias) -> ConvLayer with folded scale/shift.
+// BN(eval): y = x*alpha + beta, alpha = weight/sqrt(var+eps), beta = bias - mean*alpha  (fp32, the
+// form ATen's CPU batch_norm inference uses).
+int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const std::string& bn, int cin,
+             int cin_pad, int cout, int k, int stride, int pad, int dil, int relu, ConvLayer** out) {
+  int rc = 0;
+  const int64_t wshape[4] = {cout, cin, k, k};
+  const peanut_tensor* w = tm.get(conv + ".weight", 4, wshape, &rc);
+  if (!w) return rc;
+  std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+  const int64_t cshape[1] = {cout};
+  if (!bn.empty()) {
+    const peanut_tensor* g = tm.get(bn + ".weight", 1, cshape, &rc); if (!g) return rc;
+    const peanut_tensor* b = tm.get(bn + ".bias", 1, cshape, &rc); if (!b) return rc;
+    const peanut_tensor* mu = tm.get(bn + ".running_mean", 1, cshape, &rc); if (!mu) return rc;
+    const peanut_tensor* var = tm.get(bn + ".running_var", 1, cshape, &rc); if (!var) return rc;
+    for (int n = 0; n < cout; ++n) {
+      const float invstd = 1.0f / sqrtf(var->data[n] + h->cfg.bn_eps);
+      const float alpha = invstd * g->data[n];
+      scale[n] = alpha;
+      shift[n] = b->data[n] - mu->data[n] * alpha;
+    }
+  } else {
+    const peanut_tensor* b = tm.get(conv + ".bias", 1, cshape, &rc); if (!b) return rc;
+    for (int n = 0; n < cout; ++n) shift[n] = b->data[n];
+  }
+  auto L = std::make_unique<ConvLayer>();
+  L->name = conv;
+  rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu);
+  if (rc) return rc;
+  *out = L.get();
+  h->convs.push_back(std::move(L));
+  return 0;
+}
+
+Act make_act(Arena& a, int B, int H, int W, int C) {
+  Act t;
+  t.B = B; t.H = H; t.W = W; t.C = C;
+  t.bytes = (size_t)B * H * W * C * sizeof(float);
+  t.off = a.alloc(t.bytes);
+  return t;
+}
+
+double conv_flops(const ConvLayer* L, const Act& out) {
+  return 2.0 * (double)out.B * out.H * out.W * L->d.cout * L->cin_real * L->d.kh * L->d.kw;
+}
+
+void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out) {
+  Op op;
+  op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
+  if (in2) { op.in2 = *in2; op.has_in2 = true; }
+  if (res) { op.res = *res; op.has_res = true; }
+  op.flops = conv_flops(L, out);
+  pl.ops.push_back(op);
+}
+
+// Build the static launch sequence + workspace layout for one input shape.
+std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
+  auto pl = std::make_unique<Plan>();
+  pl->B = B; pl->H = H; pl->W = W; pl->keep_all = h->keep_all;
+  Arena ar;
+  ar.keep_all = h->keep_all;
+  auto rel = [&](const Act& t) { ar.release(t.off, t.bytes); };
+
+  // input layout change: NCHW -> NHWC, channels zero-padded to a multiple of 16
+  Act x = make_act(ar, B, H, W, h->cin_pad);
+  { Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.out = x; pl->ops.push_back(op); }
+
+  // deep stem (resnet.py:591-624) + maxpool (:638)
+  for (int i = 0; i < 3; ++i) {
+    const ConvDesc& d = h->stem[i]->d;
+    Act y = make_act(ar, B, conv_out_dim(x.H, d.kh, d.stride, d.pad, d.dil),
+                     conv_out_dim(x.W, d.kw, d.stride, d.pad, d.dil), d.cout);
+    push_conv(*pl, h->stem[i], x, nullptr, nullptr, y);
+    pl->named["stem" + std::to_string(i)] = y;
+    rel(x);
+    x = y;
+  }
+  {
+    Act y = make_act(ar, B, conv_out_dim(x.H, 3, 2, 1, 1), conv_out_dim(x.W, 3, 2, 1, 1), x.C);
+    Op op; op.kind = OP_MAXPOOL; op.name = "maxpool"; op.in = x; op.out = y; pl->ops.push_back(op);
+    pl->named["pool"] = y;
+    rel(x);
+    x = y;
+  }
+  // residual stages
+  for (size_t li = 0; li < h->layers.size(); ++li) {
+    for (const auto& blk : h->layers[li]) {
+      const ConvDesc& d2 = blk.c2->d;
+      Act t1 = make_act(ar, B, x.H, x.W, blk.c1->d.cout);
+      push_conv(*pl, blk.c1, x, nullptr, nullptr, t1);
+      Act t2 = make_act(ar, B, conv_out_dim(x.H, 3, d2.stride, d2.pad, d2.dil),
+                        conv_out_dim(x.W, 3, d2.stride, d2.pad, d2.dil), d2.cout);
+      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2);
+      rel(t1);
+      Act idn = x;
+      bool own_idn = false;
+      if (blk.down) {
+        idn = make_act(ar, B, t2.H, t2.W, blk.down->d.cout);
+        push_conv(*pl, blk.down, x, nullptr, nullptr, idn);
+        own_idn = true;
+      }
+      Act y = make_act(ar, B, t2.H, t2.W, blk.c3->d.cout);
+      push_conv(*pl, blk.c3, t2, nullptr, &idn, y);  // BN3 + identity + ReLU fused (resnet.py:289-305)
+      rel(t2);
+      if (own_idn) rel(idn);
+      rel(x);
+      x = y;
+    }
+    pl->named["layer" + std::to_string(li + 1)] = x;
+  }
+  // PSP head
+  int nbins = 0;
+  for (int i = 0; i < h->cfg.n_pool_scales; ++i) nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
+  Act pooled = make_act(ar, B, 1, nbins, x.C);
+  { Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.in = x; op.out = pooled; pl->ops.push_back(op); }
+  Act table = make_act(ar, B, 1, nbins, h->cfg.head_channels);
+  // pooled/table are SCALE-MAJOR [scale][B][k*k][C] (pspnet_aux.hip: ppm_pool_kernel), so the 1x1 conv
+  // of each scale (psp_head.py:39-46) runs on one contiguous [B*k*k, C] matrix.
+  {
+    size_t row0 = 0;
+    for (int i = 0; i < h->cfg.n_pool_scales; ++i) {
+      const int k = h->cfg.pool_scales[i];
+      Act in = pooled, out = table;
+      in.off = pooled.off + row0 * (size_t)x.C * sizeof(float);
+      in.H = 1; in.W = k * k; in.C = x.C; in.B = B;
+      out.off = table.off + row0 * (size_t)h->cfg.head_channels * sizeof(float);
+      out.H = 1; out.W = k * k; out.C = h->cfg.head_channels; out.B = B;
+      push_conv(*pl, h->ppm[i], in, nullptr, nullptr, out);
+      row0 += (size_t)B * k * k;
+    }
+  }
+  pl->named["ppm_table"] = table;
+  rel(pooled);
+  Act up = make_act(ar, B, x.H, x.W, h->cfg.n_pool_scales * h->cfg.head_channels);
+  { Op op; op.kind = OP_PPM_UP; op.name = "ppm_upsample_concat"; op.in = table; op.out = up; pl->ops.push_back(op); }
+  rel(table);
+  Act bt = make_act(ar, B, x.H, x.W, h->bottleneck->d.cout);
+  push_conv(*pl, h->bottleneck, x, &up, nullptr, bt);  // cat([x, ppm...]) is never materialised for x
+  pl->named["bottleneck"] = bt;
+  rel(up);
+  rel(x);
+  Act lo = make_act(ar, B, bt.H, bt.W, h->conv_seg->d.cout);
+  push_conv(*pl, h->conv_seg, bt, nullptr, nullptr, lo);
+  pl->named["logits_lowres"] = lo;
+  rel(bt);
+  { Op op; op.kind = OP_UPSAMPLE; op.name = "upsample_logits"; op.in = lo; pl->ops.push_back(op); }
+  rel(lo);
+  return pl;   // pl->bytes (high-water mark) is filled in by get_plan
+}
+
+}  // namespace
+
+// The arena's `top` can shrink on release; the planner needs the high-water mark.  Recompute it
+// from the ops (every Act the plan references must fit).
+static size_t plan_high_water(const Plan& pl) {
+  size_t hw = 0;
+  auto upd = [&](const Act& a) { if (a.bytes && a.off + Arena::round_up(a.bytes) > hw) hw = a.off + Arena::round_up(a.bytes); };
+  for (const auto& op : pl.ops) { upd(op.in); upd(op.in2); upd(op.res); upd(op.out); }
+  for (const auto& kv : pl.named) upd(kv.second);
+  return hw;
+}
+
+static Plan* get_plan(peanut_pred* h, int B, int H, int W) {
+  if (B <= 0 || H < 16 || W < 16) { set_error("forward: need B >= 1 and H, W >= 16"); return nullptr; }
+  const std::string key = std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W) + (h->keep_all ? "k" : "");
+  auto it = h->plans.find(key);
+  if (it == h->plans.end()) {
+    auto pl = build_plan(h, B, H, W);
+    pl->bytes = plan_high_water(*pl);
+    it = h->plans.emplace(key, std::move(pl)).first;
+  }
+  return it->second.get();
+}
+
+static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_dev, float* out_dev, int sigmoid,
+                  hipStream_t s) {
+  char* base = (char*)h->ws.p;
+  auto P = [&](const Act& a) { return (float*)(base + a.off); };
+  switch (op.kind) {
+    case OP_TO_NHWC:
+      return launch_nchw_to_nhwc_pad(in_dev, P(op.out), pl.B, h->cfg.in_channels, pl.H, pl.W, h->cin_pad, s);
+    case OP_CONV: {
+      ConvArgs a{};
+      a.x = P(op.in);
+      a.x2 = op.has_in2 ? P(op.in2) : nullptr;
+      a.res = op.has_res ? P(op.res) : nullptr;
+      a.y = P(op.out);
+      a.B = op.in.B; a.H = op.in.H; a.W = op.in.W;
+      a.c1 = op.in.C; a.c2 = op.has_in2 ? op.in2.C : 0;
+      a.Ho = op.out.H; a.Wo = op.out.W;
+      return launch_conv(op.conv->d, a, s);
+    }
+    case OP_MAXPOOL:
+      return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
+    case OP_PPM_POOL:
+      return launch_ppm_pool(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, h->cfg.pool_scales,
+                             h->cfg.n_pool_scales, s);
+    case OP_PPM_UP:
+      return launch_ppm_upsample_concat(P(op.in), P(op.out), op.out.B, op.out.H, op.out.W, h->cfg.head_channels,
+                                        h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s);
+    case OP_UPSAMPLE:
+      return launch_upsample_logits(P(op.in), out_dev, op.in.B, op.in.H, op.in.W, op.in.C, pl.H, pl.W,
+                                    h->cfg.align_corners, sigmoid, s);
+  }
+  return fail(PEANUT_EINVAL, "unknown op");
+}
+
+extern "C" {
+
+const char* peanut_last_error(void) { return g_err.c_str(); }
+int peanut_abi_version(void) { return 1; }
+const char* peanut_build_arch(void) { return "gfx950"; }
+
+int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
+  if (!out || !cfg || (!tensors && n > 0)) return fail(PEANUT_EINVAL, "peanut_pred_create: null argument");
+  if (cfg->n_pool_scales < 1 || cfg->n_pool_scales > 8) return fail(PEANUT_EINVAL, "n_pool_scales must be 1..8");
+  if (cfg->in_channels < 1 || cfg->num_classes < 1 || cfg->num_classes > 32)
+    return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
+  if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
+  auto h = std::make_unique<peanut_pred>();
+  h->cfg = *cfg;
+  h->cin_pad = (cfg->in_channels + 15) / 16 * 16;
+  TensorMap tm;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
+  int rc;
+  // stem (resnet.py:591-624): 3x3 s2 -> 3x3 -> 3x3, stem_channels = 64
+  const int sc = 64;
+  if ((rc = add_conv(h.get(), tm, "backbone.stem.0", "backbone.stem.1", cfg->in_channels, h->cin_pad, sc / 2, 3, 2, 1, 1, 1, &h->stem[0]))) return rc;
+  if ((rc = add_conv(h.get(), tm, "backbone.stem.3", "backbone.stem.4", sc / 2, sc / 2, sc / 2, 3, 1, 1, 1, 1, &h->stem[1]))) return rc;
+  if ((rc = add_conv(h.get(), tm, "backbone.stem.6", "backbone.stem.7", sc / 2, sc / 2, sc, 3, 1, 1, 1, 1, &h->stem[2]))) return rc;
+  const int stage_blocks[4] = {3, 4, 6, 3};  // ResNet.arch_settings[50] (resnet.py:386-392)
+  int inplanes = sc;
+  for (int li = 0; li < 4; ++li) {
+    const int planes = 64 << li, stride = cfg->strides[li], dilation = cfg->dilations[li];
+    if (stride < 1 || dilation < 1) return fail(PEANUT_EINVAL, "strides/dilations must be >= 1");
+    const int first_dil = (dilation > 1 && cfg->contract_dilation) ? dilation / 2 : dilation;  // res_layer.py:67-74
+    std::vector<peanut_pred::Block> blocks;
+    for (int bi = 0; bi < stage_blocks[li]; ++bi) {
+      const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      const int s = bi == 0 ? stride : 1, d = bi == 0 ? first_dil : dilation;
+      peanut_pred::Block b{nullptr, nullptr, nullptr, nullptr};
+      if ((rc = add_conv(h.get(), tm, p + ".conv1", p + ".bn1", inplanes, inplanes, planes, 1, 1, 0, 1, 1, &b.c1))) return rc;
+      if ((rc = add_conv(h.get(), tm, p + ".conv2", p + ".bn2", planes, planes, planes, 3, s, d, d, 1, &b.c2))) return rc;
+      // conv3: BN only; the block's final ReLU follows the residual add and is fused here
+      if ((rc = add_conv(h.get(), tm, p + ".conv3", p + ".bn3", planes, planes, planes * 4, 1, 1, 0, 1, 1, &b.c3))) return rc;
+      if (bi == 0 && (stride != 1 || inplanes != planes * 4)) {
+        if ((rc = add_conv(h.get(), tm, p + ".downsample.0", p + ".downsample.1", inplanes, inplanes, planes * 4, 1, stride, 0, 1, 0, &b.down))) return rc;
+      }
+      blocks.push_back(b);
+      inplanes = planes * 4;
+    }
+    h->layers.push_back(blocks);
+  }
+  h->feat_channels = inplanes;
+  const int hc = cfg->head_channels;
+  for (int i = 0; i < cfg->n_pool_scales; ++i) {
+    if (cfg->pool_scales[i] < 1) return fail(PEANUT_EINVAL, "pool_scales must be >= 1");
+    const std::string p = "decode_head.psp_modules." + std::to_string(i) + ".1";
+    ConvLayer* L;
+    if ((rc = add_conv(h.get(), tm, p + ".conv", p + ".bn", inplanes, inplanes, hc, 1, 1, 0, 1, 1, &L))) return rc;
+    h->ppm.push_back(L);
+  }
+  const int cat = inplanes + cfg->n_pool_scales * hc;
+  if ((rc = add_conv(h.get(), tm, "decode_head.bottleneck.conv", "decode_head.bottleneck.bn", cat, cat, hc, 3, 1, 1, 1, 1, &h->bottleneck))) return rc;
+  if ((rc = add_conv(h.get(), tm, "decode_head.conv_seg", "", hc, hc, cfg->num_classes, 1, 1, 0, 1, 0, &h->conv_seg))) return rc;
+  PEANUT_HIP_CHECK(hipDeviceSynchronize());
+  *out = h.release();
+  return 0;
+}
+
+void peanut_pred_destroy(peanut_pred_t* h) { delete h; }
+
+size_t peanut_pred_workspace_bytes(peanut_pred_t* h, int B, int H, int W) {
+  if (!h) return 0;
+  Plan* pl = get_plan(h, B, H, W);
+  return pl ? pl->bytes : 0;
+}
+
+double peanut_pred_flops_per_map(peanut_pred_t* h, int H, int W) {
+  if (!h) return 0;
+  Plan* pl = get_plan(h, 1, H, W);
+  if (!pl) return 0;
+  double f = 0;
+  for (const auto& op : pl->ops) f += op.flops;
+  return f;
+}
+
+int peanut_pred_debug_keep(peanut_pred_t* h, int keep) {
+  if (!h) return fail(PEANUT_EINVAL, "null handle");
+  h->keep_all = keep != 0;
+  return 0;
+}
+
+int peanut_pred_debug_tensor(peanut_pred_t* h, const char* name, const float** dev_out, int dims[4]) {
+  if (!h || !name || !dev_out || !dims) return fail(PEANUT_EINVAL, "null argument");
+  if (!h->last_plan || !h->last_plan->keep_all) return fail(PEANUT_EINVAL, "debug_tensor: run a forward after peanut_pred_debug_keep(h, 1)");
+  auto it = h->last_plan->named.find(name);
+  if (it == h->last_plan->named.end()) return fail(PEANUT_EINVAL, std::string("unknown tensor '") + name + "'");
+  const Act& a = it->second;
+  *dev_out = (const float*)((char*)h->ws.p + a.off);
+  dims[0] = a.B; dims[1] = a.H; dims[2] = a.W; dims[3] = a.C;
+  return 0;
+}
+
+int peanut_pred_debug_read(peanut_pred_t* h, const char* name, float* dst_dev, size_t max_floats, int dims[4],
+                           void* stream) {
+  const float* src = nullptr;
+  int rc = peanut_pred_debug_tensor(h, name, &src, dims);
+  if (rc || !dst_dev) return rc;
+  const size_t n = (size_t)dims[0] * dims[1] * dims[2] * dims[3];
+  if (n > max_floats) return fail(PEANUT_EINVAL, "debug_read: destination too small");
+  PEANUT_HIP_CHECK(hipMemcpyAsync(dst_dev, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W, int apply_sigmoid,
+                        void* stream) {
+  if (!h || !in_dev || !out_dev) return fail(PEANUT_EINVAL, "peanut_pred_forward: null argument");
+  Plan* pl = get_plan(h, B, H, W);
+  if (!pl) return PEANUT_EINVAL;
+  int rc;
+  if ((rc = h->ws.ensure(pl->bytes))) return rc;
+  h->last_plan = pl;
+  hipStream_t s = (hipStream_t)stream;
+  for (const auto& op : pl->ops)
+    if ((rc = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, s))) return rc;
+  return 0;
+}
+
+int peanut_pred_profile(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W, void* stream,
+                        const char** names, float* ms, double* flops, int max_ops) {
+  if (!h || !in_dev || !out_dev) return fail(PEANUT_EINVAL, "peanut_pred_profile: null argument");
+  Plan* pl = get_plan(h, B, H, W);
+  if (!pl) return PEANUT_EINVAL;
+  int rc;
+  if ((rc = h->ws.ensure(pl->bytes))) return rc;
+  h->last_plan = pl;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)pl->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) PEANUT_HIP_CHECK(hipEventCreate(&e));
+  PEANUT_HIP_CHECK(hipEventRecord(ev[0], s));
+  for (int i = 0; i < n; ++i) {
+    if ((rc = run_op(h, *pl, pl->ops[i], in_dev, out_dev, 0, s))) return rc;
+    PEANUT_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+  }
+  PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+  h->prof_names.clear();
+  for (int i = 0; i < n; ++i) h->prof_names.push_back(pl->ops[i].name);
+  for (int i = 0; i < n && i < max_ops; ++i) {
+    float t = 0;
+    PEANUT_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+    if (ms) ms[i] = t;
+    if (flops) flops[i] = pl->ops[i].flops;
+    if (names) names[i] = h->prof_names[i].c_str();
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return n;
+}
+
+// ---- operator-level conv ----
+int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, const float* shift, int cout, int cin,
+                       int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu) {
+  if (!out || !w) return fail(PEANUT_EINVAL, "peanut_conv_create: null argument");
+  if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
+    return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
+  auto c = std::make_unique<peanut_conv>();
+  c->L.name = "conv";
+  int rc = upload_conv(c->L, w, scale, shift, cout, cin, cin_pad, kh, kw, stride, pad, dil, relu);
+  if (rc) return rc;
+  PEANUT_HIP_CHECK(hipDeviceSynchronize());
+  *out = c.release();
+  return 0;
+}
+
+void peanut_conv_destroy(peanut_conv_t* c) { delete c; }
+
+int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c1, const float* res, float* y, int B,
+                        int H, int W, void* stream) {
+  if (!c || !x || !y) return fail(PEANUT_EINVAL, "peanut_conv_forward: null argument");
+  const ConvDesc& d = c->L.d;
+  ConvArgs a{};
+  a.x = x; a.x2 = x2; a.res = res; a.y = y; a.B = B; a.H = H; a.W = W;
+  a.c1 = x2 ? c1 : d.cin;
+  a.c2 = x2 ? d.cin - c1 : 0;
+  a.Ho = conv_out_dim(H, d.kh, d.stride, d.pad, d.dil);
+  a.Wo = conv_out_dim(W, d.kw, d.stride, d.pad, d.dil);
+  if (a.Ho < 1 || a.Wo < 1) return fail(PEANUT_EINVAL, "peanut_conv_forward: empty output");
+  return launch_conv(d, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/peanut_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from peanut_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if not fn.endswith(".h"):
+            continue
+        src = open(os.path.join(inc, fn)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(peanut_[a-z0-9_]+)\s*\(", src):
+            names.add(m.group(1))
+    return names
+
+
+def test_library_builds_and_loads():
+    path = build.build()
+    assert os.path.exists(path)
+    lib = _lib.load()
+    assert lib.peanut_abi_version() >= 1
+    assert lib.peanut_build_arch() == b"gfx950"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    build.build()
+    lib = ctypes.CDLL(build.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    # the python binding table covers exactly the declared ABI
+    assert set(_lib.SIGNATURES) == declared
+
+
+def test_code_object_is_gfx950_only():
+    build.build()
+    blob = open(build.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):
+        assert other not in blob
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setenv("PEANUT_HIP_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(_lib.PeanutHipError):
+        _lib.load()
+
+
+def test_product_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    from types import SimpleNamespace
+    with pytest.raises(_lib.PeanutHipError):
+        PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(PredCfg(), 0))

@@ -1,0 +1,83 @@
+"""Parity of the fused implicit-GEMM conv kernel (through the C ABI) against a plain PyTorch fp32
+CPU convolution of the same operator.  Tolerance: fp32 MFMA is an exact-fp32 fma chain, so the only
+difference to ATen's CPU kernels is summation order: |err| <= 2e-5 * (1 + |ref|) at these K."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (B, H, W, cin, cout, k, stride, pad, dil, relu, residual)
+    (2, 24, 24, 14, 32, 3, 2, 1, 1, True, False),     # stem.0: 14->pad16, BK=16, BN=32, stride 2
+    (1, 30, 30, 32, 32, 3, 1, 1, 1, True, False),     # stem.3
+    (1, 30, 30, 32, 64, 3, 1, 1, 1, True, False),     # stem.6 (BN=64)
+    (2, 15, 15, 64, 256, 1, 1, 0, 1, False, True),    # layer1 conv3 + identity + relu
+    (1, 31, 29, 256, 128, 1, 1, 0, 1, True, False),   # ragged M (899 rows)
+    (2, 20, 20, 128, 128, 3, 2, 1, 1, True, False),   # layer2.0 conv2 (stride 2)
+    (2, 17, 17, 256, 512, 1, 2, 0, 1, False, False),  # strided 1x1 downsample
+    (1, 15, 15, 256, 256, 3, 1, 2, 2, True, False),   # dilation 2
+    (1, 15, 15, 512, 512, 3, 1, 4, 4, True, False),   # dilation 4 (halo > tile)
+    (3, 13, 13, 512, 6, 1, 1, 0, 1, False, False),    # conv_seg: cout=6 (padded to 32 internally)
+    (1, 1, 36, 2048, 512, 1, 1, 0, 1, True, False),   # PPM 1x1 on pooled bins, tiny M
+]
+
+
+def _rand(shape, g, scale=1.0):
+    return torch.randn(shape, generator=g, dtype=torch.float32) * scale
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[:9])))
+def test_conv_matches_torch(case):
+    from peanut_amd.ops import FusedConv, to_nhwc_padded, round_up
+    B, H, W, cin, cout, k, s, p, d, relu, residual = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d) * scale[None, :, None, None] \
+        + shift[None, :, None, None]
+    res = None
+    if residual:
+        res = _rand(tuple(ref.shape), g)
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu)
+    xd = to_nhwc_padded(x.cuda(), round_up(cin, 16))
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+    y = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
+    assert y.shape == ref.shape
+    err = (y - ref).abs()
+    tol = 2e-5 * (1 + ref.abs())
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}"
+
+
+def test_conv_two_source_concat():
+    """K range split over two tensors (cat([x, ppm]) never materialised, psp_head.py:107-110)."""
+    from peanut_amd.ops import FusedConv
+    g = torch.Generator().manual_seed(7)
+    B, H, W, c1, c2, cout = 2, 12, 12, 64, 96, 128
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 3, 3), g, 0.05)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w, None, padding=1))
+    conv = FusedConv(w, None, None, padding=1, relu=True)
+    y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda())
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+    assert err < 5e-5, err
+
+
+def test_conv_transpose_detecting():
+    """Asymmetric one-hot probes: catches swapped rows/cols in the accumulator write-back."""
+    from peanut_amd.ops import FusedConv
+    cin, cout, H, W = 32, 64, 8, 16
+    x = torch.zeros(1, cin, H, W)
+    x[0, 3, 2, 5] = 1.0
+    x[0, 17, 7, 11] = 2.0
+    w = torch.zeros(cout, cin, 1, 1)
+    w[40, 3] = 1.0
+    w[9, 17] = 3.0
+    ref = F.conv2d(x, w)
+    y = FusedConv(w)(x.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(y, ref)
