@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): maps/sec of the 480x480x(4+N_cat) map-prediction forward at
+batch 32 per GPU, data-parallel over N GPUs of one node (weak scaling, no data-path collective).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (NCHW map batch resident in HBM -> NCHW probabilities in HBM)
+over one batch of synthetic maps.  Rank 0 prints ONE JSON line.
+`roofline` is measured live with HIP events recorded inside the timed region on the launch stream
+(peanut_pred_probe_*); `cpu_baseline` times the oracle restatement of the reference's fp32 PyTorch
+path on this box's host cores (rank 0, N=1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from peanut_amd import dist as pdist  # noqa: E402
+from peanut_amd.weights import PredCfg, conv_flops_per_map, make_seeded_state_dict  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+METRIC = "maps/sec for 480x480x(4+N_cat) prediction fwd, batch 32"
+
+
+def synth_maps(b: int, c: int, s: int, device, seed0: int = 0) -> torch.Tensor:
+    """Synthetic partial maps in the spirit of SURVEY.md sec. 8d config 2 (values in {0,1} like the
+    reference's thresholded maps): ch 0/1 (obstacle / explored) = Bernoulli(0.015) seeds dilated by
+    a 5x5 max-pool (~31 % coverage), ch 2-3 = one 5x5 square (agent location), ch 4.. = category
+    blobs from Bernoulli(0.001) seeds dilated 5x5 (~2.5 % coverage); seed = global map index."""
+    out = torch.zeros((b, c, s, s), dtype=torch.float32, device=device)
+    for i in range(b):
+        g = torch.Generator(device="cpu").manual_seed(seed0 + i)
+        occ = (torch.rand((1, 2, s, s), generator=g) < 0.3 * 0.05).float()
+        out[i, 0:2] = torch.nn.functional.max_pool2d(occ, 5, 1, 2)[0].to(device)
+        cy, cx = (int(v) for v in torch.randint(8, s - 8, (2,), generator=g))
+        out[i, 2:4, cy - 2:cy + 3, cx - 2:cx + 3] = 1.0
+        if c > 4:
+            cat = (torch.rand((1, c - 4, s, s), generator=g) < 0.02 * 0.05).float()
+            out[i, 4:] = torch.nn.functional.max_pool2d(cat, 5, 1, 2)[0].to(device)
+    return out
+
+
+def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 20.0, max_maps: int = 8):
+    """Oracle (= bit-exact restatement of the reference's CPU PyTorch path) on the host cores."""
+    from oracle import pspnet_ref
+    threads = torch.get_num_threads()
+    x = synth_maps(1, cfg.in_channels, s, "cpu", seed0=10_000)
+    pspnet_ref.forward_batch(sd, x, cfg)                      # warm-up (oneDNN primitive cache)
+    n, t0 = 0, time.perf_counter()
+    while n < max_maps and (time.perf_counter() - t0 < budget_s or n < 2):
+        pspnet_ref.forward_batch(sd, x, cfg)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "maps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} x [1,{cfg.in_channels},{s},{s}] fp32 forwards after 1 warm-up, "
+                      f"torch {torch.__version__} CPU, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="maps per GPU per step")
+    ap.add_argument("--size", type=int, default=480)
+    ap.add_argument("--channels", type=int, default=14, help="4 + N_cat input channels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the per-op HIP-event probe")
+    ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) here")
+    args = ap.parse_args()
+
+    rank, local_rank, world = pdist.init_process_group()
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    cfg = PredCfg(in_channels=args.channels)
+    sd = make_seeded_state_dict(cfg, seed=0)
+    model = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=dev.index), state_dict=sd, cfg=cfg)
+    B, S = args.batch, args.size
+    # this rank's shard of the global batch (weak scaling: B maps per GPU)
+    x = synth_maps(B, cfg.in_channels, S, dev, seed0=rank * B)
+    out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=dev)
+
+    for _ in range(args.warmup):
+        model.get_prediction_batch(x, apply_sigmoid=True, out=out)
+    torch.cuda.synchronize()
+    if not args.no_probe:
+        model.model.probe_enable(True)
+    pdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.get_prediction_batch(x, apply_sigmoid=True, out=out)
+    torch.cuda.synchronize()
+    pdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = pdist.max_over_ranks(elapsed, device=dev)
+
+    roof = None
+    if not args.no_probe:
+        nf, rows = model.model.probe_collect()
+        model.model.probe_enable(False)
+        fam = {}
+        for name, kern, ms, fl in rows:
+            f = fam.setdefault(kern, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            f["ms"] += ms
+            f["flops"] += fl * nf
+            f["launches"] += nf
+        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        k, f = dom
+        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": f["launches"] // max(nf, 1),
+                "avg_launch_ms": round(f["ms"] / max(f["launches"], 1), 4),
+                "flops_per_launch": f["flops"] / max(f["launches"], 1),
+                "share_of_step_time": round(f["ms"] / max(sum(v["ms"] for v in fam.values()), 1e-9), 4)}
+        if args.op_table and rank == 0:
+            with open(args.op_table, "w") as fh:
+                json.dump({"forwards": nf, "B": B, "S": S,
+                           "ops": [{"op": n_, "kernel": k_, "ms": ms / nf, "gflop": fl / 1e9,
+                                    "tflops": (fl / (ms / nf * 1e-3) / 1e12) if ms > 0 and fl > 0 else None}
+                                   for n_, k_, ms, fl in rows],
+                           "families": {k_: {"ms_per_step": v["ms"] / nf, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None}
+                                        for k_, v in fam.items()}}, fh, indent=1)
+
+    # logging-only collective: collate the predicted maps of the last step (untimed)
+    gather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        allmaps = pdist.allgather_maps(out)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert allmaps.shape[0] == world * B
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd, S)
+
+    if rank == 0:
+        total_maps = world * B * args.steps
+        value = total_maps / elapsed
+        line = {
+            "metric": METRIC, "value": round(value, 3), "unit": "maps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S}x{S}, {cfg.in_channels}-channel (4+{cfg.in_channels - 4}) partial maps -> "
+                                   f"{cfg.num_classes}-class prediction forward (PSPNet R50-V1c-D8), "
+                                   f"batch {B} per GPU, seeded random-init weights",
+                       "global_batch": world * B, "parallelism": f"dp{world} (map shards, no data-path collective)"},
+            "gflop_per_map": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
+            "whole_forward_tflops": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if gather_ms is not None:
+            line["allgather_maps_ms"] = round(gather_ms, 3)
+        print(json.dumps(line), flush=True)
+    pdist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

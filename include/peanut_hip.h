@@ -95,11 +95,15 @@ int peanut_pred_debug_tensor(peanut_pred_t* h, const char* name, const float** d
 int peanut_pred_debug_read(peanut_pred_t* h, const char* name, float* dst_dev, size_t max_floats, int dims[4],
                            void* stream);
 
-/* Per-op timing of the last-planned shape: runs every launch of one forward bracketed by HIP
- * events on `stream` (synchronises).  Writes up to max_ops entries; returns the op count.
- * names[i] points to storage owned by the handle. */
-int peanut_pred_profile(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W,
-                        void* stream, const char** names, float* ms, double* flops, int max_ops);
+/* Event probe (used by bench.py for the roofline figure): while enabled, every forward records a
+ * HIP event before/after each launch ON THE STREAM THE KERNELS RUN ON.  collect() synchronises
+ * on those events, sums each op's elapsed time over all forwards since the last collect and
+ * clears the probe.  names/kernels point to storage owned by the handle (valid until the plan
+ * is dropped); kernels[i] is the kernel family op i launches (e.g. "conv_igemm_128x128x32");
+ * flops[i] = algorithmic FLOPs of one launch of op i.  Returns the op count. */
+int peanut_pred_probe_enable(peanut_pred_t* h, int enable);
+int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names, const char** kernels,
+                              double* ms_sum, double* flops, int* n_forwards);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level export: one fused conv (+BN scale/shift, +residual, +ReLU) on NHWC fp32.

@@ -50,8 +50,9 @@ SIGNATURES = {
     "peanut_pred_debug_keep": (C.c_int, [_P, C.c_int]),
     "peanut_pred_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int * 4)]),
     "peanut_pred_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int * 4), _P]),
-    "peanut_pred_profile": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_char_p),
-                                      C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int]),
+    "peanut_pred_probe_enable": (C.c_int, [_P, C.c_int]),
+    "peanut_pred_probe_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 9),
     "peanut_conv_destroy": (None, [_P]),
     "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

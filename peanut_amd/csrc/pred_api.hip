@@ -131,6 +131,7 @@ enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_UPSAMP
 struct Op {
   OpKind kind;
   std::string name;
+  std::string kernel;   // kernel symbol family the op launches (groups ops in profiles)
   const ConvLayer* conv = nullptr;
   Act in, in2, res, out;
   bool has_in2 = false, has_res = false;
@@ -171,7 +172,15 @@ struct peanut_pred {
   std::map<std::string, std::unique_ptr<Plan>> plans;
   Plan* last_plan = nullptr;
   DevBuf ws;
-  std::vector<std::string> prof_names;
+  // event probe (bench.py roofline): per-op HIP events recorded inside forward
+  bool probe = false;
+  Plan* probe_plan = nullptr;
+  std::vector<std::vector<hipEvent_t>> probe_events;  // one vector (n_ops + 1 events) per forward
+  std::vector<hipEvent_t> event_pool;
+  ~peanut_pred() {
+    for (auto& v : probe_events) for (auto e : v) (void)hipEventDestroy(e);
+    for (auto e : event_pool) (void)hipEventDestroy(e);
+  }
 };
 
 namespace {
@@ -239,6 +248,7 @@ double conv_flops(const ConvLayer* L, const Act& out) {
 void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out) {
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
+  op.kernel = "conv_igemm_128x" + std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
@@ -255,7 +265,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
 
   // input layout change: NCHW -> NHWC, channels zero-padded to a multiple of 16
   Act x = make_act(ar, B, H, W, h->cin_pad);
-  { Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.out = x; pl->ops.push_back(op); }
+  { Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.kernel = "nchw_to_nhwc"; op.out = x; pl->ops.push_back(op); }
 
   // deep stem (resnet.py:591-624) + maxpool (:638)
   for (int i = 0; i < 3; ++i) {
@@ -269,7 +279,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   }
   {
     Act y = make_act(ar, B, conv_out_dim(x.H, 3, 2, 1, 1), conv_out_dim(x.W, 3, 2, 1, 1), x.C);
-    Op op; op.kind = OP_MAXPOOL; op.name = "maxpool"; op.in = x; op.out = y; pl->ops.push_back(op);
+    Op op; op.kind = OP_MAXPOOL; op.name = "maxpool"; op.kernel = "maxpool"; op.in = x; op.out = y; pl->ops.push_back(op);
     pl->named["pool"] = y;
     rel(x);
     x = y;
@@ -304,7 +314,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   int nbins = 0;
   for (int i = 0; i < h->cfg.n_pool_scales; ++i) nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
   Act pooled = make_act(ar, B, 1, nbins, x.C);
-  { Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.in = x; op.out = pooled; pl->ops.push_back(op); }
+  { Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.kernel = "ppm_pool"; op.in = x; op.out = pooled; pl->ops.push_back(op); }
   Act table = make_act(ar, B, 1, nbins, h->cfg.head_channels);
   // pooled/table are SCALE-MAJOR [scale][B][k*k][C] (pspnet_aux.hip: ppm_pool_kernel), so the 1x1 conv
   // of each scale (psp_head.py:39-46) runs on one contiguous [B*k*k, C] matrix.
@@ -324,7 +334,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   pl->named["ppm_table"] = table;
   rel(pooled);
   Act up = make_act(ar, B, x.H, x.W, h->cfg.n_pool_scales * h->cfg.head_channels);
-  { Op op; op.kind = OP_PPM_UP; op.name = "ppm_upsample_concat"; op.in = table; op.out = up; pl->ops.push_back(op); }
+  { Op op; op.kind = OP_PPM_UP; op.name = "ppm_upsample_concat"; op.kernel = "ppm_upsample_concat"; op.in = table; op.out = up; pl->ops.push_back(op); }
   rel(table);
   Act bt = make_act(ar, B, x.H, x.W, h->bottleneck->d.cout);
   push_conv(*pl, h->bottleneck, x, &up, nullptr, bt);  // cat([x, ppm...]) is never materialised for x
@@ -335,7 +345,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   push_conv(*pl, h->conv_seg, bt, nullptr, nullptr, lo);
   pl->named["logits_lowres"] = lo;
   rel(bt);
-  { Op op; op.kind = OP_UPSAMPLE; op.name = "upsample_logits"; op.in = lo; pl->ops.push_back(op); }
+  { Op op; op.kind = OP_UPSAMPLE; op.name = "upsample_logits"; op.kernel = "upsample_logits"; op.in = lo; pl->ops.push_back(op); }
   rel(lo);
   return pl;   // pl->bytes (high-water mark) is filled in by get_plan
 }
@@ -515,39 +525,58 @@ int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, i
   if ((rc = h->ws.ensure(pl->bytes))) return rc;
   h->last_plan = pl;
   hipStream_t s = (hipStream_t)stream;
-  for (const auto& op : pl->ops)
-    if ((rc = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, s))) return rc;
+  if (!h->probe) {
+    for (const auto& op : pl->ops)
+      if ((rc = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, s))) return rc;
+    return 0;
+  }
+  if (h->probe_plan && h->probe_plan != pl) return fail(PEANUT_EINVAL, "probe: shape changed while probing; collect first");
+  h->probe_plan = pl;
+  std::vector<hipEvent_t> ev(pl->ops.size() + 1);
+  for (auto& e : ev) {
+    if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+    else PEANUT_HIP_CHECK(hipEventCreate(&e));
+  }
+  PEANUT_HIP_CHECK(hipEventRecord(ev[0], s));
+  for (size_t i = 0; i < pl->ops.size(); ++i) {
+    if ((rc = run_op(h, *pl, pl->ops[i], in_dev, out_dev, apply_sigmoid, s))) return rc;
+    PEANUT_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+  }
+  h->probe_events.push_back(std::move(ev));
   return 0;
 }
 
-int peanut_pred_profile(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W, void* stream,
-                        const char** names, float* ms, double* flops, int max_ops) {
-  if (!h || !in_dev || !out_dev) return fail(PEANUT_EINVAL, "peanut_pred_profile: null argument");
-  Plan* pl = get_plan(h, B, H, W);
-  if (!pl) return PEANUT_EINVAL;
-  int rc;
-  if ((rc = h->ws.ensure(pl->bytes))) return rc;
-  h->last_plan = pl;
-  hipStream_t s = (hipStream_t)stream;
+int peanut_pred_probe_enable(peanut_pred_t* h, int enable) {
+  if (!h) return fail(PEANUT_EINVAL, "null handle");
+  h->probe = enable != 0;
+  return 0;
+}
+
+int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names, const char** kernels, double* ms_sum,
+                              double* flops, int* n_forwards) {
+  if (!h) return fail(PEANUT_EINVAL, "null handle");
+  Plan* pl = h->probe_plan;
+  if (!pl || h->probe_events.empty()) { if (n_forwards) *n_forwards = 0; return 0; }
   const int n = (int)pl->ops.size();
-  std::vector<hipEvent_t> ev(n + 1);
-  for (auto& e : ev) PEANUT_HIP_CHECK(hipEventCreate(&e));
-  PEANUT_HIP_CHECK(hipEventRecord(ev[0], s));
-  for (int i = 0; i < n; ++i) {
-    if ((rc = run_op(h, *pl, pl->ops[i], in_dev, out_dev, 0, s))) return rc;
-    PEANUT_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+  std::vector<double> sum(n, 0.0);
+  for (auto& ev : h->probe_events) {
+    PEANUT_HIP_CHECK(hipEventSynchronize(ev.back()));
+    for (int i = 0; i < n; ++i) {
+      float t = 0;
+      PEANUT_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      sum[i] += t;
+    }
+    for (auto e : ev) h->event_pool.push_back(e);
   }
-  PEANUT_HIP_CHECK(hipStreamSynchronize(s));
-  h->prof_names.clear();
-  for (int i = 0; i < n; ++i) h->prof_names.push_back(pl->ops[i].name);
+  if (n_forwards) *n_forwards = (int)h->probe_events.size();
+  h->probe_events.clear();
+  h->probe_plan = nullptr;
   for (int i = 0; i < n && i < max_ops; ++i) {
-    float t = 0;
-    PEANUT_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
-    if (ms) ms[i] = t;
+    if (names) names[i] = pl->ops[i].name.c_str();
+    if (kernels) kernels[i] = pl->ops[i].kernel.c_str();
+    if (ms_sum) ms_sum[i] = sum[i];
     if (flops) flops[i] = pl->ops[i].flops;
-    if (names) names[i] = h->prof_names[i].c_str();
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   return n;
 }
 

@@ -200,8 +200,7 @@ int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int
   if (nscales > 8 || Cp % 4) return fail(-2, "ppm_upsample: unsupported configuration");
   PpmScales sc;
   sc.n = nscales;
-  int nbins = 0;
-  for (int i = 0; i < nscales; ++i) { sc.s[i] = scales[i]; nbins += scales[i] * scales[i]; }
+  for (int i = 0; i < nscales; ++i) sc.s[i] = scales[i];
   const long long total = (long long)B * H * W * nscales * (Cp / 4);
   hipLaunchKernelGGL(ppm_upsample_concat_kernel, dim3(grid_for(total)), dim3(256), 0, s, table, out, H, W, Cp, sc,
                      B, align_corners, total);

@@ -1,0 +1,91 @@
+"""Multi-GPU layer of the hot path: one process per GPU, maps / episodes sharded data-parallel,
+no collective on the data path.  The only collective is an all-gather of predicted maps to
+collate them for logging (BASELINE.json north_star), over RCCL/xGMI (``backend='nccl'`` on ROCm)
+or gloo on CPU for tests.
+
+The reference shards by hand with ``--start_ep/--end_ep/--sem_gpu_id`` (nav/arguments.py:15-20,
+nav/collect.py:37-39,50) and never communicates; :func:`shard_range` reproduces that partition.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the env if WORLD_SIZE > 1.  ``nccl`` (= RCCL) when a GPU
+    is visible, else ``gloo``.  Binds this process to GPU ``LOCAL_RANK``."""
+    rank, local_rank, world = env_rank_world()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, end) slice of ``n_items`` units (maps of a batch, or episodes) owned by
+    ``rank`` -- the ``--start_ep/--end_ep`` partition; the first ``n_items % world`` ranks get
+    one extra unit, empty shards are allowed when world > n_items."""
+    if n_items < 0 or world < 1 or not (0 <= rank < world):
+        raise ValueError("bad shard arguments")
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def allgather_maps(local: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
+    """Collate equally-shaped predicted-map shards [B_local,K,H,W] from every rank into
+    [world*B_local,K,H,W] (rank-major) with ONE all-gather; logging only, off the data path.
+    With one process it is the identity."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = world or dist.get_world_size()
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out
+
+
+def allgather_ragged(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
+    """Ragged variant (shards of different B_local, e.g. 10 maps over 4 ranks): pads to the
+    largest shard, gathers once, strips the padding."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    if len(counts) != world:
+        raise ValueError("counts must have one entry per rank")
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    full = allgather_maps(pad, world)
+    parts = [full[r * mx: r * mx + counts[r]] for r in range(world)]
+    return torch.cat(parts, 0)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

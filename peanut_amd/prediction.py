@@ -115,21 +115,32 @@ class HipSegmentor:
                        "peanut_pred_debug_read")
         return out
 
-    def profile(self, x: torch.Tensor):
-        """[(op name, ms, flops)] of one forward, every launch bracketed by HIP events."""
-        x = x.contiguous()
-        b, _, h, w = x.shape
-        out = torch.empty((b, self.cfg.num_classes, h, w), dtype=torch.float32, device=x.device)
+    def probe_enable(self, enable: bool = True):
+        """Per-op HIP-event probe inside forward (see include/peanut_hip.h)."""
+        _lib.check(self._lib.peanut_pred_probe_enable(self._h, int(enable)), "peanut_pred_probe_enable")
+
+    def probe_collect(self):
+        """-> (n_forwards, [(op name, kernel family, total ms over the forwards, flops per launch)])"""
         n = 256
-        names = (C.c_char_p * n)()
-        ms = (C.c_float * n)()
-        fl = (C.c_double * n)()
-        with torch.cuda.device(x.device):
-            cnt = self._lib.peanut_pred_profile(self._h, x.data_ptr(), out.data_ptr(), b, h, w,
-                                                _lib.current_stream_ptr(x.device), names, ms, fl, n)
+        names, kernels = (C.c_char_p * n)(), (C.c_char_p * n)()
+        ms, fl = (C.c_double * n)(), (C.c_double * n)()
+        nf = C.c_int(0)
+        cnt = self._lib.peanut_pred_probe_collect(self._h, n, names, kernels, ms, fl, C.byref(nf))
         if cnt < 0:
-            _lib.check(cnt, "peanut_pred_profile")
-        return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(min(cnt, n))]
+            _lib.check(cnt, "peanut_pred_probe_collect")
+        return nf.value, [(names[i].decode(), kernels[i].decode(), float(ms[i]), float(fl[i]))
+                          for i in range(min(cnt, n))]
+
+    def profile(self, x: torch.Tensor, repeats: int = 1):
+        """[(op name, kernel family, mean ms, flops)] of a forward, via the event probe."""
+        self.probe_enable(True)
+        try:
+            for _ in range(repeats):
+                self.forward_logits(x)
+            nf, rows = self.probe_collect()
+        finally:
+            self.probe_enable(False)
+        return [(a, k, ms / max(nf, 1), f) for a, k, ms, f in rows]
 
 
 def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None) -> HipSegmentor:

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) result: per-kernel call count / total / average duration
+(the `--kernel-trace --stats` view) and, when the run carried --pmc counters, per-kernel counter
+sums and per-dispatch averages.  Usage: rocpd_summary.py results.db [--skip-first N]"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    name = name.replace("peanut::", "").replace("void ", "")
+    if "(" in name:
+        name = name[:name.index("(")]
+    return name[:90]
+
+
+def main():
+    path = sys.argv[1]
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute("select name, duration, dispatch_id, grid_x, workgroup_x, lds_size, vgpr_count, "
+                       "accum_vgpr_count, sgpr_count from kernels order by start").fetchall()
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0, None])
+    for name, dur, did, gx, wx, lds, vg, ag, sg in rows:
+        a = agg[short(name)]
+        a[0] += 1
+        a[1] += dur
+        a[2] = min(a[2], dur)
+        a[3] = max(a[3], dur)
+        a[4] = (lds, vg, ag, sg)
+    total = sum(a[1] for a in agg.values())
+    print(f"# {path}: {len(rows)} dispatches, {total / 1e6:.3f} ms of kernel time")
+    print(f"{'kernel':92s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}  lds/vgpr/agpr/sgpr")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k:92s} {a[0]:6d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:10.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} "
+              f"{100 * a[1] / total:6.2f}  {a[4]}")
+    try:
+        crow = cur.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection").fetchall()
+    except sqlite3.Error:
+        crow = []
+    if crow:
+        cagg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        for kname, cname, val, did in crow:
+            c = cagg[short(kname)][cname]
+            c[0] += 1
+            c[1] += val
+        print("\n# counters: per kernel, sum over dispatches (and mean per dispatch)")
+        for k, cs in sorted(cagg.items(), key=lambda kv: -agg.get(kv[0], [0, 0])[1]):
+            print(k)
+            for cname, (n, s) in sorted(cs.items()):
+                print(f"    {cname:32s} n={n:5d} sum={s:.6g} mean={s / n:.6g}")
+
+
+if __name__ == "__main__":
+    main()
