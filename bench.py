@@ -29,7 +29,11 @@ if ROOT not in sys.path:
 from peanut_amd import dist as pdist  # noqa: E402
 from peanut_amd.weights import PredCfg, conv_flops_per_map, make_seeded_state_dict  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+# MI355X_MICROARCH.md: fp32 MFMA 157.3 TF (v_mfma_f32_32x32x2_f32); dense bf16/f16 MFMA 2.5 PF, of which a
+# split-product mode can deliver at most one third as fp32-equivalent FLOPs (3 MFMAs per product).
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}
+DTYPE = {"fp32": "f32", "bf16x3": "f32 (bf16x3 split products, f32 accumulate)",
+         "fp16x3": "f32 (fp16x3 split products, f32 accumulate)"}
 METRIC = "maps/sec for 480x480x(4+N_cat) prediction fwd, batch 32"
 
 
@@ -75,6 +79,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="maps per GPU per step")
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--channels", type=int, default=14, help="4 + N_cat input channels")
+    ap.add_argument("--precision", default=os.environ.get("PEANUT_PRECISION", "fp32"),
+                    choices=sorted(PEAK_TFLOPS), help="conv arithmetic (include/peanut_hip.h PEANUT_PREC_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-op HIP-event probe")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) here")
@@ -90,7 +96,8 @@ def main():
     from peanut_amd.prediction import PEANUT_Prediction_Model
     cfg = PredCfg(in_channels=args.channels)
     sd = make_seeded_state_dict(cfg, seed=0)
-    model = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=dev.index), state_dict=sd, cfg=cfg)
+    model = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=dev.index), state_dict=sd, cfg=cfg,
+                                    precision=args.precision)
     B, S = args.batch, args.size
     # this rank's shard of the global batch (weak scaling: B maps per GPU)
     x = synth_maps(B, cfg.in_channels, S, dev, seed0=rank * B)
@@ -124,8 +131,9 @@ def main():
         dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
         k, f = dom
         ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches_per_step": f["launches"] // max(nf, 1),
                 "avg_launch_ms": round(f["ms"] / max(f["launches"], 1), 4),
                 "flops_per_launch": f["flops"] / max(f["launches"], 1),
@@ -160,7 +168,7 @@ def main():
             "metric": METRIC, "value": round(value, 3), "unit": "maps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"{S}x{S}, {cfg.in_channels}-channel (4+{cfg.in_channels - 4}) partial maps -> "
                                    f"{cfg.num_classes}-class prediction forward (PSPNet R50-V1c-D8), "
                                    f"batch {B} per GPU, seeded random-init weights",

@@ -47,7 +47,16 @@ typedef struct peanut_pred_cfg {
   int head_channels;     /* decode_head.channels (512) */
   int align_corners;     /* decode_head.align_corners (False) */
   float bn_eps;          /* nn.BatchNorm2d default 1e-5 */
+  int precision;         /* PEANUT_PREC_*: arithmetic of the conv contractions (see below) */
 } peanut_pred_cfg;
+
+/* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32, exact fp32 (bit-identical to an fmaf chain).
+ * BF16X3 / FP16X3: every fp32 operand is split into two 16-bit parts and each product is rebuilt from
+ * three 16-bit matrix-core products with fp32 accumulation (fp32-class result, ~1e-4 / ~2e-5 max-abs
+ * on the logits vs the fp32 reference, bound 1e-3); FP16X3 overflows for |activation| > 65504. */
+#define PEANUT_PREC_FP32 0
+#define PEANUT_PREC_BF16X3 1
+#define PEANUT_PREC_FP16X3 2
 
 /* One entry of an mmcv/PyTorch state dict (HOST memory, fp32, contiguous, OIHW for convs). */
 typedef struct peanut_tensor {
@@ -113,10 +122,11 @@ int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names,
 typedef struct peanut_conv peanut_conv_t;
 /* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
  * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
- * which the packer guarantees). */
+ * which the packer guarantees).  precision = PEANUT_PREC_* (split modes need cin_pad % 32 == 0,
+ * otherwise the layer silently stays fp32). */
 int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
                        const float* shift_host, int cout, int cin, int cin_pad, int kh, int kw, int stride,
-                       int pad, int dil, int relu);
+                       int pad, int dil, int relu, int precision);
 void peanut_conv_destroy(peanut_conv_t* c);
 /* x_dev [B,H,W,cin_pad] (or split x_dev [..,c1] ++ x2_dev [..,cin_pad-c1] when x2_dev != NULL),
  * res_dev optional [B,Ho,Wo,cout], y_dev [B,Ho,Wo,cout]. */

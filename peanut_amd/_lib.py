@@ -29,6 +29,7 @@ class PredCfgC(C.Structure):
         ("strides", C.c_int * 4), ("dilations", C.c_int * 4), ("contract_dilation", C.c_int),
         ("pool_scales", C.c_int * 8), ("n_pool_scales", C.c_int),
         ("head_channels", C.c_int), ("align_corners", C.c_int), ("bn_eps", C.c_float),
+        ("precision", C.c_int),
     ]
 
 
@@ -53,10 +54,13 @@ SIGNATURES = {
     "peanut_pred_probe_enable": (C.c_int, [_P, C.c_int]),
     "peanut_pred_probe_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 9),
+    "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 10),
     "peanut_conv_destroy": (None, [_P]),
     "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
 }
+
+
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x3": 2}
 
 
 def lib_path() -> str:

@@ -29,6 +29,7 @@ struct ConvDesc {
   int bn_tile;    // BN used for packing (32/64/128)
   int bk;         // BK used for packing (16/32)
   int cout_pad;   // cout rounded up to bn_tile
+  int mode;       // 0 = fp32 MFMA (exact), 1 = bf16x3 split products, 2 = fp16x3 split products
   const float* w_packed;   // device
   const float* scale;      // device [cout_pad]
   const float* shift;      // device [cout_pad]
@@ -52,6 +53,8 @@ void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk);
 size_t conv_packed_floats(int cin_pad, int cout, int kh, int kw, int bn_tile);
 void pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw,
                        int bn_tile, int bk, float* out);
+void pack_conv_weights_split(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile,
+                             int fp16, void* out);
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
 
 // ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----

@@ -26,40 +26,9 @@
 //   segments), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel.
 //   Workgroup -> tile map is XCD-aware: each XCD (private 4 MiB L2) owns a contiguous run of
 //   tiles, n-tile fastest, so the co-resident workgroups of an XCD share A panels.
-#include "common.h"
+#include "conv_common.h"
 
 namespace peanut {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: no struct memcpy, stays in VGPRs
-
-struct ConvKParams {
-  const float* x;
-  const float* x2;
-  const float* w;
-  const float* scale;
-  const float* shift;
-  const float* res;
-  float* y;
-  int H, W, c1, c2, Ho, Wo, cout;
-  int kw, ntaps, stride, pad, dil, relu;
-  int M, nkt, ntiles, HoWo;
-};
-
-template <int I>
-struct IC { static constexpr int value = I; };
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(IC<I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
-struct KIter {
-  int tap, ky, kx, cbase;
-  const float* wtile;
-};
 
 // Issue the global loads of one k-tile (A gathered from the shifted input pixels, W linear) into
 // registers and advance the k-tile iterator.
@@ -127,18 +96,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is a multiple of the 32x32 MFMA");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  constexpr int CS = BN + 4;             // epilogue staging row stride (floats)
+  constexpr int SMEM_FLOATS = (2 * STAGE > BM * CS) ? 2 * STAGE : BM * CS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
-  // ---- XCD-aware tile assignment (bijective for any grid size; guide T1) ----
   int mt, nt;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    mt = L / p.ntiles;
-    nt = L - mt * p.ntiles;
-  }
+  xcd_tile(p.ntiles, &mt, &nt);
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread staging coordinates ----
@@ -221,22 +185,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   }
 
   // ---- epilogue: y = relu(acc * scale[n] + shift[n] + res) ----
+  // The accumulators go through LDS once so that global traffic is whole rows: each thread then
+  // handles 16-byte pieces (4 consecutive channels) -- a wave reads the residual and writes the
+  // output as 512-byte (BN=128) contiguous row segments instead of 64 scalar accesses per lane.
+  // (The k-loop's last barrier has retired every LDS read, so the pipeline buffers are free.)
 #pragma unroll
-  for (int u = 0; u < NI; ++u) {
-    const int n = n0 + wn * TN + u * 32 + li;
-    const float sc = p.scale[n], sh = p.shift[n];
-    const bool nok = n < p.cout;
+  for (int t = 0; t < MI; ++t)
 #pragma unroll
-    for (int t = 0; t < MI; ++t) {
+    for (int u = 0; u < NI; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (nok && m < p.M) {
-          const size_t o = (size_t)m * p.cout + n;
-          float v = acc[t][u][r] * sc + sh;
-          if (p.res) v += p.res[o];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.y[o] = v;
+        const int row = wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        smem[row * CS + wn * TN + u * 32 + li] = acc[t][u][r];
+      }
+  __syncthreads();
+  constexpr int NV = BN / 4;               // float4 per output row of the tile
+  constexpr int ROWS_PER_PASS = 256 / NV;  // rows covered by the 256 threads per pass
+  const int c4 = (tid % NV) * 4, r0 = tid / NV;
+  const int n = n0 + c4;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);   // scale/shift are padded to cout_pad
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+  const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
+#pragma unroll 4
+  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+    v = v * sc + sh;
+    const size_t o = (size_t)m * p.cout + n;
+    if (vec_ok) {
+      if (n < p.cout) {
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(p.y + o) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < p.cout) {
+          float x = v[e];
+          if (p.res) x += p.res[o + e];
+          if (p.relu) x = fmaxf(x, 0.f);
+          p.y[o + e] = x;
         }
       }
     }
@@ -299,6 +289,10 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.M = (int)M;
   p.nkt = (d.cin / d.bk) * p.ntaps;
   p.ntiles = d.cout_pad / d.bn_tile;
+  if (d.mode != 0) {
+    if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
+    return launch_conv_split(p, d.bn_tile, d.mode == 2, stream);
+  }
   if (d.bk == 32) {
     if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, stream);
     if (d.bn_tile == 64) return launch_t<128, 64, 32, 2, 2>(p, stream);

@@ -52,16 +52,18 @@ struct ConvLayer {
 };
 
 int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
-                int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu) {
+                int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision) {
   if (cin_pad % 16 != 0 || cin_pad < cin) return fail(PEANUT_EINVAL, L.name + ": cin_pad must be a multiple of 16 and >= cin");
   ConvDesc& d = L.d;
   d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
   conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
+  d.mode = (precision != 0 && d.bk == 32) ? precision : 0;   // 16-channel (stem.0) layers stay fp32
   L.cin_real = cin;
-  const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);
+  const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);   // same byte count in every mode
   std::vector<float> packed(nw);
-  pack_conv_weights(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.bk, packed.data());
+  if (d.mode == 0) pack_conv_weights(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.bk, packed.data());
+  else pack_conv_weights_split(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.mode == 2, packed.data());
   std::vector<float> ss(2 * (size_t)d.cout_pad, 0.f);
   for (int n = 0; n < cout; ++n) {
     ss[n] = scale ? scale[n] : 1.f;
@@ -226,7 +228,8 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   }
   auto L = std::make_unique<ConvLayer>();
   L->name = conv;
-  rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu);
+  rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu,
+                   h->cfg.precision);
   if (rc) return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
@@ -248,7 +251,8 @@ double conv_flops(const ConvLayer* L, const Act& out) {
 void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out) {
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = "conv_igemm_128x" + std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
+  op.kernel = std::string(L->d.mode == 0 ? "conv_igemm_128x" : (L->d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
+              std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
@@ -410,7 +414,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
 extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
-int peanut_abi_version(void) { return 1; }
+int peanut_abi_version(void) { return 2; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
@@ -419,6 +423,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
   if (cfg->in_channels < 1 || cfg->num_classes < 1 || cfg->num_classes > 32)
     return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
   if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
+  if (cfg->precision < 0 || cfg->precision > 2) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3}");
   auto h = std::make_unique<peanut_pred>();
   h->cfg = *cfg;
   h->cin_pad = (cfg->in_channels + 15) / 16 * 16;
@@ -582,13 +587,14 @@ int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names,
 
 // ---- operator-level conv ----
 int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, const float* shift, int cout, int cin,
-                       int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu) {
+                       int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision) {
   if (!out || !w) return fail(PEANUT_EINVAL, "peanut_conv_create: null argument");
   if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
+  if (precision < 0 || precision > 2) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
   auto c = std::make_unique<peanut_conv>();
   c->L.name = "conv";
-  int rc = upload_conv(c->L, w, scale, shift, cout, cin, cin_pad, kh, kw, stride, pad, dil, relu);
+  int rc = upload_conv(c->L, w, scale, shift, cout, cin, cin_pad, kh, kw, stride, pad, dil, relu, precision);
   if (rc) return rc;
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = c.release();

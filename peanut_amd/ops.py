@@ -25,7 +25,8 @@ class FusedConv:
 
     def __init__(self, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0,
-                 dilation: int = 1, relu: bool = False, cin_pad: Optional[int] = None):
+                 dilation: int = 1, relu: bool = False, cin_pad: Optional[int] = None,
+                 precision: str = "fp32"):
         self._lib = _lib.load()
         w = np.ascontiguousarray(weight.detach().cpu().numpy(), dtype=np.float32)
         cout, cin, kh, kw = w.shape
@@ -38,7 +39,7 @@ class FusedConv:
         _lib.check(self._lib.peanut_conv_create(
             C.byref(self._h), w.ctypes.data, None if sc is None else sc.ctypes.data,
             None if sh is None else sh.ctypes.data, cout, cin, self.cin_pad, kh, kw, stride, padding,
-            dilation, int(relu)), "peanut_conv_create")
+            dilation, int(relu), _lib.PRECISIONS[precision]), "peanut_conv_create")
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -9,6 +9,7 @@ top (the reference is batch-1 only): ``get_prediction_batch`` for device tensors
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -29,12 +30,15 @@ class HipSegmentor:
     device, ``prediction/mmseg/apis/inference.py:12-40``), here a handle of the HIP library."""
 
     def __init__(self, cfg: PredCfg, state_dict: Dict[str, torch.Tensor], device="cuda:0",
-                 classes=None):
+                 classes=None, precision: str = "fp32"):
         if not torch.cuda.is_available():
             raise _lib.PeanutHipError("PEANUT_Prediction_Model needs a HIP device (no CPU fallback)")
         self.cfg = cfg
         self.device = torch.device(device)
         self.CLASSES = classes
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        self.precision = precision
         self._lib = _lib.load()
         tensors = select_inference_tensors(state_dict, cfg)     # raises on missing/mis-shaped keys
         arr = (_lib.TensorC * len(tensors))()
@@ -55,6 +59,7 @@ class HipSegmentor:
             c.pool_scales[i] = k
         c.n_pool_scales = len(cfg.pool_scales)
         c.head_channels, c.align_corners, c.bn_eps = cfg.head_channels, int(cfg.align_corners), cfg.bn_eps
+        c.precision = _lib.PRECISIONS[precision]
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.peanut_pred_create(C.byref(self._h), C.byref(c), arr, len(tensors)),
@@ -143,7 +148,8 @@ class HipSegmentor:
         return [(a, k, ms / max(nf, 1), f) for a, k, ms, f in rows]
 
 
-def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None) -> HipSegmentor:
+def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
+                   precision: str = "fp32") -> HipSegmentor:
     """``prediction/mmseg/apis/inference.py:12-40``: config path (or PredCfg) + mmcv checkpoint.
     ``state_dict`` lets tests/benchmarks pass seeded weights instead of a checkpoint file."""
     if isinstance(config, str):
@@ -159,7 +165,7 @@ def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None) ->
     if state_dict is None:
         raise ValueError("init_segmentor needs a checkpoint (or an explicit state_dict): the HIP "
                          "model has no random-init mode")
-    return HipSegmentor(cfg, state_dict, device=device, classes=classes)
+    return HipSegmentor(cfg, state_dict, device=device, classes=classes, precision=precision)
 
 
 def run_inference(model: HipSegmentor, full_map: np.ndarray) -> List[np.ndarray]:
@@ -179,7 +185,7 @@ class PEANUT_Prediction_Model():
     ``pred_model_cfg`` and ``sem_gpu_id`` (``nav/arguments.py``); ``state_dict`` may replace the
     checkpoint file (seeded weights for tests/benchmarks)."""
 
-    def __init__(self, args, state_dict=None, cfg: Optional[PredCfg] = None):
+    def __init__(self, args, state_dict=None, cfg: Optional[PredCfg] = None, precision: Optional[str] = None):
         self.args = args
         ckpt = getattr(args, "pred_model_wts", None) if state_dict is None else None
         if cfg is None:
@@ -187,7 +193,10 @@ class PEANUT_Prediction_Model():
             cfg = pred_cfg_from_file(cfg_path) if cfg_path else PredCfg()
         device = ("cuda:" + str(args.sem_gpu_id)) if args is not None and hasattr(args, "sem_gpu_id") \
             else "cuda:0"
-        self.model = init_segmentor(cfg, checkpoint=ckpt, device=device, state_dict=state_dict)
+        if precision is None:
+            precision = getattr(args, "pred_precision", None) or os.environ.get("PEANUT_PRECISION", "fp32")
+        self.model = init_segmentor(cfg, checkpoint=ckpt, device=device, state_dict=state_dict,
+                                    precision=precision)
         self.model.eval()
         self.model.cfg = cfg
 

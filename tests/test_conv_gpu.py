@@ -81,3 +81,34 @@ def test_conv_transpose_detecting():
     ref = F.conv2d(x, w)
     y = FusedConv(w)(x.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
     assert torch.equal(y, ref)
+
+
+SPLIT_TOL = {"bf16x3": 1e-4, "fp16x3": 2e-5}   # relative to (1 + |ref|); fp32 products rebuilt from 3 halves
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 32 == 0], ids=lambda c: "x".join(map(str, c[:9])))
+def test_split_precision_conv(case, precision):
+    """bf16x3 / fp16x3 split-product kernels against the same fp32 PyTorch reference."""
+    from peanut_amd.ops import FusedConv, to_nhwc_padded, round_up
+    B, H, W, cin, cout, k, s, p, d, relu, residual = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d) * scale[None, :, None, None] \
+        + shift[None, :, None, None]
+    res = None
+    if residual:
+        res = _rand(tuple(ref.shape), g)
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, precision=precision)
+    xd = to_nhwc_padded(x.cuda(), round_up(cin, 16))
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+    y = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
+    err = (y - ref).abs()
+    tol = SPLIT_TOL[precision] * (1 + ref.abs())
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}"

@@ -136,3 +136,25 @@ def test_golden_vectors(model_and_sd, golden_dir):
         got = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu().numpy()
         err = np.abs(got - ref).max()
         assert err <= TOL, f"{case}: max err {err:.3e}"
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("fp16x3", 1e-4)])
+def test_split_precision_forward_within_contract(precision, tol, golden_dir):
+    """Split-product modes (3 x 16-bit MFMA per fp32 product, fp32 accumulate) must stay inside the
+    north_star bound (1e-3) with margin, on config 1 (240x240 golden vector from the reference)."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    cfg = PredCfg()
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg, 0),
+                                cfg=cfg, precision=precision)
+    worst = 0.0
+    for case in ("cfg1_240", "odd_100", "rect_72x104"):
+        x = torch.from_numpy(z[f"{case}/input"].astype(np.float32))
+        ref = torch.from_numpy(z[f"{case}/logits"])
+        got = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu()
+        err = (got - ref).abs().max().item()
+        errp = (torch.sigmoid(got) - torch.sigmoid(ref)).abs().max().item()
+        worst = max(worst, err)
+        assert err <= tol and errp <= tol, f"{precision} {case}: logits {err:.3e} sigmoid {errp:.3e}"
+    print(f"{precision}: worst logits max-abs {worst:.3e} (contract {CONTRACT})")
