@@ -48,6 +48,9 @@ typedef struct peanut_pred_cfg {
   int align_corners;     /* decode_head.align_corners (False) */
   float bn_eps;          /* nn.BatchNorm2d default 1e-5 */
   int precision;         /* PEANUT_PREC_*: arithmetic of the conv contractions (see below) */
+  int fold_ppm;          /* 1: evaluate the pyramid half of the PSP bottleneck conv through linearity
+                            (conv of a bilinear upsample of k*k vectors = bilinear blend of k*k folded
+                            vectors; halves that conv's FLOPs, fp32 re-association only); 0: plain conv */
 } peanut_pred_cfg;
 
 /* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32, exact fp32 (bit-identical to an fmaf chain).

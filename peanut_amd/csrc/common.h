@@ -66,6 +66,9 @@ int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, cons
 // bilinear (align_corners=False) upsample of the pooled pyramid + channel concat: out [B,H,W,nscales*Cp]
 int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int W, int Cp, const int* scales,
                                int nscales, int align_corners, hipStream_t s);
+// pyramid half of the 3x3 bottleneck conv evaluated from the folded tables Q (see pspnet_aux.hip)
+int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
+                         int align_corners, hipStream_t s);
 // bilinear resize of NHWC logits [B,h,w,K] to NCHW [B,K,H,W], optional sigmoid
 int launch_upsample_logits(const float* lo, float* out, int B, int h, int w, int K, int H, int W,
                            int align_corners, int sigmoid, hipStream_t s);

@@ -128,7 +128,7 @@ struct Act {  // an NHWC activation inside the workspace
   int B = 0, H = 0, W = 0, C = 0;
 };
 
-enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_UPSAMPLE };
+enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE };
 
 struct Op {
   OpKind kind;
@@ -166,7 +166,9 @@ struct peanut_pred {
   struct Block { ConvLayer *c1, *c2, *c3, *down; };
   std::vector<std::vector<Block>> layers;
   std::vector<ConvLayer*> ppm;
-  ConvLayer* bottleneck = nullptr;
+  ConvLayer* bottleneck = nullptr;     // unfolded form: 3x3 over cat([x, ppm...])
+  ConvLayer* bottleneck_x = nullptr;   // folded form: 3x3 over x only ...
+  std::vector<ConvLayer*> ppm_q;       // ... plus the per-scale tables Q_s = W_s (x) p_s (1x1 convs, cout = 9*hc)
   ConvLayer* conv_seg = nullptr;
   int feat_channels = 0;
   // runtime
@@ -200,6 +202,23 @@ struct TensorMap {
   }
 };
 
+// BN(eval) as y = x*alpha + beta, alpha = weight/sqrt(var+eps), beta = bias - mean*alpha (fp32).
+int bn_fold(peanut_pred* h, const TensorMap& tm, const std::string& bn, int cout, float* scale, float* shift) {
+  int rc = 0;
+  const int64_t cshape[1] = {cout};
+  const peanut_tensor* g = tm.get(bn + ".weight", 1, cshape, &rc); if (!g) return rc;
+  const peanut_tensor* b = tm.get(bn + ".bias", 1, cshape, &rc); if (!b) return rc;
+  const peanut_tensor* mu = tm.get(bn + ".running_mean", 1, cshape, &rc); if (!mu) return rc;
+  const peanut_tensor* var = tm.get(bn + ".running_var", 1, cshape, &rc); if (!var) return rc;
+  for (int n = 0; n < cout; ++n) {
+    const float invstd = 1.0f / sqrtf(var->data[n] + h->cfg.bn_eps);
+    const float alpha = invstd * g->data[n];
+    scale[n] = alpha;
+    shift[n] = b->data[n] - mu->data[n] * alpha;
+  }
+  return 0;
+}
+
 // conv weight + (BatchNorm | bias) -> ConvLayer with folded scale/shift.
 // BN(eval): y = x*alpha + beta, alpha = weight/sqrt(var+eps), beta = bias - mean*alpha  (fp32, the
 // form ATen's CPU batch_norm inference uses).
@@ -212,16 +231,7 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
   const int64_t cshape[1] = {cout};
   if (!bn.empty()) {
-    const peanut_tensor* g = tm.get(bn + ".weight", 1, cshape, &rc); if (!g) return rc;
-    const peanut_tensor* b = tm.get(bn + ".bias", 1, cshape, &rc); if (!b) return rc;
-    const peanut_tensor* mu = tm.get(bn + ".running_mean", 1, cshape, &rc); if (!mu) return rc;
-    const peanut_tensor* var = tm.get(bn + ".running_var", 1, cshape, &rc); if (!var) return rc;
-    for (int n = 0; n < cout; ++n) {
-      const float invstd = 1.0f / sqrtf(var->data[n] + h->cfg.bn_eps);
-      const float alpha = invstd * g->data[n];
-      scale[n] = alpha;
-      shift[n] = b->data[n] - mu->data[n] * alpha;
-    }
+    if ((rc = bn_fold(h, tm, bn, cout, scale.data(), shift.data()))) return rc;
   } else {
     const peanut_tensor* b = tm.get(conv + ".bias", 1, cshape, &rc); if (!b) return rc;
     for (int n = 0; n < cout; ++n) shift[n] = b->data[n];
@@ -337,13 +347,39 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   }
   pl->named["ppm_table"] = table;
   rel(pooled);
-  Act up = make_act(ar, B, x.H, x.W, h->cfg.n_pool_scales * h->cfg.head_channels);
-  { Op op; op.kind = OP_PPM_UP; op.name = "ppm_upsample_concat"; op.kernel = "ppm_upsample_concat"; op.in = table; op.out = up; pl->ops.push_back(op); }
-  rel(table);
-  Act bt = make_act(ar, B, x.H, x.W, h->bottleneck->d.cout);
-  push_conv(*pl, h->bottleneck, x, &up, nullptr, bt);  // cat([x, ppm...]) is never materialised for x
+  Act bt;
+  if (h->bottleneck_x) {
+    // folded pyramid half (pspnet_aux.hip: ppm_conv_term_kernel): Q_s = table_s x W_s, then the 9-tap
+    // bilinear evaluation R, then the 3x3 conv over x alone with R as its residual term
+    const int hc = h->cfg.head_channels;
+    Act q = make_act(ar, B, 1, nbins, 9 * hc);
+    size_t row0 = 0;
+    for (int i = 0; i < h->cfg.n_pool_scales; ++i) {
+      const int k = h->cfg.pool_scales[i];
+      Act in = table, out = q;
+      in.off = table.off + row0 * (size_t)hc * sizeof(float);
+      in.H = 1; in.W = k * k; in.C = hc; in.B = B;
+      out.off = q.off + row0 * (size_t)(9 * hc) * sizeof(float);
+      out.H = 1; out.W = k * k; out.C = 9 * hc; out.B = B;
+      push_conv(*pl, h->ppm_q[i], in, nullptr, nullptr, out);
+      row0 += (size_t)B * k * k;
+    }
+    rel(table);
+    Act r = make_act(ar, B, x.H, x.W, hc);
+    { Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; pl->ops.push_back(op); }
+    rel(q);
+    bt = make_act(ar, B, x.H, x.W, h->bottleneck_x->d.cout);
+    push_conv(*pl, h->bottleneck_x, x, nullptr, &r, bt);
+    rel(r);
+  } else {
+    Act up = make_act(ar, B, x.H, x.W, h->cfg.n_pool_scales * h->cfg.head_channels);
+    { Op op; op.kind = OP_PPM_UP; op.name = "ppm_upsample_concat"; op.kernel = "ppm_upsample_concat"; op.in = table; op.out = up; pl->ops.push_back(op); }
+    rel(table);
+    bt = make_act(ar, B, x.H, x.W, h->bottleneck->d.cout);
+    push_conv(*pl, h->bottleneck, x, &up, nullptr, bt);  // cat([x, ppm...]) is never materialised for x
+    rel(up);
+  }
   pl->named["bottleneck"] = bt;
-  rel(up);
   rel(x);
   Act lo = make_act(ar, B, bt.H, bt.W, h->conv_seg->d.cout);
   push_conv(*pl, h->conv_seg, bt, nullptr, nullptr, lo);
@@ -404,6 +440,9 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
     case OP_PPM_UP:
       return launch_ppm_upsample_concat(P(op.in), P(op.out), op.out.B, op.out.H, op.out.W, h->cfg.head_channels,
                                         h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s);
+    case OP_PPM_TERM:
+      return launch_ppm_conv_term(P(op.in), P(op.out), op.out.B, op.out.H, op.out.W, h->cfg.head_channels,
+                                  h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s);
     case OP_UPSAMPLE:
       return launch_upsample_logits(P(op.in), out_dev, op.in.B, op.in.H, op.in.W, op.in.C, pl.H, pl.W,
                                     h->cfg.align_corners, sigmoid, s);
@@ -469,7 +508,41 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
     h->ppm.push_back(L);
   }
   const int cat = inplanes + cfg->n_pool_scales * hc;
-  if ((rc = add_conv(h.get(), tm, "decode_head.bottleneck.conv", "decode_head.bottleneck.bn", cat, cat, hc, 3, 1, 1, 1, 1, &h->bottleneck))) return rc;
+  if (!cfg->fold_ppm) {
+    if ((rc = add_conv(h.get(), tm, "decode_head.bottleneck.conv", "decode_head.bottleneck.bn", cat, cat, hc, 3, 1, 1, 1, 1, &h->bottleneck))) return rc;
+  } else {
+    // Split W[hc][cat][3][3] into the x part (conv proper) and one folded 1x1 table-builder per scale:
+    //   Wq_s[(tap*hc + n)][c] = alpha[n] * W[n][feat + s*hc + c][tap]   (alpha = BN scale, so that the
+    //   evaluated term enters the conv epilogue after the scale: relu(alpha*conv_x + beta + alpha*T)).
+    const int64_t wshape[4] = {hc, cat, 3, 3};
+    const peanut_tensor* w = tm.get("decode_head.bottleneck.conv.weight", 4, wshape, &rc);
+    if (!w) return rc;
+    std::vector<float> scale(hc), shift(hc);
+    if ((rc = bn_fold(h.get(), tm, "decode_head.bottleneck.bn", hc, scale.data(), shift.data()))) return rc;
+    std::vector<float> wx((size_t)hc * inplanes * 9);
+    for (int n = 0; n < hc; ++n)
+      memcpy(&wx[(size_t)n * inplanes * 9], &w->data[(size_t)n * cat * 9], (size_t)inplanes * 9 * sizeof(float));
+    {
+      auto L = std::make_unique<ConvLayer>();
+      L->name = "decode_head.bottleneck.conv[x]";
+      if ((rc = upload_conv(*L, wx.data(), scale.data(), shift.data(), hc, inplanes, inplanes, 3, 3, 1, 1, 1, 1, cfg->precision))) return rc;
+      h->bottleneck_x = L.get();
+      h->convs.push_back(std::move(L));
+    }
+    std::vector<float> wq((size_t)9 * hc * hc);
+    for (int s = 0; s < cfg->n_pool_scales; ++s) {
+      for (int tap = 0; tap < 9; ++tap)
+        for (int n = 0; n < hc; ++n)
+          for (int c = 0; c < hc; ++c)
+            wq[((size_t)tap * hc + n) * hc + c] = scale[n] * w->data[((size_t)n * cat + inplanes + (size_t)s * hc + c) * 9 + tap];
+      auto L = std::make_unique<ConvLayer>();
+      L->name = "decode_head.bottleneck.conv[ppm" + std::to_string(s) + "]";
+      // exact fp32 for the tiny table GEMMs regardless of the handle's precision
+      if ((rc = upload_conv(*L, wq.data(), nullptr, nullptr, 9 * hc, hc, hc, 1, 1, 1, 0, 1, 0, PEANUT_PREC_FP32))) return rc;
+      h->ppm_q.push_back(L.get());
+      h->convs.push_back(std::move(L));
+    }
+  }
   if ((rc = add_conv(h.get(), tm, "decode_head.conv_seg", "", hc, hc, cfg->num_classes, 1, 1, 0, 1, 0, &h->conv_seg))) return rc;
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = h.release();

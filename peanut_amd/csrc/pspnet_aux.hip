@@ -208,6 +208,79 @@ int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int
   return e == hipSuccess ? 0 : fail(-3, std::string("ppm_upsample: ") + hipGetErrorString(e));
 }
 
+// ---- pyramid half of the PSP bottleneck conv, folded through linearity ----
+// The reference convolves cat([x, up(p_1), up(p_2), up(p_3), up(p_6)]) with a 3x3 kernel
+// (psp_head.py:107-110).  The pyramid half of that sum is low-rank: up(p_s) is a bilinear
+// interpolation of only k_s^2 vectors, and the conv is linear, so
+//     sum_tap sum_c W[n][c][tap] * up(p_s)[c](pix+tap)  =  sum_tap bilinear_s(Q_s[.][tap][n])(pix+tap)
+// with Q_s[g][tap][n] = sum_c W[n][c][tap] * p_s[g][c]  (a tiny GEMM over the 50 pooled vectors, done by
+// the conv kernel).  This kernel evaluates the right-hand side for every output pixel: 9 taps (zero
+// outside the image, like the conv's zero padding) x nscales x 4 bilinear neighbours.  Q already
+// carries the BatchNorm scale, so the result is added as the bottleneck conv's "residual".
+// Q rows are scale-major like the pooled table: row = B*base_s + b*k_s^2 + g, each row [9][C].
+__global__ __launch_bounds__(256) void ppm_conv_term_kernel(const float* __restrict__ Q, float* __restrict__ R, int H,
+                                                            int W, int C, PpmScales sc, int B, int align_corners,
+                                                            long long total) {
+  const int groups = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    long long pix = i / groups;
+    const int xx = (int)(pix % W);
+    const long long t = pix / W;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int base = 0;
+    for (int s = 0; s < sc.n; ++s) {
+      const int k = sc.s[s];
+      const float* qs = Q + ((size_t)B * base + (size_t)b * k * k) * (9 * C) + g * 4;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int py = yy + dy - 1;
+        if ((unsigned)py >= (unsigned)H) continue;
+        int y0, y1;
+        float ly;
+        bilinear_src(py, k, H, align_corners, &y0, &y1, &ly);
+        const float hy = 1.f - ly;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int px = xx + dx - 1;
+          if ((unsigned)px >= (unsigned)W) continue;
+          int x0, x1;
+          float lx;
+          bilinear_src(px, k, W, align_corners, &x0, &x1, &lx);
+          const float hx = 1.f - lx;
+          const float* qt = qs + (dy * 3 + dx) * C;
+          const float4 v00 = *reinterpret_cast<const float4*>(qt + (size_t)(y0 * k + x0) * (9 * C));
+          const float4 v01 = *reinterpret_cast<const float4*>(qt + (size_t)(y0 * k + x1) * (9 * C));
+          const float4 v10 = *reinterpret_cast<const float4*>(qt + (size_t)(y1 * k + x0) * (9 * C));
+          const float4 v11 = *reinterpret_cast<const float4*>(qt + (size_t)(y1 * k + x1) * (9 * C));
+          acc.x += hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+          acc.y += hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+          acc.z += hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+          acc.w += hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        }
+      }
+      base += k * k;
+    }
+    *reinterpret_cast<float4*>(R + (size_t)pix * C + g * 4) = acc;
+  }
+}
+
+int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
+                         int align_corners, hipStream_t s) {
+  if (nscales > 8 || C % 4) return fail(-2, "ppm_conv_term: unsupported configuration");
+  PpmScales sc;
+  sc.n = nscales;
+  for (int i = 0; i < nscales; ++i) sc.s[i] = scales[i];
+  const long long total = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(ppm_conv_term_kernel, dim3(grid_for(total)), dim3(256), 0, s, Q, R, H, W, C, sc, B,
+                     align_corners, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(-3, std::string("ppm_conv_term: ") + hipGetErrorString(e));
+}
+
 // ---- final resize: NHWC logits [B,h,w,K] -> NCHW [B,K,H,W] (+ optional sigmoid) ----
 // One thread per output pixel, all K classes: consecutive lanes = consecutive x -> every class
 // plane is written in coalesced 256-byte wave segments; the low-res source stays in L1/L2.

@@ -30,7 +30,7 @@ class HipSegmentor:
     device, ``prediction/mmseg/apis/inference.py:12-40``), here a handle of the HIP library."""
 
     def __init__(self, cfg: PredCfg, state_dict: Dict[str, torch.Tensor], device="cuda:0",
-                 classes=None, precision: str = "fp32"):
+                 classes=None, precision: str = "fp32", fold_ppm: bool = True):
         if not torch.cuda.is_available():
             raise _lib.PeanutHipError("PEANUT_Prediction_Model needs a HIP device (no CPU fallback)")
         self.cfg = cfg
@@ -60,6 +60,8 @@ class HipSegmentor:
         c.n_pool_scales = len(cfg.pool_scales)
         c.head_channels, c.align_corners, c.bn_eps = cfg.head_channels, int(cfg.align_corners), cfg.bn_eps
         c.precision = _lib.PRECISIONS[precision]
+        c.fold_ppm = int(fold_ppm)
+        self.fold_ppm = bool(fold_ppm)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.peanut_pred_create(C.byref(self._h), C.byref(c), arr, len(tensors)),
@@ -149,7 +151,7 @@ class HipSegmentor:
 
 
 def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
-                   precision: str = "fp32") -> HipSegmentor:
+                   precision: str = "fp32", fold_ppm: bool = True) -> HipSegmentor:
     """``prediction/mmseg/apis/inference.py:12-40``: config path (or PredCfg) + mmcv checkpoint.
     ``state_dict`` lets tests/benchmarks pass seeded weights instead of a checkpoint file."""
     if isinstance(config, str):
@@ -165,7 +167,8 @@ def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
     if state_dict is None:
         raise ValueError("init_segmentor needs a checkpoint (or an explicit state_dict): the HIP "
                          "model has no random-init mode")
-    return HipSegmentor(cfg, state_dict, device=device, classes=classes, precision=precision)
+    return HipSegmentor(cfg, state_dict, device=device, classes=classes, precision=precision,
+                        fold_ppm=fold_ppm)
 
 
 def run_inference(model: HipSegmentor, full_map: np.ndarray) -> List[np.ndarray]:
@@ -185,7 +188,8 @@ class PEANUT_Prediction_Model():
     ``pred_model_cfg`` and ``sem_gpu_id`` (``nav/arguments.py``); ``state_dict`` may replace the
     checkpoint file (seeded weights for tests/benchmarks)."""
 
-    def __init__(self, args, state_dict=None, cfg: Optional[PredCfg] = None, precision: Optional[str] = None):
+    def __init__(self, args, state_dict=None, cfg: Optional[PredCfg] = None, precision: Optional[str] = None,
+                 fold_ppm: Optional[bool] = None):
         self.args = args
         ckpt = getattr(args, "pred_model_wts", None) if state_dict is None else None
         if cfg is None:
@@ -195,8 +199,10 @@ class PEANUT_Prediction_Model():
             else "cuda:0"
         if precision is None:
             precision = getattr(args, "pred_precision", None) or os.environ.get("PEANUT_PRECISION", "fp32")
+        if fold_ppm is None:
+            fold_ppm = os.environ.get("PEANUT_FOLD_PPM", "1") != "0"
         self.model = init_segmentor(cfg, checkpoint=ckpt, device=device, state_dict=state_dict,
-                                    precision=precision)
+                                    precision=precision, fold_ppm=fold_ppm)
         self.model.eval()
         self.model.cfg = cfg
 

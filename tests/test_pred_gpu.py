@@ -158,3 +158,22 @@ def test_split_precision_forward_within_contract(precision, tol, golden_dir):
         worst = max(worst, err)
         assert err <= tol and errp <= tol, f"{precision} {case}: logits {err:.3e} sigmoid {errp:.3e}"
     print(f"{precision}: worst logits max-abs {worst:.3e} (contract {CONTRACT})")
+
+
+def test_folded_and_plain_bottleneck_agree(model_and_sd):
+    """fold_ppm=True (pyramid half of the 3x3 bottleneck evaluated through linearity, default) and
+    fold_ppm=False (plain conv over cat([x, up(ppm)])) are the same function up to fp32
+    re-association, and both match the oracle."""
+    from oracle import pspnet_ref
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    assert m.model.fold_ppm
+    plain = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, fold_ppm=False)
+    for (b, h, w) in [(2, 96, 96), (1, 100, 100), (1, 72, 104)]:
+        x = _inputs(b, cfg.in_channels, h, w, seed=77 + h)
+        ref = pspnet_ref.forward_batch(sd, x, cfg)
+        a = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu()
+        p = plain.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu()
+        assert (a - ref).abs().max().item() <= TOL
+        assert (p - ref).abs().max().item() <= TOL
+        assert (a - p).abs().max().item() <= 5e-5
