@@ -118,6 +118,54 @@ int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names,
                               double* ms_sum, double* flops, int* n_forwards);
 
 /* ------------------------------------------------------------------------------------------
+ * Stage 2 -- egocentric -> allocentric semantic-map projection
+ * ---------------------------------------------------------------------------------------- */
+
+/* The `args` fields Semantic_Mapping.__init__ reads (nav/agent/mapping.py:15-37); python floats are
+ * doubles here and are narrowed to fp32 exactly where torch narrows them. */
+typedef struct peanut_map_cfg {
+  int frame_height, frame_width;   /* 120, 160 */
+  int map_resolution;              /* 5 (cm per cell) */
+  int map_size_cm;                 /* 4800 */
+  int global_downscaling;          /* 2 */
+  int vision_range;                /* 100 */
+  double hfov;                     /* 79.0 */
+  int du_scale;                    /* 1 (only value supported) */
+  double cat_pred_threshold, exp_pred_threshold, map_pred_threshold;   /* 5.0, 1.0, 0.1 */
+  int num_sem_categories;          /* 10 */
+  double camera_height;            /* 0.88 (m) */
+} peanut_map_cfg;
+
+typedef struct peanut_map peanut_map_t;
+
+/* Replaces Semantic_Mapping.__init__ (mapping.py:12-50): derives the constants (camera matrix,
+ * z bins, paste window) and allocates the per-frame scratch (a few MB).  Synchronous. */
+int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* cfg);
+void peanut_map_destroy(peanut_map_t* h);
+/* dims = {C (= 4 + num_sem_categories), M (local map cells), vision_range, frame points} */
+int peanut_map_dims(peanut_map_t* h, int dims[4]);
+
+/* Replaces Semantic_Mapping.forward (mapping.py:52-179) for batch size 1.  All pointers are device
+ * fp32: obs [1,C,h,w] (ch 3 = depth in cm, ch 4.. = semantic), pose_obs [3] = (dx, dy, dtheta),
+ * maps_last [C,M,M], poses_inout [3] = (x m, y m, theta deg) updated IN PLACE (the reference's
+ * returned pose_pred / current_poses both alias poses_last, mapping.py:143-160), fp_map_pred
+ * [1,V,V], map_pred [C,M,M] (must not alias maps_last).  Enqueues ~14 launches, no host sync. */
+int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
+                       float* poses_inout, float* fp_map_pred, float* map_pred, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 1 -- per-instance mask accumulation of SemanticPredMaskRCNN.get_prediction
+ * (nav/agent/utils/segmentation.py:47-60): for every detected instance j whose class is in
+ * range(n_cats) and whose score passes sem_pred_prob_thr (and goal_thr when class == goal_cat),
+ * out[:, :, class] += mask_j.  masks [n,H,W] uint8/bool, classes [n] int32, scores [n] fp32,
+ * out [H,W,n_cats+1] fp32 (zeroed by the call; channel n_cats stays zero).  The Mask R-CNN
+ * network itself (detectron2, not vendored) is not part of this library.
+ * ---------------------------------------------------------------------------------------- */
+int peanut_seg_accumulate(const uint8_t* masks, const int32_t* classes, const float* scores, int n, int H, int W,
+                          int n_cats, float sem_pred_prob_thr, float goal_thr, int goal_cat, float* out,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Operator-level export: one fused conv (+BN scale/shift, +residual, +ReLU) on NHWC fp32.
  * Mirrors mmcv ConvModule / build_conv_layer+build_norm_layer call sites
  * (prediction/mmseg/models/backbones/resnet.py:164-209, decode_heads/psp_head.py:39-46,86-93).

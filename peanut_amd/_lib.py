@@ -33,6 +33,16 @@ class PredCfgC(C.Structure):
     ]
 
 
+class MapCfgC(C.Structure):
+    _fields_ = [
+        ("frame_height", C.c_int), ("frame_width", C.c_int), ("map_resolution", C.c_int),
+        ("map_size_cm", C.c_int), ("global_downscaling", C.c_int), ("vision_range", C.c_int),
+        ("hfov", C.c_double), ("du_scale", C.c_int),
+        ("cat_pred_threshold", C.c_double), ("exp_pred_threshold", C.c_double),
+        ("map_pred_threshold", C.c_double), ("num_sem_categories", C.c_int), ("camera_height", C.c_double),
+    ]
+
+
 class TensorC(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
 
@@ -54,6 +64,12 @@ SIGNATURES = {
     "peanut_pred_probe_enable": (C.c_int, [_P, C.c_int]),
     "peanut_pred_probe_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "peanut_map_create": (C.c_int, [C.POINTER(_P), C.POINTER(MapCfgC)]),
+    "peanut_map_destroy": (None, [_P]),
+    "peanut_map_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
+    "peanut_map_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                        C.c_int, _P, _P]),
     "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 10),
     "peanut_conv_destroy": (None, [_P]),
     "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

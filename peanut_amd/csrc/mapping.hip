@@ -1,0 +1,516 @@
+// Stage 2 of the PEANUT hot path: egocentric -> allocentric semantic-map projection, the HIP
+// counterpart of Semantic_Mapping.forward (nav/agent/mapping.py:52-179) with its helpers
+// (nav/agent/utils/depth_utils.py:129-252, nav/agent/utils/model.py:7-43).
+//
+// The reference is ~60 tiny tensor ops plus 8 rounds over a 35 MB voxel grid.  Here it is a short
+// chain of small kernels on one stream, with no host synchronisation and no dense voxel grid:
+//
+//   map_points   depth pixel -> normalised (x,y,z), SAME fp32 operation order as the reference
+//   map_stairs   low-stairs heuristic (mapping.py:90-97): counts + exact 3 % quantile by radix select
+//   map_keys     mask, splat position, base-cell key of every point
+//   (sort)       stable radix sort of (key, point index)  [rocPRIM via hipcub::DeviceRadixSort]
+//   map_heads    first sorted position of every occupied base cell -> dense lookup table
+//   map_voxels   one thread per (touched voxel, feature): replays the reference's 8 corner passes for
+//                that voxel only -- contributions added IN POINT ORDER, rintf after every pass -- and
+//                adds the (integer-valued, hence order-free) result into the two height projections
+//   map_view     thresholds/clamps -> the 100x100 egocentric window (+ fp_map_pred), clears scratch
+//   map_pose     pose integration + the two affine_grid theta rows
+//   map_warp     rotation resample -> translation resample -> max with the previous map, fused
+//
+// Why the voxel trick is exact: splat_feat_nd rounds the WHOLE grid after each corner pass
+// (depth_utils.py:249-250), so a voxel's final value depends only on the contributions it receives
+// per pass, in order.  In pass c a voxel v receives exactly the points whose floor cell is v - c, and
+// scatter_add_ on the CPU adds them in point order; grouping points by floor cell with a STABLE sort
+// keeps that order, so each voxel can be evaluated independently and bit-identically.  Unsafe corners
+// have weight 0 and only add +0.0.  The projections sum integer-valued floats (< 2^24), so atomics do
+// not introduce order dependence.
+//
+// fp32 contraction is OFF in this file: where the reference's CPU kernels use fused multiply-adds
+// (affine_grid's bmm, grid_sample's blend, lerp) fmaf is written explicitly.
+#include <hipcub/hipcub.hpp>
+
+#include <memory>
+
+#include "../../include/peanut_hip.h"
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace peanut {
+namespace {
+
+constexpr unsigned INVALID_KEY = 1u << 20;   // > 100*100*80; keys are sorted on 21 bits
+
+struct MapP {
+  int h, w, N, ncat, F, C;       // frame, points, semantic channels, feature rows (1+ncat), map channels (4+ncat)
+  int vr, zb, M;                 // vision range (cells), z bins, local map size (cells)
+  float xc, zc, f;               // camera matrix (depth_utils.py:27-34)
+  float agent_h, shift_x;        // 88 cm, 250 cm
+  float res, vr_half, vr_f, z_mid, z_span;
+  int min_z, max_z;
+  float thr_map, thr_exp, thr_cat;
+  unsigned allh_mask;            // feature rows that use the all-height projection (mapping.py:107-113)
+  int x1, y1;                    // paste window origin (mapping.py:130-133)
+  float half_cells;              // map_size_cm // (resolution*2) = 240
+  int toilet_ch;                 // obs channel of feat[0, 1+4]
+};
+
+// ---- 1. depth -> normalised coordinates (mapping.py:59-88) ----
+__global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict__ obs, float* __restrict__ coords,
+                                                         MapP P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  const int r = p / P.w, c = p - r * P.w;
+  const float d = obs[3 * P.N + p];
+  const float gx = (float)c, gz = (float)(P.h - 1 - r);
+  float X = ((gx - P.xc) * d) / P.f;          // get_point_cloud_from_z_t
+  float Z = ((gz - P.zc) * d) / P.f;
+  float Y = d;
+  Z = Z + P.agent_h;                          // transform_camera_view_t (R = I)
+  X = X + P.shift_x;                          // transform_pose_t (R = I, shift (250, 0))
+  Y = Y + 0.0f;
+  const float xs = (((X / P.res) - P.vr_half) / P.vr_f) * 2.0f;
+  const float ys = (((Y / P.res) - P.vr_half) / P.vr_f) * 2.0f;
+  const float zs = (((Z / P.res) - P.z_mid) / P.z_span) * 2.0f;
+  coords[p] = xs;
+  coords[P.N + p] = ys;
+  coords[2 * P.N + p] = zs;
+}
+
+// ---- 2. low-stairs heuristic: one workgroup, exact order statistics by 4x8-bit radix select ----
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// k-th smallest (0-based) of the in-range my_z values; all threads of the block participate.
+__device__ unsigned block_select(const float* zs, int N, int k, unsigned* hist, unsigned* bcast) {
+  unsigned prefix = 0, mask = 0;
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      const float z = zs[i];
+      if (z > -1.0f && z < 1.0f) {
+        const unsigned o = f2ord(z * 2.0f + 1.6f);
+        if ((o & mask) == prefix) atomicAdd(&hist[(o >> (8 * pass)) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, b = 0;
+      for (; b < 256; ++b) {
+        if (acc + (int)hist[b] > k) break;
+        acc += (int)hist[b];
+      }
+      bcast[0] = (unsigned)b;
+      bcast[1] = (unsigned)acc;
+    }
+    __syncthreads();
+    prefix |= bcast[0] << (8 * pass);
+    mask |= 255u << (8 * pass);
+    k -= (int)bcast[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(1024) void map_stairs_kernel(const float* __restrict__ coords, int* __restrict__ flag,
+                                                          MapP P) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned bcast[2];
+  __shared__ int cnt_n, cnt_mid;
+  const float* zs = coords + 2 * P.N;
+  if (threadIdx.x == 0) { cnt_n = 0; cnt_mid = 0; }
+  __syncthreads();
+  int n = 0, mid = 0;
+  for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
+    const float z = zs[i];
+    if (z > -1.0f && z < 1.0f) {
+      ++n;
+      const float m = z * 2.0f + 1.6f;
+      if (m > 0.2f && m < 0.7f) ++mid;
+    }
+  }
+  atomicAdd(&cnt_n, n);
+  atomicAdd(&cnt_mid, mid);
+  __syncthreads();
+  const int N_in = cnt_n, N_mid = cnt_mid;
+  if (N_in == 0) {
+    if (threadIdx.x == 0) *flag = 0;
+    return;
+  }
+  // torch.quantile(my_zs, 0.03), linear interpolation: ranks = q * (n-1) in fp32, lerp as one fma
+  const float ranks = 0.03f * (float)(N_in - 1);
+  const int k_lo = (int)ranks;
+  const int k_hi = (int)ceilf(ranks);
+  const float wgt = ranks - (float)k_lo;
+  const float a = ord2f(block_select(zs, P.N, k_lo, hist, bcast));
+  const float b = (k_hi == k_lo) ? a : ord2f(block_select(zs, P.N, k_hi, hist, bcast));
+  if (threadIdx.x == 0) {
+    const float diff = b - a;
+    const float q = (fabsf(wgt) < 0.5f) ? fmaf(wgt, diff, a) : fmaf(wgt - 1.0f, diff, b);
+    const bool take = (q > 0.2f) && ((float)N_mid > (float)(0.2 * (double)N_in));
+    *flag = take ? 1 : 0;
+  }
+}
+
+// ---- 3. splat position + base-cell key (depth_utils.py:217-236) ----
+__global__ __launch_bounds__(256) void map_keys_kernel(const float* __restrict__ obs, const float* __restrict__ coords,
+                                                       const int* __restrict__ flag, float* __restrict__ pos,
+                                                       unsigned* __restrict__ keys, unsigned* __restrict__ idx, MapP P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  float xs = coords[p], ys = coords[P.N + p], zs = coords[2 * P.N + p];
+  if (*flag) {
+    const bool below = (zs * 2.0f + 1.6f) < 0.7f;
+    const bool no_toilet = obs[P.toilet_ch * P.N + p] == 0.0f;
+    if (below && no_toilet) { xs = 99999.0f; ys = 99999.0f; zs = 99999.0f; }
+  }
+  const float px = (xs * (float)P.vr) / 2.0f + (float)P.vr / 2.0f;
+  const float py = (ys * (float)P.vr) / 2.0f + (float)P.vr / 2.0f;
+  const float pz = (zs * (float)P.zb) / 2.0f + (float)P.zb / 2.0f;
+  pos[p] = px;
+  pos[P.N + p] = py;
+  pos[2 * P.N + p] = pz;
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  unsigned key = INVALID_KEY;
+  // a point has at least one safe corner per dimension iff 0 <= floor <= dim-1
+  if (fx >= 0.0f && fx <= (float)(P.vr - 1) && fy >= 0.0f && fy <= (float)(P.vr - 1) && fz >= 0.0f &&
+      fz <= (float)(P.zb - 1))
+    key = ((unsigned)fx * (unsigned)P.vr + (unsigned)fy) * (unsigned)P.zb + (unsigned)fz;
+  keys[p] = key;
+  idx[p] = (unsigned)p;
+}
+
+// ---- 4. group heads ----
+__global__ __launch_bounds__(256) void map_heads_kernel(const unsigned* __restrict__ skey, int* __restrict__ cell_head,
+                                                        int N, int set) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const unsigned k = skey[i];
+  if (k != INVALID_KEY && (i == 0 || skey[i - 1] != k)) cell_head[k] = set ? i : -1;
+}
+
+// ---- 5. per-voxel replay of the 8 corner passes ----
+__global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict__ obs, const float* __restrict__ pos,
+                                                         const unsigned* __restrict__ skey,
+                                                         const unsigned* __restrict__ sidx,
+                                                         const int* __restrict__ cell_head, float* __restrict__ proj,
+                                                         MapP P) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)P.N * 8 * P.F;
+  if (t >= total) return;
+  const int f = (int)(t % P.F);
+  const int c = (int)((t / P.F) & 7);
+  const int i = (int)(t / (8 * P.F));
+  const unsigned k = skey[i];
+  if (k == INVALID_KEY || (i > 0 && skey[i - 1] == k)) return;   // not a group head
+  const int g2 = (int)(k % (unsigned)P.zb);
+  const int g1 = (int)((k / (unsigned)P.zb) % (unsigned)P.vr);
+  const int g0 = (int)(k / ((unsigned)P.zb * (unsigned)P.vr));
+  const int v0 = g0 + ((c >> 2) & 1), v1 = g1 + ((c >> 1) & 1), v2 = g2 + (c & 1);
+  // safe_ix: 0 < pos_ix < dim (strict), depth_utils.py:225
+  if (!(v0 > 0 && v0 < P.vr && v1 > 0 && v1 < P.vr && v2 > 0 && v2 < P.zb)) return;
+  // canonical owner of voxel v = the smallest corner c' whose floor cell v - c' is occupied
+  for (int cc = 0; cc < c; ++cc) {
+    const int h0 = v0 - ((cc >> 2) & 1), h1 = v1 - ((cc >> 1) & 1), h2 = v2 - (cc & 1);
+    if (h0 < 0 || h1 < 0 || h2 < 0) continue;   // (h <= dim-1 always holds since v < dim)
+    if (cell_head[(h0 * P.vr + h1) * P.zb + h2] >= 0) return;
+  }
+  float val = 0.0f;
+  const float fv0 = (float)v0, fv1 = (float)v1, fv2 = (float)v2;
+  for (int cc = 0; cc < 8; ++cc) {
+    const int h0 = v0 - ((cc >> 2) & 1), h1 = v1 - ((cc >> 1) & 1), h2 = v2 - (cc & 1);
+    if (h0 < 0 || h1 < 0 || h2 < 0) continue;
+    const unsigned hk = (unsigned)((h0 * P.vr + h1) * P.zb + h2);
+    const int hd = cell_head[hk];
+    if (hd < 0) continue;
+    for (int j = hd; j < P.N && skey[j] == hk; ++j) {
+      const int q = (int)sidx[j];
+      const float w0 = 1.0f - fabsf(pos[q] - fv0);
+      const float w1 = 1.0f - fabsf(pos[P.N + q] - fv1);
+      const float w2 = 1.0f - fabsf(pos[2 * P.N + q] - fv2);
+      const float wts = (w0 * w1) * w2;
+      const float ft = (f == 0) ? 1.0f : obs[(3 + f) * P.N + q];
+      val = val + ft * wts;            // scatter_add_ in point order
+    }
+    val = rintf(val);                  // torch.round of the whole grid after this pass
+  }
+  if (val != 0.0f) {
+    // voxels.transpose(2,3): projections are indexed [f][dim1][dim0]
+    const int o = (f * P.vr + v1) * P.vr + v0;
+    atomicAdd(&proj[o], val);                                                   // all_height_proj
+    if (v2 >= P.min_z && v2 < P.max_z) atomicAdd(&proj[P.F * P.vr * P.vr + o], val);   // agent_height_proj
+  }
+}
+
+// ---- 6. thresholds -> egocentric window, fp_map_pred; clears the projections for the next frame ----
+__global__ __launch_bounds__(256) void map_view_kernel(float* __restrict__ proj, float* __restrict__ view,
+                                                       float* __restrict__ fp_map_pred, MapP P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cells = P.vr * P.vr;
+  if (t >= cells) return;
+  float* all_h = proj;
+  float* agent_h = proj + P.F * cells;
+  const float a0 = agent_h[t], e0 = all_h[t];
+  const float m = fminf(fmaxf(a0 / P.thr_map, 0.0f), 1.0f);
+  const float e = fminf(fmaxf(e0 / P.thr_exp, 0.0f), 1.0f);
+  view[t] = m;
+  view[cells + t] = e;
+  view[2 * cells + t] = 0.0f;
+  view[3 * cells + t] = 0.0f;
+  fp_map_pred[t] = m;
+  for (int f = 1; f < P.F; ++f) {
+    const float v = ((P.allh_mask >> f) & 1u) ? all_h[f * cells + t] : agent_h[f * cells + t];
+    view[(3 + f) * cells + t] = fminf(fmaxf(v / P.thr_cat, 0.0f), 1.0f);
+  }
+  for (int f = 0; f < P.F; ++f) { all_h[f * cells + t] = 0.0f; agent_h[f * cells + t] = 0.0f; }
+}
+
+// ---- 7. pose integration (mapping.py:143-167) + affine thetas (model.py:19-38) ----
+struct WarpT { float c, s, tx, ty; };
+
+__global__ void map_pose_kernel(const float* __restrict__ rel, float* __restrict__ pose, WarpT* __restrict__ wt,
+                                MapP P) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float k = 57.29577951308232f;
+  float p0 = pose[0], p1 = pose[1], p2 = pose[2];
+  const float r0 = rel[0], r1 = rel[1], r2 = rel[2];
+  const float ang = p2 / k;
+  p1 = p1 + (r0 * sinf(ang) + r1 * cosf(ang));
+  p0 = p0 + (r0 * cosf(ang) - r1 * sinf(ang));
+  p2 = p2 + r2 * k;
+  p2 = fmodf(p2 - 180.0f, 360.0f) + 180.0f;
+  p2 = fmodf(p2 + 180.0f, 360.0f) - 180.0f;
+  pose[0] = p0; pose[1] = p1; pose[2] = p2;
+  const float sx = (-(((p0 * 100.0f) / P.res) - P.half_cells)) / P.half_cells;
+  const float sy = (-(((p1 * 100.0f) / P.res) - P.half_cells)) / P.half_cells;
+  const float st2 = 90.0f - p2;
+  const float tr = (st2 * 3.14159265358979323846f) / 180.0f;
+  wt->c = cosf(tr);
+  wt->s = sinf(tr);
+  wt->tx = sx;
+  wt->ty = sy;
+}
+
+// F.affine_grid base coordinate (align_corners=False): linspace(-1,1,n)[i] * (n-1) / n with ATen's
+// symmetric linspace (each half one fma) -- verified bit-exact against torch on the build host.
+__device__ __forceinline__ float base_coord(int i, int n) {
+  const float step = 2.0f / (float)(n - 1);
+  const float l = (i < n / 2) ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(n - i - 1), 1.0f);
+  return (l * (float)(n - 1)) / (float)n;
+}
+
+// agent_view[c] at integer pixel (y, x): the 100x100 window pasted at (y1, x1), zero elsewhere
+__device__ __forceinline__ float view_at(const float* __restrict__ view, int c, int y, int x, const MapP& P) {
+  const int wy = y - P.y1, wx = x - P.x1;
+  if ((unsigned)wy >= (unsigned)P.vr || (unsigned)wx >= (unsigned)P.vr) return 0.0f;
+  return view[(c * P.vr + wy) * P.vr + wx];
+}
+
+struct Tap { int x0, y0; float nw, ne, sw, se; bool any; };
+
+// grid_sample(bilinear, zeros, align_corners=True) tap for normalised coordinate (gx, gy)
+__device__ __forceinline__ Tap make_tap(float gx, float gy, int n) {
+  const float sf = (float)(n - 1) / 2.0f;
+  const float ix = (gx + 1.0f) * sf, iy = (gy + 1.0f) * sf;
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = ix - xw, e = 1.0f - w, nn = iy - yn, s = 1.0f - nn;
+  Tap t;
+  t.nw = s * e; t.ne = s * w; t.sw = nn * e; t.se = nn * w;
+  // clamp before the int conversion so far-out-of-range coordinates stay out of range
+  t.x0 = (int)fminf(fmaxf(xw, -2.0f), (float)n + 1.0f);
+  t.y0 = (int)fminf(fmaxf(yn, -2.0f), (float)n + 1.0f);
+  t.any = true;
+  return t;
+}
+
+// rotated[c][yy][xx] = grid_sample(agent_view, rot_grid)[c][yy][xx]; zero outside the image
+__device__ __forceinline__ float rotated_at(const float* __restrict__ view, int c, int yy, int xx, const Tap& rt,
+                                            bool in_img, const MapP& P) {
+  if (!in_img) return 0.0f;
+  const float nwv = view_at(view, c, rt.y0, rt.x0, P), nev = view_at(view, c, rt.y0, rt.x0 + 1, P);
+  const float swv = view_at(view, c, rt.y0 + 1, rt.x0, P), sev = view_at(view, c, rt.y0 + 1, rt.x0 + 1, P);
+  float acc = nwv * rt.nw;
+  acc = fmaf(nev, rt.ne, acc);
+  acc = fmaf(swv, rt.sw, acc);
+  acc = fmaf(sev, rt.se, acc);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__ view, const float* __restrict__ maps_last,
+                                                       float* __restrict__ map_pred, const WarpT* __restrict__ wtp,
+                                                       MapP P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int M = P.M;
+  if (t >= M * M) return;
+  const int y = t / M, x = t - y * M;
+  const WarpT wt = *wtp;
+  // translation grid (theta2 = [[1,-0,tx],[0,1,ty]]): bmm as an fma chain over k = 0,1,2
+  const float bx = base_coord(x, M), by = base_coord(y, M);
+  float gxt = bx * 1.0f; gxt = fmaf(by, -0.0f, gxt); gxt = fmaf(1.0f, wt.tx, gxt);
+  float gyt = bx * 0.0f; gyt = fmaf(by, 1.0f, gyt); gyt = fmaf(1.0f, wt.ty, gyt);
+  const Tap tt = make_tap(gxt, gyt, M);
+  // the four `rotated` pixels this output blends, each with its own rotation tap
+  Tap rt[4];
+  bool in_img[4], touch = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int yy = tt.y0 + (q >> 1), xx = tt.x0 + (q & 1);
+    in_img[q] = (unsigned)yy < (unsigned)M && (unsigned)xx < (unsigned)M;
+    if (in_img[q]) {
+      const float rbx = base_coord(xx, M), rby = base_coord(yy, M);
+      float gxr = rbx * wt.c; gxr = fmaf(rby, -wt.s, gxr); gxr = fmaf(1.0f, 0.0f, gxr);
+      float gyr = rbx * wt.s; gyr = fmaf(rby, wt.c, gyr); gyr = fmaf(1.0f, 0.0f, gyr);
+      rt[q] = make_tap(gxr, gyr, M);
+      // does this rotation tap reach the pasted window at all?
+      const bool hit = rt[q].x0 + 1 >= P.x1 && rt[q].x0 < P.x1 + P.vr && rt[q].y0 + 1 >= P.y1 && rt[q].y0 < P.y1 + P.vr;
+      in_img[q] = hit;      // a miss contributes exactly 0 (all four view taps are outside the window)
+      touch |= hit;
+    }
+  }
+  for (int c = 0; c < P.C; ++c) {
+    float tr = 0.0f;
+    if (touch && c != 2 && c != 3) {
+      const float v0 = rotated_at(view, c, tt.y0, tt.x0, rt[0], in_img[0], P);
+      const float v1 = rotated_at(view, c, tt.y0, tt.x0 + 1, rt[1], in_img[1], P);
+      const float v2 = rotated_at(view, c, tt.y0 + 1, tt.x0, rt[2], in_img[2], P);
+      const float v3 = rotated_at(view, c, tt.y0 + 1, tt.x0 + 1, rt[3], in_img[3], P);
+      tr = v0 * tt.nw;
+      tr = fmaf(v1, tt.ne, tr);
+      tr = fmaf(v2, tt.sw, tr);
+      tr = fmaf(v3, tt.se, tr);
+    }
+    const size_t o = (size_t)c * M * M + t;
+    map_pred[o] = fmaxf(maps_last[o], tr);     // torch.max over the stacked pair (mapping.py:175-177)
+  }
+}
+
+}  // namespace
+}  // namespace peanut
+
+using namespace peanut;
+
+struct peanut_map {
+  peanut_map_cfg cfg{};
+  MapP P{};
+  float* coords = nullptr;   // [3][N]
+  float* pos = nullptr;      // [3][N]
+  unsigned *keys = nullptr, *idx = nullptr, *skeys = nullptr, *sidx = nullptr;
+  int* cell_head = nullptr;  // [vr*vr*zb], -1 = empty
+  int* flag = nullptr;
+  float* proj = nullptr;     // [2][F][vr][vr]
+  float* view = nullptr;     // [C][vr][vr]
+  WarpT* wt = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  ~peanut_map() {
+    for (void* p : {(void*)coords, (void*)pos, (void*)keys, (void*)idx, (void*)skeys, (void*)sidx, (void*)cell_head,
+                    (void*)flag, (void*)proj, (void*)view, (void*)wt, sort_tmp})
+      if (p) (void)hipFree(p);
+  }
+};
+
+extern "C" {
+
+int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
+  if (!out || !c) return fail(PEANUT_EINVAL, "peanut_map_create: null argument");
+  if (c->du_scale != 1) return fail(PEANUT_EINVAL, "peanut_map_create: only du_scale == 1 is supported");
+  if (c->frame_height < 2 || c->frame_width < 2 || c->num_sem_categories < 5 || c->num_sem_categories > 28 ||
+      c->map_resolution < 1 || c->vision_range < 2 || c->global_downscaling < 1)
+    return fail(PEANUT_EINVAL, "peanut_map_create: unsupported configuration");
+  auto h = std::make_unique<peanut_map>();
+  h->cfg = *c;
+  MapP& P = h->P;
+  P.h = c->frame_height; P.w = c->frame_width; P.N = P.h * P.w;
+  P.ncat = c->num_sem_categories; P.F = 1 + P.ncat; P.C = 4 + P.ncat;
+  P.vr = c->vision_range;
+  const int res = c->map_resolution;
+  const int max_h = (int)(360 / res), min_h = (int)(-40 / res);      // mapping.py:31-32 (int() truncation)
+  P.zb = max_h - min_h;
+  const int local_cm = c->map_size_cm / c->global_downscaling;
+  P.M = local_cm / res;
+  if ((long long)P.vr * P.vr * P.zb >= (long long)INVALID_KEY)
+    return fail(PEANUT_EINVAL, "peanut_map_create: voxel grid too large for 20-bit keys");
+  // camera matrix in double like numpy, then to fp32 as torch does for python scalars
+  P.xc = (float)((P.w - 1.0) / 2.0);
+  P.zc = (float)((P.h - 1.0) / 2.0);
+  P.f = (float)((P.w / 2.0) / tan(c->hfov / 2.0 * 3.14159265358979323846 / 180.0));   // np.deg2rad(x) = x * pi / 180
+  P.agent_h = (float)(c->camera_height * 100.0);
+  P.shift_x = (float)(P.vr * res / 2);
+  P.res = (float)res;
+  P.vr_half = (float)(P.vr / 2);                 // vision_range // 2.
+  P.vr_f = (float)P.vr;
+  P.z_mid = floorf((float)(max_h + min_h) / 2.0f);   // (max_h + min_h) // 2.
+  P.z_span = (float)(max_h - min_h);
+  P.min_z = (int)(25.0 / res - min_h);
+  P.max_z = (int)((c->camera_height * 100.0 + 1) / res - min_h);
+  P.thr_map = (float)c->map_pred_threshold; P.thr_exp = (float)c->exp_pred_threshold; P.thr_cat = (float)c->cat_pred_threshold;
+  P.allh_mask = (P.ncat <= 16) ? ((1u << (1 + 5)) | (1u << (1 + 2))) : ((1u << (1 + 3)) | (1u << (1 + 9)) | (1u << (1 + 14)));
+  P.x1 = local_cm / (res * 2) - P.vr / 2;
+  P.y1 = local_cm / (res * 2);
+  P.half_cells = (float)(local_cm / (res * 2));
+  P.toilet_ch = 4 + 4;
+  if (P.y1 + P.vr > P.M || P.x1 < 0 || P.x1 + P.vr > P.M) return fail(PEANUT_EINVAL, "peanut_map_create: window outside map");
+  const size_t N = P.N, cells = (size_t)P.vr * P.vr;
+  PEANUT_HIP_CHECK(hipMalloc(&h->coords, 3 * N * sizeof(float)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->pos, 3 * N * sizeof(float)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->keys, N * sizeof(unsigned)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->idx, N * sizeof(unsigned)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->skeys, N * sizeof(unsigned)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->sidx, N * sizeof(unsigned)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->cell_head, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMemset(h->cell_head, 0xff, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->flag, sizeof(int)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->proj, 2 * P.F * cells * sizeof(float)));
+  PEANUT_HIP_CHECK(hipMemset(h->proj, 0, 2 * P.F * cells * sizeof(float)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->view, P.C * cells * sizeof(float)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->wt, sizeof(WarpT)));
+  PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, h->sort_tmp_bytes, h->keys, h->skeys, h->idx, h->sidx,
+                                                      (int)N, 0, 21, (hipStream_t)0));
+  PEANUT_HIP_CHECK(hipMalloc(&h->sort_tmp, h->sort_tmp_bytes ? h->sort_tmp_bytes : 16));
+  PEANUT_HIP_CHECK(hipDeviceSynchronize());
+  *out = h.release();
+  return 0;
+}
+
+void peanut_map_destroy(peanut_map_t* h) { delete h; }
+
+int peanut_map_dims(peanut_map_t* h, int dims[4]) {
+  if (!h || !dims) return fail(PEANUT_EINVAL, "null argument");
+  dims[0] = h->P.C; dims[1] = h->P.M; dims[2] = h->P.vr; dims[3] = h->P.N;
+  return 0;
+}
+
+int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
+                       float* poses_inout, float* fp_map_pred, float* map_pred, void* stream) {
+  if (!h || !obs || !pose_obs || !maps_last || !poses_inout || !fp_map_pred || !map_pred)
+    return fail(PEANUT_EINVAL, "peanut_map_forward: null argument");
+  if (maps_last == map_pred) return fail(PEANUT_EINVAL, "peanut_map_forward: map_pred must not alias maps_last");
+  hipStream_t s = (hipStream_t)stream;
+  const MapP& P = h->P;
+  const int nb = (P.N + 255) / 256;
+  hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, P);
+  hipLaunchKernelGGL(map_stairs_kernel, dim3(1), dim3(1024), 0, s, h->coords, h->flag, P);
+  hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->flag, h->pos, h->keys, h->idx, P);
+  size_t tmp = h->sort_tmp_bytes;
+  PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tmp, h->keys, h->skeys, h->idx, h->sidx, P.N, 0, 21, s));
+  hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 1);
+  const long long vt = (long long)P.N * 8 * P.F;
+  hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, obs, h->pos, h->skeys,
+                     h->sidx, h->cell_head, h->proj, P);
+  hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 0);
+  hipLaunchKernelGGL(map_view_kernel, dim3((P.vr * P.vr + 255) / 256), dim3(256), 0, s, h->proj, h->view, fp_map_pred, P);
+  hipLaunchKernelGGL(map_pose_kernel, dim3(1), dim3(64), 0, s, pose_obs, poses_inout, h->wt, P);
+  hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
+                     h->wt, P);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_map_forward: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"
