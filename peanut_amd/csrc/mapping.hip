@@ -6,9 +6,10 @@
 // chain of small kernels on one stream, with no host synchronisation and no dense voxel grid:
 //
 //   map_points   depth pixel -> normalised (x,y,z), SAME fp32 operation order as the reference
-//   map_stairs   low-stairs heuristic (mapping.py:90-97): counts + exact 3 % quantile by radix select
+//                (+ the five statistics that decide the low-stairs branch, mapping.py:90-97, exactly)
 //   map_keys     mask, splat position, base-cell key of every point
 //   (sort)       stable radix sort of (key, point index)  [rocPRIM via hipcub::DeviceRadixSort]
+//   map_gather   per sorted point: 1-D splat weights + feature values, contiguous
 //   map_heads    first sorted position of every occupied base cell -> dense lookup table
 //   map_voxels   one thread per (touched voxel, feature): replays the reference's 8 corner passes for
 //                that voxel only -- contributions added IN POINT ORDER, rintf after every pass -- and
@@ -55,29 +56,7 @@ struct MapP {
   int toilet_ch;                 // obs channel of feat[0, 1+4]
 };
 
-// ---- 1. depth -> normalised coordinates (mapping.py:59-88) ----
-__global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict__ obs, float* __restrict__ coords,
-                                                         MapP P) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P.N) return;
-  const int r = p / P.w, c = p - r * P.w;
-  const float d = obs[3 * P.N + p];
-  const float gx = (float)c, gz = (float)(P.h - 1 - r);
-  float X = ((gx - P.xc) * d) / P.f;          // get_point_cloud_from_z_t
-  float Z = ((gz - P.zc) * d) / P.f;
-  float Y = d;
-  Z = Z + P.agent_h;                          // transform_camera_view_t (R = I)
-  X = X + P.shift_x;                          // transform_pose_t (R = I, shift (250, 0))
-  Y = Y + 0.0f;
-  const float xs = (((X / P.res) - P.vr_half) / P.vr_f) * 2.0f;
-  const float ys = (((Y / P.res) - P.vr_half) / P.vr_f) * 2.0f;
-  const float zs = (((Z / P.res) - P.z_mid) / P.z_span) * 2.0f;
-  coords[p] = xs;
-  coords[P.N + p] = ys;
-  coords[2 * P.N + p] = zs;
-}
-
-// ---- 2. low-stairs heuristic: one workgroup, exact order statistics by 4x8-bit radix select ----
+// order-preserving float <-> uint maps (for atomicMax / atomicMin on floats)
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -86,86 +65,79 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// k-th smallest (0-based) of the in-range my_z values; all threads of the block participate.
-__device__ unsigned block_select(const float* zs, int N, int k, unsigned* hist, unsigned* bcast) {
-  unsigned prefix = 0, mask = 0;
-  for (int pass = 3; pass >= 0; --pass) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      const float z = zs[i];
-      if (z > -1.0f && z < 1.0f) {
-        const unsigned o = f2ord(z * 2.0f + 1.6f);
-        if ((o & mask) == prefix) atomicAdd(&hist[(o >> (8 * pass)) & 255u], 1u);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, b = 0;
-      for (; b < 256; ++b) {
-        if (acc + (int)hist[b] > k) break;
-        acc += (int)hist[b];
-      }
-      bcast[0] = (unsigned)b;
-      bcast[1] = (unsigned)acc;
-    }
-    __syncthreads();
-    prefix |= bcast[0] << (8 * pass);
-    mask |= 255u << (8 * pass);
-    k -= (int)bcast[1];
-    __syncthreads();
+// Statistics of the low-stairs heuristic (mapping.py:90-97), accumulated by map_points:
+//   [0] n      = #points with -1 < z < 1                      (len(my_zs))
+//   [1] mid    = #those with 0.2 < my_z < 0.7
+//   [2] le     = #those with my_z <= 0.2
+//   [3] max_le = max{my_z : my_z <= 0.2}  (ordered-uint)       [4] min_gt = min{my_z : my_z > 0.2}
+// torch.quantile(my_zs, 0.03) > 0.2 only needs the two order statistics around rank 0.03*(n-1):
+// both lie above 0.2 iff le <= k_lo, both at or below iff le >= k_hi + 1, and otherwise they are
+// exactly max_le and min_gt -- so no sort/selection is needed to reproduce the branch bit for bit.
+struct StairStats { unsigned n, mid, le, max_le, min_gt; };
+
+__device__ __forceinline__ bool stairs_branch(const StairStats& s) {
+  if (s.n == 0) return false;
+  const float ranks = 0.03f * (float)(s.n - 1);        // q (fp32 tensor) * last_index
+  const int k_lo = (int)ranks, k_hi = (int)ceilf(ranks);
+  bool q_gt;
+  if ((int)s.le <= k_lo) q_gt = true;
+  else if ((int)s.le >= k_hi + 1) q_gt = false;
+  else {
+    const float a = ord2f(s.max_le), b = ord2f(s.min_gt), wgt = ranks - (float)k_lo, diff = b - a;
+    const float q = (fabsf(wgt) < 0.5f) ? fmaf(wgt, diff, a) : fmaf(wgt - 1.0f, diff, b);   // ATen lerp
+    q_gt = q > 0.2f;
   }
-  return prefix;
+  return q_gt && ((float)s.mid > (float)(0.2 * (double)s.n));
 }
 
-__global__ __launch_bounds__(1024) void map_stairs_kernel(const float* __restrict__ coords, int* __restrict__ flag,
-                                                          MapP P) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned bcast[2];
-  __shared__ int cnt_n, cnt_mid;
-  const float* zs = coords + 2 * P.N;
-  if (threadIdx.x == 0) { cnt_n = 0; cnt_mid = 0; }
+// ---- 1. depth -> normalised coordinates (mapping.py:59-88) + stairs statistics ----
+__global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict__ obs, float* __restrict__ coords,
+                                                         StairStats* __restrict__ stats, MapP P) {
+  __shared__ unsigned s_n, s_mid, s_le, s_max, s_min;
+  if (threadIdx.x == 0) { s_n = 0; s_mid = 0; s_le = 0; s_max = 0u; s_min = 0xffffffffu; }
   __syncthreads();
-  int n = 0, mid = 0;
-  for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
-    const float z = zs[i];
-    if (z > -1.0f && z < 1.0f) {
-      ++n;
-      const float m = z * 2.0f + 1.6f;
-      if (m > 0.2f && m < 0.7f) ++mid;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P.N) {
+    const int r = p / P.w, c = p - r * P.w;
+    const float d = obs[3 * P.N + p];
+    const float gx = (float)c, gz = (float)(P.h - 1 - r);
+    float X = ((gx - P.xc) * d) / P.f;          // get_point_cloud_from_z_t
+    float Z = ((gz - P.zc) * d) / P.f;
+    float Y = d;
+    Z = Z + P.agent_h;                          // transform_camera_view_t (R = I)
+    X = X + P.shift_x;                          // transform_pose_t (R = I, shift (250, 0))
+    Y = Y + 0.0f;
+    const float xs = (((X / P.res) - P.vr_half) / P.vr_f) * 2.0f;
+    const float ys = (((Y / P.res) - P.vr_half) / P.vr_f) * 2.0f;
+    const float zs = (((Z / P.res) - P.z_mid) / P.z_span) * 2.0f;
+    coords[p] = xs;
+    coords[P.N + p] = ys;
+    coords[2 * P.N + p] = zs;
+    if (zs > -1.0f && zs < 1.0f) {
+      const float m = zs * 2.0f + 1.6f;
+      atomicAdd(&s_n, 1u);
+      if (m > 0.2f && m < 0.7f) atomicAdd(&s_mid, 1u);
+      if (m <= 0.2f) { atomicAdd(&s_le, 1u); atomicMax(&s_max, f2ord(m)); }
+      else atomicMin(&s_min, f2ord(m));
     }
   }
-  atomicAdd(&cnt_n, n);
-  atomicAdd(&cnt_mid, mid);
   __syncthreads();
-  const int N_in = cnt_n, N_mid = cnt_mid;
-  if (N_in == 0) {
-    if (threadIdx.x == 0) *flag = 0;
-    return;
-  }
-  // torch.quantile(my_zs, 0.03), linear interpolation: ranks = q * (n-1) in fp32, lerp as one fma
-  const float ranks = 0.03f * (float)(N_in - 1);
-  const int k_lo = (int)ranks;
-  const int k_hi = (int)ceilf(ranks);
-  const float wgt = ranks - (float)k_lo;
-  const float a = ord2f(block_select(zs, P.N, k_lo, hist, bcast));
-  const float b = (k_hi == k_lo) ? a : ord2f(block_select(zs, P.N, k_hi, hist, bcast));
-  if (threadIdx.x == 0) {
-    const float diff = b - a;
-    const float q = (fabsf(wgt) < 0.5f) ? fmaf(wgt, diff, a) : fmaf(wgt - 1.0f, diff, b);
-    const bool take = (q > 0.2f) && ((float)N_mid > (float)(0.2 * (double)N_in));
-    *flag = take ? 1 : 0;
+  if (threadIdx.x == 0 && s_n) {
+    atomicAdd(&stats->n, s_n);
+    if (s_mid) atomicAdd(&stats->mid, s_mid);
+    if (s_le) { atomicAdd(&stats->le, s_le); atomicMax(&stats->max_le, s_max); }
+    if (s_min != 0xffffffffu) atomicMin(&stats->min_gt, s_min);
   }
 }
 
 // ---- 3. splat position + base-cell key (depth_utils.py:217-236) ----
 __global__ __launch_bounds__(256) void map_keys_kernel(const float* __restrict__ obs, const float* __restrict__ coords,
-                                                       const int* __restrict__ flag, float* __restrict__ pos,
+                                                       const StairStats* __restrict__ stats, float* __restrict__ pos,
                                                        unsigned* __restrict__ keys, unsigned* __restrict__ idx, MapP P) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.N) return;
   float xs = coords[p], ys = coords[P.N + p], zs = coords[2 * P.N + p];
-  if (*flag) {
+  if (stairs_branch(*stats)) {
     const bool below = (zs * 2.0f + 1.6f) < 0.7f;
     const bool no_toilet = obs[P.toilet_ch * P.N + p] == 0.0f;
     if (below && no_toilet) { xs = 99999.0f; ys = 99999.0f; zs = 99999.0f; }
@@ -195,10 +167,34 @@ __global__ __launch_bounds__(256) void map_heads_kernel(const unsigned* __restri
   if (k != INVALID_KEY && (i == 0 || skey[i - 1] != k)) cell_head[k] = set ? i : -1;
 }
 
-// ---- 5. per-voxel replay of the 8 corner passes ----
-__global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict__ obs, const float* __restrict__ pos,
+// ---- 4b. per sorted point: the two 1-D weights per dimension and the feature values, in sorted order,
+// so that the voxel replay below reads contiguous memory instead of chasing sidx ----
+__global__ __launch_bounds__(256) void map_gather_kernel(const float* __restrict__ obs, const float* __restrict__ pos,
                                                          const unsigned* __restrict__ skey,
-                                                         const unsigned* __restrict__ sidx,
+                                                         const unsigned* __restrict__ sidx, float* __restrict__ wts6,
+                                                         float* __restrict__ feat_s, MapP P) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P.N) return;
+  const unsigned k = skey[j];
+  if (k == INVALID_KEY) return;
+  const int q = (int)sidx[j];
+  const float g2 = (float)(k % (unsigned)P.zb);
+  const float g1 = (float)((k / (unsigned)P.zb) % (unsigned)P.vr);
+  const float g0 = (float)(k / ((unsigned)P.zb * (unsigned)P.vr));
+  const float p0 = pos[q], p1 = pos[P.N + q], p2 = pos[2 * P.N + q];
+  // wts_ix = 1 - |pos - (floor + ix)|  (depth_utils.py:229)
+  wts6[0 * P.N + j] = 1.0f - fabsf(p0 - g0);
+  wts6[1 * P.N + j] = 1.0f - fabsf(p0 - (g0 + 1.0f));
+  wts6[2 * P.N + j] = 1.0f - fabsf(p1 - g1);
+  wts6[3 * P.N + j] = 1.0f - fabsf(p1 - (g1 + 1.0f));
+  wts6[4 * P.N + j] = 1.0f - fabsf(p2 - g2);
+  wts6[5 * P.N + j] = 1.0f - fabsf(p2 - (g2 + 1.0f));
+  for (int f = 1; f < P.F; ++f) feat_s[(f - 1) * P.N + j] = obs[(3 + f) * P.N + q];
+}
+
+// ---- 5. per-voxel replay of the 8 corner passes ----
+__global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict__ wts6, const float* __restrict__ feat_s,
+                                                         const unsigned* __restrict__ skey,
                                                          const int* __restrict__ cell_head, float* __restrict__ proj,
                                                          MapP P) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,23 +218,23 @@ __global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict
     if (cell_head[(h0 * P.vr + h1) * P.zb + h2] >= 0) return;
   }
   float val = 0.0f;
-  const float fv0 = (float)v0, fv1 = (float)v1, fv2 = (float)v2;
+  const float* fs = feat_s + (size_t)(f > 0 ? f - 1 : 0) * P.N;
   for (int cc = 0; cc < 8; ++cc) {
-    const int h0 = v0 - ((cc >> 2) & 1), h1 = v1 - ((cc >> 1) & 1), h2 = v2 - (cc & 1);
+    const int c0 = (cc >> 2) & 1, c1 = (cc >> 1) & 1, c2 = cc & 1;
+    const int h0 = v0 - c0, h1 = v1 - c1, h2 = v2 - c2;
     if (h0 < 0 || h1 < 0 || h2 < 0) continue;
     const unsigned hk = (unsigned)((h0 * P.vr + h1) * P.zb + h2);
     const int hd = cell_head[hk];
     if (hd < 0) continue;
+    const float* wa = wts6 + (size_t)c0 * P.N;
+    const float* wb = wts6 + (size_t)(2 + c1) * P.N;
+    const float* wc = wts6 + (size_t)(4 + c2) * P.N;
     for (int j = hd; j < P.N && skey[j] == hk; ++j) {
-      const int q = (int)sidx[j];
-      const float w0 = 1.0f - fabsf(pos[q] - fv0);
-      const float w1 = 1.0f - fabsf(pos[P.N + q] - fv1);
-      const float w2 = 1.0f - fabsf(pos[2 * P.N + q] - fv2);
-      const float wts = (w0 * w1) * w2;
-      const float ft = (f == 0) ? 1.0f : obs[(3 + f) * P.N + q];
-      val = val + ft * wts;            // scatter_add_ in point order
+      const float wts = (wa[j] * wb[j]) * wc[j];      // ((1*w0)*w1)*w2
+      const float ft = (f == 0) ? 1.0f : fs[j];
+      val = val + ft * wts;                           // scatter_add_ in point order
     }
-    val = rintf(val);                  // torch.round of the whole grid after this pass
+    val = rintf(val);                                 // torch.round of the whole grid after this pass
   }
   if (val != 0.0f) {
     // voxels.transpose(2,3): projections are indexed [f][dim1][dim0]
@@ -250,8 +246,10 @@ __global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict
 
 // ---- 6. thresholds -> egocentric window, fp_map_pred; clears the projections for the next frame ----
 __global__ __launch_bounds__(256) void map_view_kernel(float* __restrict__ proj, float* __restrict__ view,
-                                                       float* __restrict__ fp_map_pred, MapP P) {
+                                                       float* __restrict__ fp_map_pred, StairStats* __restrict__ stats,
+                                                       MapP P) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) { stats->n = 0; stats->mid = 0; stats->le = 0; stats->max_le = 0u; stats->min_gt = 0xffffffffu; }
   const int cells = P.vr * P.vr;
   if (t >= cells) return;
   float* all_h = proj;
@@ -402,7 +400,9 @@ struct peanut_map {
   float* pos = nullptr;      // [3][N]
   unsigned *keys = nullptr, *idx = nullptr, *skeys = nullptr, *sidx = nullptr;
   int* cell_head = nullptr;  // [vr*vr*zb], -1 = empty
-  int* flag = nullptr;
+  StairStats* stats = nullptr;
+  float* wts6 = nullptr;     // [6][N]
+  float* feat_s = nullptr;   // [ncat][N]
   float* proj = nullptr;     // [2][F][vr][vr]
   float* view = nullptr;     // [C][vr][vr]
   WarpT* wt = nullptr;
@@ -410,7 +410,7 @@ struct peanut_map {
   size_t sort_tmp_bytes = 0;
   ~peanut_map() {
     for (void* p : {(void*)coords, (void*)pos, (void*)keys, (void*)idx, (void*)skeys, (void*)sidx, (void*)cell_head,
-                    (void*)flag, (void*)proj, (void*)view, (void*)wt, sort_tmp})
+                    (void*)stats, (void*)wts6, (void*)feat_s, (void*)proj, (void*)view, (void*)wt, sort_tmp})
       if (p) (void)hipFree(p);
   }
 };
@@ -465,7 +465,13 @@ int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
   PEANUT_HIP_CHECK(hipMalloc(&h->sidx, N * sizeof(unsigned)));
   PEANUT_HIP_CHECK(hipMalloc(&h->cell_head, cells * P.zb * sizeof(int)));
   PEANUT_HIP_CHECK(hipMemset(h->cell_head, 0xff, cells * P.zb * sizeof(int)));
-  PEANUT_HIP_CHECK(hipMalloc(&h->flag, sizeof(int)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->stats, sizeof(StairStats)));
+  {
+    const StairStats init = {0u, 0u, 0u, 0u, 0xffffffffu};   // map_view re-arms it after every frame
+    PEANUT_HIP_CHECK(hipMemcpy(h->stats, &init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  PEANUT_HIP_CHECK(hipMalloc(&h->wts6, 6 * N * sizeof(float)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->feat_s, (size_t)P.ncat * N * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->proj, 2 * P.F * cells * sizeof(float)));
   PEANUT_HIP_CHECK(hipMemset(h->proj, 0, 2 * P.F * cells * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->view, P.C * cells * sizeof(float)));
@@ -494,17 +500,18 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
   hipStream_t s = (hipStream_t)stream;
   const MapP& P = h->P;
   const int nb = (P.N + 255) / 256;
-  hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, P);
-  hipLaunchKernelGGL(map_stairs_kernel, dim3(1), dim3(1024), 0, s, h->coords, h->flag, P);
-  hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->flag, h->pos, h->keys, h->idx, P);
+  hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, P);
+  hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, h->pos, h->keys, h->idx, P);
   size_t tmp = h->sort_tmp_bytes;
   PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tmp, h->keys, h->skeys, h->idx, h->sidx, P.N, 0, 21, s));
   hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 1);
   const long long vt = (long long)P.N * 8 * P.F;
-  hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, obs, h->pos, h->skeys,
-                     h->sidx, h->cell_head, h->proj, P);
+  hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(256), 0, s, obs, h->pos, h->skeys, h->sidx, h->wts6, h->feat_s, P);
+  hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, h->wts6, h->feat_s, h->skeys,
+                     h->cell_head, h->proj, P);
   hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 0);
-  hipLaunchKernelGGL(map_view_kernel, dim3((P.vr * P.vr + 255) / 256), dim3(256), 0, s, h->proj, h->view, fp_map_pred, P);
+  hipLaunchKernelGGL(map_view_kernel, dim3((P.vr * P.vr + 255) / 256), dim3(256), 0, s, h->proj, h->view, fp_map_pred,
+                     h->stats, P);
   hipLaunchKernelGGL(map_pose_kernel, dim3(1), dim3(64), 0, s, pose_obs, poses_inout, h->wt, P);
   hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
                      h->wt, P);

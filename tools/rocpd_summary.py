@@ -8,7 +8,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    name = name.replace("peanut::", "").replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").replace("peanut::", "").replace("void ", "")
     if "(" in name:
         name = name[:name.index("(")]
     return name[:90]
