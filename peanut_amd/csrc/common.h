@@ -63,6 +63,10 @@ int launch_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, in
 // adaptive average pooling of [B,H,W,C] into all pyramid bins: out [B,nbins_total,C]
 int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, const int* scales, int nscales,
                     hipStream_t s);
+// two-pass form (reads x once); scratch = ppm_pool_scratch_floats(...) floats (0 -> falls back to the above)
+size_t ppm_pool_scratch_floats(int B, int H, int C, const int* scales, int nscales);
+int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, int W, int C, const int* scales,
+                     int nscales, hipStream_t s);
 // bilinear (align_corners=False) upsample of the pooled pyramid + channel concat: out [B,H,W,nscales*Cp]
 int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int W, int Cp, const int* scales,
                                int nscales, int align_corners, hipStream_t s);

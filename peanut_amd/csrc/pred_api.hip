@@ -328,7 +328,18 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   int nbins = 0;
   for (int i = 0; i < h->cfg.n_pool_scales; ++i) nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
   Act pooled = make_act(ar, B, 1, nbins, x.C);
-  { Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.kernel = "ppm_pool"; op.in = x; op.out = pooled; pl->ops.push_back(op); }
+  {
+    Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.kernel = "ppm_pool"; op.in = x; op.out = pooled;
+    const size_t sf = ppm_pool_scratch_floats(B, x.H, x.C, h->cfg.pool_scales, h->cfg.n_pool_scales);
+    if (sf) {   // per-row partial sums of the two-pass pooling
+      Act scr; scr.B = 1; scr.H = 1; scr.W = 1; scr.C = 0; scr.bytes = sf * sizeof(float); scr.off = ar.alloc(scr.bytes);
+      op.in2 = scr; op.has_in2 = true;
+      pl->ops.push_back(op);
+      rel(scr);
+    } else {
+      pl->ops.push_back(op);
+    }
+  }
   Act table = make_act(ar, B, 1, nbins, h->cfg.head_channels);
   // pooled/table are SCALE-MAJOR [scale][B][k*k][C] (pspnet_aux.hip: ppm_pool_kernel), so the 1x1 conv
   // of each scale (psp_head.py:39-46) runs on one contiguous [B*k*k, C] matrix.
@@ -435,8 +446,8 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:
-      return launch_ppm_pool(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, h->cfg.pool_scales,
-                             h->cfg.n_pool_scales, s);
+      return launch_ppm_pool2(P(op.in), op.has_in2 ? P(op.in2) : nullptr, P(op.out), op.in.B, op.in.H, op.in.W, op.in.C,
+                              h->cfg.pool_scales, h->cfg.n_pool_scales, s);
     case OP_PPM_UP:
       return launch_ppm_upsample_concat(P(op.in), P(op.out), op.out.B, op.out.H, op.out.W, h->cfg.head_channels,
                                         h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s);

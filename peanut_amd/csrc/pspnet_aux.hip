@@ -136,6 +136,99 @@ int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, cons
   return e == hipSuccess ? 0 : fail(-3, std::string("ppm_pool: ") + hipGetErrorString(e));
 }
 
+// ---- pyramid pooling, two-pass form: the feature map is read ONCE ----
+// Pass 1 (one workgroup per (row y, image b, 1024-channel slab)): for every pyramid scale and every
+// bin column, the sum over that bin's x-range of row y  -> rowsum[b][y][slot][C]  (slot = scale-major
+// bin-column index, at most PPM_MAX_SLOTS = sum of the scales).  Pass 2 adds a bin's rows and divides.
+// The single-pass kernel above stays as the fallback for exotic scale sets.
+#define PPM_MAX_SLOTS 16
+struct PpmSlots { short x0[PPM_MAX_SLOTS], x1[PPM_MAX_SLOTS]; int n; };
+
+__global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict__ x, float* __restrict__ rowsum, int H,
+                                                         int W, int C, PpmSlots sl) {
+  const int y = blockIdx.x, b = blockIdx.y;
+  const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  float4 acc[PPM_MAX_SLOTS];
+#pragma unroll
+  for (int s = 0; s < PPM_MAX_SLOTS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* row = x + (((size_t)b * H + y) * W) * C + c;
+  for (int xx = 0; xx < W; ++xx) {
+    const float4 v = *reinterpret_cast<const float4*>(row + (size_t)xx * C);
+#pragma unroll
+    for (int s = 0; s < PPM_MAX_SLOTS; ++s) {
+      if (s < sl.n && xx >= sl.x0[s] && xx < sl.x1[s]) {
+        acc[s].x += v.x; acc[s].y += v.y; acc[s].z += v.z; acc[s].w += v.w;
+      }
+    }
+  }
+  float* out = rowsum + (((size_t)b * H + y) * sl.n) * C + c;
+#pragma unroll
+  for (int s = 0; s < PPM_MAX_SLOTS; ++s)
+    if (s < sl.n) *reinterpret_cast<float4*>(out + (size_t)s * C) = acc[s];
+}
+
+__global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict__ rowsum, float* __restrict__ out, int H,
+                                                         int W, int C, PpmScales sc, int nslots) {
+  const int bin = blockIdx.x, b = blockIdx.y;
+  const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  int k = 0, local = bin, before = 0, slot0 = 0;
+  for (int i = 0; i < sc.n; ++i) {
+    const int kk = sc.s[i];
+    if (local < kk * kk) { k = kk; break; }
+    local -= kk * kk;
+    before += kk * kk;
+    slot0 += kk;
+  }
+  const int by = local / k, bx = local - by * k;
+  const int y0 = (by * H) / k, y1 = ((by + 1) * H + k - 1) / k;
+  const int x0 = (bx * W) / k, x1 = ((bx + 1) * W + k - 1) / k;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int yy = y0; yy < y1; ++yy) {
+    const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)b * H + yy) * nslots + slot0 + bx) * C + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float cnt = (float)((y1 - y0) * (x1 - x0));
+  acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
+  const size_t row = (size_t)gridDim.y * before + (size_t)b * k * k + local;
+  *reinterpret_cast<float4*>(out + row * C + c) = acc;
+}
+
+size_t ppm_pool_scratch_floats(int B, int H, int C, const int* scales, int nscales) {
+  int slots = 0;
+  for (int i = 0; i < nscales; ++i) slots += scales[i];
+  if (slots > PPM_MAX_SLOTS) return 0;      // fallback kernel needs no scratch
+  return (size_t)B * H * slots * C;
+}
+
+int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, int W, int C, const int* scales,
+                     int nscales, hipStream_t s) {
+  if (nscales > 8 || C % 4) return fail(-2, "ppm_pool: unsupported configuration");
+  PpmScales sc;
+  PpmSlots sl;
+  sc.n = nscales;
+  sl.n = 0;
+  int nbins = 0;
+  for (int i = 0; i < nscales; ++i) {
+    const int k = scales[i];
+    sc.s[i] = k;
+    nbins += k * k;
+    for (int bx = 0; bx < k; ++bx) {
+      if (sl.n >= PPM_MAX_SLOTS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+      sl.x0[sl.n] = (short)((bx * W) / k);
+      sl.x1[sl.n] = (short)(((bx + 1) * W + k - 1) / k);
+      ++sl.n;
+    }
+  }
+  if (!scratch) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+  const int slabs = (C / 4 + 255) / 256;
+  hipLaunchKernelGGL(ppm_rowsum_kernel, dim3(H, B, slabs), dim3(256), 0, s, x, scratch, H, W, C, sl);
+  hipLaunchKernelGGL(ppm_binsum_kernel, dim3(nbins, B, slabs), dim3(256), 0, s, scratch, out, H, W, C, sc, sl.n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(-3, std::string("ppm_pool2: ") + hipGetErrorString(e));
+}
+
 // ---- bilinear source index/weight, ATen upsample_bilinear2d semantics ----
 __device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size, int align_corners, int* i0,
                                              int* i1, float* l1) {
@@ -208,6 +301,9 @@ int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int
   return e == hipSuccess ? 0 : fail(-3, std::string("ppm_upsample: ") + hipGetErrorString(e));
 }
 
+int launch_ppm_conv_term_l2(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
+                            int align_corners, hipStream_t s);
+
 // ---- pyramid half of the PSP bottleneck conv, folded through linearity ----
 // The reference convolves cat([x, up(p_1), up(p_2), up(p_3), up(p_6)]) with a 3x3 kernel
 // (psp_head.py:107-110).  The pyramid half of that sum is low-rank: up(p_s) is a bilinear
@@ -268,8 +364,134 @@ __global__ __launch_bounds__(256) void ppm_conv_term_kernel(const float* __restr
   }
 }
 
+// LDS-staged form of the same evaluation: one workgroup per (image, 32-channel chunk) keeps that
+// image's folded tables Q[all bins][9 taps][32 ch] (57.6 KB for the (1,2,3,6) pyramid) and the
+// per-coordinate bilinear taps in LDS and sweeps the image row by row with a separable evaluation
+// (24 LDS reads per output instead of 144 L2 round trips).
+struct BlTap { short i0, i1; float l; };
+
+__global__ __launch_bounds__(256) void ppm_conv_term_lds_kernel(const float* __restrict__ Q, float* __restrict__ R,
+                                                                int H, int W, int C, PpmScales sc, int B, int nbins,
+                                                                int align_corners) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int CH = 32;                                   // channels per workgroup
+  float* q = reinterpret_cast<float*>(lds_raw);            // [nbins][9][CH]
+  BlTap* taps = reinterpret_cast<BlTap*>(lds_raw + (size_t)nbins * 9 * CH * sizeof(float));   // [n][2][L+2]
+  const int L = (H > W ? H : W) + 2;
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  // stage Q (rows are scale-major: row(s, b, g) = B*base_s + b*k*k + g)
+  {
+    int base = 0;
+    for (int s = 0; s < sc.n; ++s) {
+      const int k = sc.s[s], cells = k * k;
+      const float* src = Q + ((size_t)B * base + (size_t)b * cells) * (9 * C) + c0;
+      for (int i = threadIdx.x; i < cells * 9 * (CH / 4); i += blockDim.x) {
+        const int v4 = i % (CH / 4), rt = i / (CH / 4);        // rt = cell*9 + tap
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)rt * C + v4 * 4);
+        *reinterpret_cast<float4*>(q + ((size_t)(base * 9 + rt)) * CH + v4 * 4) = v;
+      }
+      base += cells;
+    }
+  }
+  for (int i = threadIdx.x; i < sc.n * 2 * L; i += blockDim.x) {
+    const int s = i / (2 * L), r = i - s * 2 * L, dim = r / L, t = r - dim * L;   // coordinate = t - 1
+    const int n = dim == 0 ? H : W, coord = t - 1;
+    BlTap tp;
+    tp.i0 = -1; tp.i1 = -1; tp.l = 0.f;
+    if ((unsigned)coord < (unsigned)n) {
+      int i0, i1;
+      float l;
+      bilinear_src(coord, sc.s[s], n, align_corners, &i0, &i1, &l);
+      tp.i0 = (short)i0; tp.i1 = (short)i1; tp.l = l;
+    }
+    taps[i] = tp;
+  }
+  __syncthreads();
+  // Separable evaluation, one output row at a time.  The x-interpolation weights do not depend on the
+  // vertical tap, so the three vertical taps are folded first:
+  //     S[s][gx][dx][n] = sum_dy inb(y+dy-1) * ( hy*Q_s[y0][gx][dy*3+dx][n] + ly*Q_s[y1][gx][dy*3+dx][n] )
+  //     R[y][x][n]      = sum_s sum_dx inb(x+dx-1) * ( hx*S[s][x0][dx][n] + lx*S[s][x1][dx][n] )
+  // -> 24 LDS reads per output instead of 144.
+  float* srow = reinterpret_cast<float*>(taps + (size_t)sc.n * 2 * L);       // [slots][3][CH], slots = sum_s k_s
+  int slots = 0;
+  for (int s = 0; s < sc.n; ++s) slots += sc.s[s];
+  for (int yy = 0; yy < H; ++yy) {
+    for (int i = threadIdx.x; i < slots * 3 * (CH / 4); i += blockDim.x) {
+      const int g = i % (CH / 4), r = i / (CH / 4), dx = r % 3, slot = r / 3;
+      int s = 0, gx = slot, base = 0;
+      while (gx >= sc.s[s]) { gx -= sc.s[s]; base += sc.s[s] * sc.s[s]; ++s; }
+      const int k = sc.s[s];
+      const BlTap* ty = taps + (s * 2 + 0) * L + yy;
+      const float* qs = q + (size_t)base * 9 * CH + g * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const BlTap t = ty[dy];
+        if (t.i0 < 0) continue;
+        const float hy = 1.f - t.l;
+        const float4 v0 = *reinterpret_cast<const float4*>(qs + ((t.i0 * k + gx) * 9 + dy * 3 + dx) * CH);
+        const float4 v1 = *reinterpret_cast<const float4*>(qs + ((t.i1 * k + gx) * 9 + dy * 3 + dx) * CH);
+        acc.x += hy * v0.x + t.l * v1.x; acc.y += hy * v0.y + t.l * v1.y;
+        acc.z += hy * v0.z + t.l * v1.z; acc.w += hy * v0.w + t.l * v1.w;
+      }
+      *reinterpret_cast<float4*>(srow + (size_t)r * CH + g * 4) = acc;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < W * (CH / 4); it += blockDim.x) {
+      const int g = it % (CH / 4), xx = it / (CH / 4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int slot0 = 0;
+      for (int s = 0; s < sc.n; ++s) {
+        const BlTap* tx = taps + (s * 2 + 1) * L + xx;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const BlTap t = tx[dx];
+          if (t.i0 < 0) continue;
+          const float hx = 1.f - t.l;
+          const float4 v0 = *reinterpret_cast<const float4*>(srow + ((size_t)(slot0 + t.i0) * 3 + dx) * CH + g * 4);
+          const float4 v1 = *reinterpret_cast<const float4*>(srow + ((size_t)(slot0 + t.i1) * 3 + dx) * CH + g * 4);
+          acc.x += hx * v0.x + t.l * v1.x; acc.y += hx * v0.y + t.l * v1.y;
+          acc.z += hx * v0.z + t.l * v1.z; acc.w += hx * v0.w + t.l * v1.w;
+        }
+        slot0 += sc.s[s];
+      }
+      *reinterpret_cast<float4*>(R + (((size_t)b * H + yy) * W + xx) * C + c0 + g * 4) = acc;
+    }
+    __syncthreads();
+  }
+}
+
 int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
                          int align_corners, hipStream_t s) {
+  if (nscales <= 8 && C % 32 == 0) {
+    PpmScales sc;
+    sc.n = nscales;
+    int nbins = 0;
+    for (int i = 0; i < nscales; ++i) { sc.s[i] = scales[i]; nbins += scales[i] * scales[i]; }
+    const int L = (H > W ? H : W) + 2;
+    int slots = 0;
+    for (int i = 0; i < nscales; ++i) slots += scales[i];
+    const size_t lds = (size_t)nbins * 9 * 32 * sizeof(float) + (size_t)nscales * 2 * L * sizeof(BlTap) +
+                       (size_t)slots * 3 * 32 * sizeof(float);
+    if (lds <= 150 * 1024) {    // the (1,2,3,6) pyramid needs 66 KB at 60x60: above the 64 KB default limit
+      static bool raised = false;
+      if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppm_conv_term_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return fail(-3, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        raised = true;
+      }
+      hipLaunchKernelGGL(ppm_conv_term_lds_kernel, dim3(C / 32, B), dim3(256), lds, s, Q, R, H, W, C, sc, B, nbins,
+                         align_corners);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? 0 : fail(-3, std::string("ppm_conv_term_lds: ") + hipGetErrorString(e));
+    }
+  }
+  return launch_ppm_conv_term_l2(Q, R, B, H, W, C, scales, nscales, align_corners, s);
+}
+
+int launch_ppm_conv_term_l2(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
+                            int align_corners, hipStream_t s) {
   if (nscales > 8 || C % 4) return fail(-2, "ppm_conv_term: unsupported configuration");
   PpmScales sc;
   sc.n = nscales;
