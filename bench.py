@@ -58,7 +58,11 @@ def synth_maps(b: int, c: int, s: int, device, seed0: int = 0) -> torch.Tensor:
 def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 20.0, max_maps: int = 8):
     """Oracle (= bit-exact restatement of the reference's CPU PyTorch path) on the host cores."""
     from oracle import pspnet_ref
-    threads = torch.get_num_threads()
+    # tools/cpu_baseline_sweep.py on the MI355X box's 2x EPYC 9575F (profiles/cpu_baseline_sweep_r1.json):
+    # 16 threads at batch 1 is this path's best single-process configuration (5.8 maps/s; torch's
+    # default of 128 threads gives 1.0), so that is what the CPU baseline gets.
+    threads = int(os.environ.get("PEANUT_CPU_THREADS", min(16, os.cpu_count() or 1)))
+    torch.set_num_threads(threads)
     x = synth_maps(1, cfg.in_channels, s, "cpu", seed0=10_000)
     pspnet_ref.forward_batch(sd, x, cfg)                      # warm-up (oneDNN primitive cache)
     n, t0 = 0, time.perf_counter()
@@ -81,6 +85,9 @@ def main():
     ap.add_argument("--channels", type=int, default=14, help="4 + N_cat input channels")
     ap.add_argument("--precision", default=os.environ.get("PEANUT_PRECISION", "fp32"),
                     choices=sorted(PEAK_TFLOPS), help="conv arithmetic (include/peanut_hip.h PEANUT_PREC_*)")
+    ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO", "bf16x3"),
+                    help="comma list of extra precision modes measured after the main run and reported under "
+                         "'modes' (empty string to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-op HIP-event probe")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) here")
@@ -96,56 +103,69 @@ def main():
     from peanut_amd.prediction import PEANUT_Prediction_Model
     cfg = PredCfg(in_channels=args.channels)
     sd = make_seeded_state_dict(cfg, seed=0)
-    model = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=dev.index), state_dict=sd, cfg=cfg,
-                                    precision=args.precision)
     B, S = args.batch, args.size
     # this rank's shard of the global batch (weak scaling: B maps per GPU)
     x = synth_maps(B, cfg.in_channels, S, dev, seed0=rank * B)
     out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=dev)
 
-    for _ in range(args.warmup):
-        model.get_prediction_batch(x, apply_sigmoid=True, out=out)
-    torch.cuda.synchronize()
-    if not args.no_probe:
-        model.model.probe_enable(True)
-    pdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.get_prediction_batch(x, apply_sigmoid=True, out=out)
-    torch.cuda.synchronize()
-    pdist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = pdist.max_over_ranks(elapsed, device=dev)
+    def run_mode(precision, steps, warmup, op_table=""):
+        """W untimed warm-up steps, then exactly `steps` timed steps bracketed by barrier + synchronize;
+        returns (max-over-ranks seconds, roofline dict)."""
+        model = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=dev.index), state_dict=sd, cfg=cfg,
+                                        precision=precision)
+        for _ in range(warmup):
+            model.get_prediction_batch(x, apply_sigmoid=True, out=out)
+        torch.cuda.synchronize()
+        if not args.no_probe:
+            model.model.probe_enable(True)
+        pdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.get_prediction_batch(x, apply_sigmoid=True, out=out)
+        torch.cuda.synchronize()
+        pdist.barrier()
+        elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+        roof = None
+        if not args.no_probe:
+            nf, rows = model.model.probe_collect()
+            model.model.probe_enable(False)
+            fam = {}
+            for name, kern, ms, fl in rows:
+                f = fam.setdefault(kern, {"ms": 0.0, "flops": 0.0, "launches": 0})
+                f["ms"] += ms
+                f["flops"] += fl * nf
+                f["launches"] += nf
+            k, f = max(fam.items(), key=lambda kv: kv[1]["ms"])
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[precision]
+            roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "launches_per_step": f["launches"] // max(nf, 1),
+                    "avg_launch_ms": round(f["ms"] / max(f["launches"], 1), 4),
+                    "flops_per_launch": f["flops"] / max(f["launches"], 1),
+                    "share_of_step_time": round(f["ms"] / max(sum(v["ms"] for v in fam.values()), 1e-9), 4)}
+            if op_table and rank == 0:
+                with open(op_table, "w") as fh:
+                    json.dump({"forwards": nf, "B": B, "S": S, "precision": precision,
+                               "ops": [{"op": n_, "kernel": k_, "ms": ms / nf, "gflop": fl / 1e9,
+                                        "tflops": (fl / (ms / nf * 1e-3) / 1e12) if ms > 0 and fl > 0 else None}
+                                       for n_, k_, ms, fl in rows],
+                               "families": {k_: {"ms_per_step": v["ms"] / nf,
+                                                 "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None}
+                                            for k_, v in fam.items()}}, fh, indent=1)
+        del model
+        return elapsed, roof
 
-    roof = None
-    if not args.no_probe:
-        nf, rows = model.model.probe_collect()
-        model.model.probe_enable(False)
-        fam = {}
-        for name, kern, ms, fl in rows:
-            f = fam.setdefault(kern, {"ms": 0.0, "flops": 0.0, "launches": 0})
-            f["ms"] += ms
-            f["flops"] += fl * nf
-            f["launches"] += nf
-        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        k, f = dom
-        ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                "launches_per_step": f["launches"] // max(nf, 1),
-                "avg_launch_ms": round(f["ms"] / max(f["launches"], 1), 4),
-                "flops_per_launch": f["flops"] / max(f["launches"], 1),
-                "share_of_step_time": round(f["ms"] / max(sum(v["ms"] for v in fam.values()), 1e-9), 4)}
-        if args.op_table and rank == 0:
-            with open(args.op_table, "w") as fh:
-                json.dump({"forwards": nf, "B": B, "S": S,
-                           "ops": [{"op": n_, "kernel": k_, "ms": ms / nf, "gflop": fl / 1e9,
-                                    "tflops": (fl / (ms / nf * 1e-3) / 1e12) if ms > 0 and fl > 0 else None}
-                                   for n_, k_, ms, fl in rows],
-                           "families": {k_: {"ms_per_step": v["ms"] / nf, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None}
-                                        for k_, v in fam.items()}}, fh, indent=1)
+    elapsed, roof = run_mode(args.precision, args.steps, args.warmup, args.op_table)
+    modes = {}
+    for extra in [m for m in args.also.split(",") if m and m != args.precision]:
+        e_s, e_roof = run_mode(extra, max(3, args.steps // 2), 2)
+        st = max(3, args.steps // 2)
+        modes[extra] = {"value": round(world * B * st / e_s, 3), "unit": "maps/s", "ms_per_step": round(e_s / st * 1e3, 3),
+                        "dtype": DTYPE[extra], "steps": st, "roofline": e_roof,
+                        "note": "opt-in split-precision conv mode (3 x 16-bit MFMA products per fp32 product, fp32 "
+                                "accumulate; 1.3e-4 max-abs vs the fp32 reference, bound 1e-3); not the headline value"}
 
     # logging-only collective: collate the predicted maps of the last step (untimed)
     gather_ms = None
@@ -173,10 +193,12 @@ def main():
                                    f"{cfg.num_classes}-class prediction forward (PSPNet R50-V1c-D8), "
                                    f"batch {B} per GPU, seeded random-init weights",
                        "global_batch": world * B, "parallelism": f"dp{world} (map shards, no data-path collective)"},
-            "gflop_per_map": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
-            "whole_forward_tflops": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
+            "gflop_per_map_nominal": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
+            "whole_forward_tflops_nominal": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if modes:
+            line["modes"] = modes
         if gather_ms is not None:
             line["allgather_maps_ms"] = round(gather_ms, 3)
         print(json.dumps(line), flush=True)
