@@ -153,6 +153,14 @@ int peanut_map_dims(peanut_map_t* h, int dims[4]);
 int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
                        float* poses_inout, float* fp_map_pred, float* map_pred, void* stream);
 
+/* Observation formatting, Agent_Helper._preprocess_obs/_preprocess_depth
+ * (nav/agent/agent_helper.py:175-217): per-column invalid-depth fill, >0.99 -> far, metres -> cm
+ * (min_d*100 + d*(max_d-min_d)*100 in fp32), then rows/cols ds//2::ds of RGB (the reference's PIL
+ * NEAREST resize picks the same pixels), depth and semantics.  rgb [H,W,3] uint8, depth [H,W] fp32 in
+ * [0,1] (0 = invalid), sem [H,W,ncat] fp32 -> obs [3+1+ncat, H/ds, W/ds] fp32. */
+int peanut_preprocess_obs(const uint8_t* rgb, const float* depth, const float* sem, int H, int W, int ncat, int ds,
+                          float min_d, float max_d, float* obs, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Stage 1 -- per-instance mask accumulation of SemanticPredMaskRCNN.get_prediction
  * (nav/agent/utils/segmentation.py:47-60): for every detected instance j whose class is in

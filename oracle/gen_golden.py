@@ -78,11 +78,9 @@ def main():
     torch.set_num_threads(8)
     report = {"pspnet": {}, "mapping": {}, "torch": torch.__version__}
     gen_pspnet(report)
-    try:
-        from oracle import gen_golden_mapping
-        gen_golden_mapping.generate(report)
-    except ImportError:
-        pass
+    from oracle import gen_golden_agent, gen_golden_mapping
+    gen_golden_mapping.generate(report)
+    gen_golden_agent.generate(report)
     with open(os.path.join(GOLDEN, "golden_report.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
 

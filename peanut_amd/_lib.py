@@ -68,6 +68,7 @@ SIGNATURES = {
     "peanut_map_destroy": (None, [_P]),
     "peanut_map_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
     "peanut_map_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_int, _P, _P]),
     "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 10),

@@ -1,0 +1,47 @@
+"""Habitat-free replay of the reference's episode/step loop (nav/collect.py:44-84 +
+PEANUT_Agent.act, nav/agent/peanut_agent.py:38-68) over recorded -- or synthetic -- frame tuples:
+per step  seg mask accumulation -> observation formatting -> map projection -> (every
+update_goal_freq steps) map prediction, with episodes sharded over ranks exactly like the
+reference's ``--start_ep/--end_ep`` flags.  Planning/acting needs the simulator and is not here."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+
+from . import dist as pdist
+from .agent_helper import preprocess_obs
+from .agent_state import Agent_State
+from .segmentation import accumulate_instances
+
+
+def run_episode(state: Agent_State, frames: Iterable[Dict], goal_cat: int,
+                on_step: Optional[Callable[[int, Agent_State, bool], None]] = None) -> int:
+    """frames: dicts with either a ready ``obs`` [1,C,h,w] HIP tensor or the raw tuple
+    (``rgb`` u8 [H,W,3], ``depth`` [H,W,1], instance ``masks``/``classes``/``scores``), plus
+    ``sensor_pose`` = (dx, dy, do) (peanut_agent.py:70-95).  Returns the number of predictions."""
+    args = state.args
+    state.reset()
+    n_pred = 0
+    for i, fr in enumerate(frames):
+        if "obs" in fr:
+            obs = fr["obs"]
+        else:
+            sem = accumulate_instances(fr["masks"], fr["classes"], fr["scores"], args.num_sem_categories - 1,
+                                       args.sem_pred_prob_thr, args.goal_thr, goal_cat)
+            obs = preprocess_obs(fr["rgb"], fr["depth"], sem, args)
+        infos = {"sensor_pose": fr["sensor_pose"], "goal_cat_id": goal_cat}
+        if i == 0:
+            state.init_with_obs(obs, infos)
+        predicted = state.update_state(obs, infos)
+        n_pred += int(predicted)
+        if on_step is not None:
+            on_step(i, state, predicted)
+    return n_pred
+
+
+def episode_shard(n_episodes: int) -> List[int]:
+    """Episode ids owned by this rank (contiguous ``[start_ep, end_ep)`` like nav/collect.py:50)."""
+    rank, _, world = pdist.env_rank_world()
+    s, e = pdist.shard_range(n_episodes, rank, world)
+    return list(range(s, e))

@@ -1,0 +1,116 @@
+"""Hot-path callers on the device against the golden episode produced
+by the reference's own Agent_State (tests/golden/agent_state_golden.npz, oracle/gen_golden_agent.py)
+and against the NumPy restatement of the observation formatting (oracle/agent_ref.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class FakePredictionGPU:
+    """Device twin of oracle.agent_ref.FakePrediction (same formula on HIP tensors)."""
+
+    def __init__(self, pattern):
+        self.pattern = torch.from_numpy(pattern).cuda()
+
+    def get_prediction_batch(self, maps, apply_sigmoid=True, out=None):
+        sel = maps[:, [0, 1, 4, 5, 6, 7]]
+        return torch.tanh(sel + self.pattern[None]) * 0.5 + 0.5
+
+
+def test_agent_state_episode_matches_reference(golden_dir):
+    from oracle import mapping_scenes
+    from oracle.agent_ref import agent_args, fake_pattern
+    from peanut_amd.agent_state import Agent_State
+    z = np.load(os.path.join(golden_dir, "agent_state_golden.npz"))
+    args = agent_args()
+    st = Agent_State(args, prediction_model=FakePredictionGPU(fake_pattern(size=args.prediction_window)))
+    frames = mapping_scenes.make_sequence(seed=int(z["seed"]), n_frames=int(z["n_frames"]))
+    for f in frames:
+        f["pose"][0] = np.float32(f["pose"][0] * 3.0)
+    goal = int(z["goal_cat"])
+    st.reset()
+    pred_steps, last_pred = [], None
+    for i, fr in enumerate(frames):
+        obs = torch.from_numpy(mapping_scenes.frame_to_obs(fr))[None].cuda()
+        infos = {"sensor_pose": [float(v) for v in fr["pose"]], "goal_cat_id": goal}
+        if i == 0:
+            st.init_with_obs(obs, infos)
+        step_before = st.step
+        predicted = st.update_state(obs, infos)
+        assert st.step == step_before + 1
+        assert list(st.lmb) == list(z["lmb"][i]), f"step {i}: local map boundaries"
+        assert [st.loc_r, st.loc_c] == list(z["loc"][i]), f"step {i}: agent cell"
+        np.testing.assert_allclose(st.local_pose.cpu().numpy(), z["local_pose"][i], rtol=0, atol=2e-5)
+        sums = st.local_map.double().sum((1, 2)).cpu().numpy()
+        np.testing.assert_allclose(sums, z["channel_sums"][i], rtol=1e-6, atol=0.05, err_msg=f"step {i}")
+        if predicted:
+            pred_steps.append(i)
+            tp = st.target_pred.double()
+            k = len(pred_steps) - 1
+            assert abs(float(tp.sum()) - z["pred_sum"][k]) <= 1e-5 * abs(z["pred_sum"][k]) + 0.05
+            assert abs(float((tp * tp).sum()) - z["pred_sq"][k]) <= 1e-5 * abs(z["pred_sq"][k]) + 0.05
+            last_pred = st.target_pred.cpu().numpy()
+    assert pred_steps == list(z["pred_steps"])
+    assert int(z["last_pred_step"]) == pred_steps[-1]
+    assert np.abs(last_pred - z["last_target_pred"]).max() <= 1e-4
+    # full_map has the same write history on both sides (update_full_map at l_step 19, update_prediction's
+    # write-back at every prediction step), so it is compared as is
+    full = st.full_map.cpu().numpy().reshape(-1)
+    ref = np.zeros_like(full)
+    ref[z["full_idx"]] = z["full_val"]
+    assert np.abs(full - ref).max() <= 5e-5
+
+
+def test_preprocess_obs_matches_reference_loop():
+    from types import SimpleNamespace
+    from oracle.agent_ref import preprocess_obs_ref
+    from peanut_amd.agent_helper import preprocess_obs
+    rng = np.random.RandomState(0)
+    H, W, ncat = 480, 640, 10
+    depth = rng.uniform(0.0, 1.1, size=(H, W, 1)).astype(np.float32)
+    depth[rng.uniform(size=(H, W, 1)) < 0.1] = 0.0          # scattered invalid pixels
+    depth[:, 100:140] = 0.0                                  # fully invalid columns (> 90 %)
+    depth[:470, 300:320] = 0.0                               # mostly invalid columns with a few valid rows
+    depth[:, 500:520][depth[:, 500:520] > 0.5] = 0.995       # too-far pixels
+    rgb = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+    sem = (rng.uniform(size=(H, W, ncat)) > 0.9).astype(np.float32)
+    args = SimpleNamespace(env_frame_width=W, frame_width=160, min_depth=0.5, max_depth=5.0)
+    ref = preprocess_obs_ref(rgb.astype(np.float32), depth.copy(), sem, args).astype(np.float32)
+    got = preprocess_obs(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(sem).cuda(), args)
+    assert got.shape == (1, 14, 120, 160)
+    assert np.array_equal(got[0].cpu().numpy(), ref)         # bit-exact (fp32, same operation order)
+
+
+def test_replay_loop_runs_full_pipeline():
+    """collect.py order on synthetic raw frames: seg accumulation -> obs formatting -> projection ->
+    prediction (real HIP PSPNet, seeded weights) every update_goal_freq steps."""
+    from oracle.agent_ref import agent_args
+    from peanut_amd.agent_state import Agent_State
+    from peanut_amd.replay import run_episode
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    args = agent_args(only_explore=0, prediction_window=240, map_size_cm=2400)
+    sd = make_seeded_state_dict(PredCfg(), 0)
+    st = Agent_State(args, state_dict=sd)
+    g = torch.Generator().manual_seed(0)
+    frames = []
+    for i in range(12):
+        depth = torch.full((480, 640, 1), 0.3) + torch.rand((480, 640, 1), generator=g) * 0.01   # ~1.85 m wall
+        masks = torch.zeros((3, 480, 640), dtype=torch.bool)
+        masks[0, 280:400, 100:220] = True     # below the horizon: lands in the agent-height z range
+        masks[1, 150:260, 300:420] = True
+        masks[2, 10:60, 500:600] = True
+        frames.append(dict(rgb=torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).cuda(),
+                           depth=depth.cuda(), masks=masks.cuda(), classes=torch.tensor([1, 4, 7]).cuda(),
+                           scores=torch.tensor([0.99, 0.97, 0.5]).cuda(), sensor_pose=[0.1, 0.0, 0.05 if i % 3 else 0.0]))
+    n_pred = run_episode(st, frames, goal_cat=1)
+    assert n_pred == 2                                        # steps 0 and 9
+    tp = st.target_pred
+    assert tp.shape == (240, 240) and bool(torch.isfinite(tp).all())
+    assert float(tp.max()) <= 1.0 and float(tp.min()) >= 0.0
+    assert float(st.local_map[1].sum()) > 0                   # something was explored
+    assert float(st.local_map[4 + 1].sum()) > 0               # class-1 instance reached the map
+    assert float(st.local_map[4 + 7].sum()) == 0              # score 0.5 < 0.95 was gated out
