@@ -43,7 +43,11 @@ struct ConvArgs {
   int B, H, W;
   int c1, c2;         // c1 + c2 == desc.cin
   int Ho, Wo;
+  float* ws;          // optional scratch for tail split-K partial tiles (see conv_common.h)
+  size_t ws_floats;
 };
+
+constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 partial 128x128 tiles and then some
 
 inline int conv_out_dim(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 

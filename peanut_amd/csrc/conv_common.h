@@ -18,6 +18,9 @@ struct ConvKParams {
   int H, W, c1, c2, Ho, Wo, cout;
   int kw, ntaps, stride, pad, dil, relu;
   int M, nkt, ntiles, HoWo;
+  // tail split-K (see decode_work): the last `n_sp / split_p` tiles are cut into split_p k-ranges each
+  int n_full, n_sp, split_p;
+  float* partial;   // [n_sp][BM*BN] raw accumulator tiles of the split parts
 };
 
 template <int I>
@@ -36,16 +39,130 @@ struct KIter {
 };
 
 
-int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, hipStream_t stream);
+int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, float* ws, size_t ws_floats, hipStream_t stream);
 
-// XCD-aware tile assignment (bijective for any grid size; guide T1): each XCD (private L2) owns a
-// contiguous run of tiles, n-tile fastest.
-__device__ __forceinline__ void xcd_tile(int ntiles, int* mt, int* nt) {
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-  const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  *mt = L / ntiles;
-  *nt = L - *mt * ntiles;
+// Work decomposition of one launch.
+//  * XCD-aware (guide T1): workgroup b runs on XCD b % 8 (observed, used for speed only); every XCD gets
+//    a contiguous run of logical work items so that its private L2 sees neighbouring tiles (n-tile
+//    fastest -> co-resident workgroups share A panels).  Bijective for any grid size.
+//  * Tail split-K: T tiles over S resident workgroup slots take ceil(T/S) "rounds"; when the last round
+//    is mostly empty (e.g. 3600 tiles over 512 slots = 7.03 rounds) the t = T mod S tail tiles are each
+//    cut into split_p k-ranges whose raw accumulators go to `partial` and are summed IN A FIXED ORDER
+//    by conv_splitk_reduce_kernel (deterministic, no atomics).  The split parts are spread evenly over
+//    the XCD runs (they are shorter than full tiles, so lumping them on one XCD would unbalance it).
+struct Work { int mt, nt, kt0, kt1, item; };   // item >= 0: split part -> partial tile #item
+
+__device__ __forceinline__ Work decode_work(const ConvKParams& p) {
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int q = G >> 3, r = G & 7, xcd = bid & 7, local = bid >> 3;
+  const int sq = p.n_sp >> 3, sr = p.n_sp & 7;
+  const int sp_x = sq + (xcd < sr), sp_before = xcd * sq + (xcd < sr ? xcd : sr);
+  const int chunk_before = xcd * q + (xcd < r ? xcd : r);
+  Work w;
+  int tile;
+  if (local < sp_x) {
+    const int s = sp_before + local;
+    const int j = s / p.split_p, part = s - j * p.split_p;
+    tile = p.n_full + j;
+    w.item = s;
+    w.kt0 = (int)((long long)part * p.nkt / p.split_p);
+    w.kt1 = (int)((long long)(part + 1) * p.nkt / p.split_p);
+  } else {
+    tile = (chunk_before - sp_before) + (local - sp_x);
+    w.item = -1;
+    w.kt0 = 0;
+    w.kt1 = p.nkt;
+  }
+  w.mt = tile / p.ntiles;
+  w.nt = tile - w.mt * p.ntiles;
+  return w;
+}
+
+// host side: pick split_p for T tiles over S slots; returns the number of tail tiles (0 = no split)
+inline int plan_tail_split(int T, int S, int nkt, size_t tile_floats, size_t ws_floats, int* split_p) {
+  *split_p = 1;
+  if (S <= 0 || ws_floats == 0) return 0;
+  const int t = T % S;
+  if (t == 0) return 0;
+  double best = 1.0;   // cost of the tail round without splitting, in tile-times
+  int best_p = 1;
+  for (int p = 2; p <= 32 && nkt / p >= 4; ++p) {
+    if ((size_t)t * p * tile_floats > ws_floats) break;
+    const int rounds = (int)(((long long)t * p + S - 1) / S);
+    const double cost = (double)rounds / p * (1.0 + 3.0 * p / nkt);   // ~3 k-tiles of fill/drain per part
+    if (cost < best - 0.02) { best = cost; best_p = p; }
+  }
+  if (best_p == 1) return 0;
+  *split_p = best_p;
+  return t;
+}
+
+// sum the split_p partial tiles of every tail tile in order and apply the fused epilogue
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKParams p) {
+  const int j = blockIdx.x;                    // tail tile
+  const int tile = p.n_full + j;
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  constexpr int NV = BN / 4, ROWS_PER_PASS = 256 / NV;
+  const int tid = threadIdx.x;
+  const int c4 = (tid % NV) * 4, r0 = tid / NV;
+  const int n = n0 + c4;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+  const bool vec_ok = (p.cout & 3) == 0;
+  const float* base = p.partial + (size_t)j * p.split_p * (BM * BN);
+  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(base + row * BN + c4);
+    for (int s = 1; s < p.split_p; ++s) v += *reinterpret_cast<const f32x4*>(base + (size_t)s * (BM * BN) + row * BN + c4);
+    v = v * sc + sh;
+    const size_t o = (size_t)m * p.cout + n;
+    if (vec_ok) {
+      if (n < p.cout) {
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(p.y + o) = v;
+      }
+    } else {
+      for (int e = 0; e < 4; ++e) {
+        if (n + e < p.cout) {
+          float x = v[e];
+          if (p.res) x += p.res[o + e];
+          if (p.relu) x = fmaxf(x, 0.f);
+          p.y[o + e] = x;
+        }
+      }
+    }
+  }
+}
+
+// shared host launcher: occupancy query (once per instantiation), tail-split plan, launch, reduce
+template <typename KernelT, int BM, int BN>
+int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream,
+                           int* cached_slots) {
+  if (*cached_slots == 0) {
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1)
+      *cached_slots = -1;   // unknown -> never split
+    else
+      *cached_slots = cus * occ;
+  }
+  const int mtiles = (p.M + BM - 1) / BM;
+  const int T = mtiles * p.ntiles;
+  int sp = 1;
+  const int t = plan_tail_split(T, *cached_slots, p.nkt, (size_t)BM * BN, ws ? ws_floats : 0, &sp);
+  p.split_p = sp;
+  p.n_sp = t * sp;
+  p.n_full = T - t;
+  p.partial = ws;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(256), 0, stream, p);
+  if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t), dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));
+  return 0;
 }
 
 }  // namespace peanut

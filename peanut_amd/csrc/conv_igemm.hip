@@ -26,6 +26,8 @@
 //   segments), row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel.
 //   Workgroup -> tile map is XCD-aware: each XCD (private 4 MiB L2) owns a contiguous run of
 //   tiles, n-tile fastest, so the co-resident workgroups of an XCD share A panels.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace peanut {
@@ -97,12 +99,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is a multiple of the 32x32 MFMA");
 
   constexpr int CS = BN + 4;             // epilogue staging row stride (floats)
-  constexpr int SMEM_FLOATS = (2 * STAGE > BM * CS) ? 2 * STAGE : BM * CS;
+  // epilogue passes: when the pipeline buffers are smaller than a whole staged tile (BK = 16), the tile is
+  // staged in WM row-slabs (one per wave row) so that LDS -- hence workgroups per CU -- is set by the pipeline
+  constexpr int EP = (BM * CS > 2 * STAGE) ? WM : 1;
+  constexpr int ER = BM / EP;
+  constexpr int SMEM_FLOATS = (2 * STAGE > ER * CS) ? 2 * STAGE : ER * CS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
-  int mt, nt;
-  xcd_tile(p.ntiles, &mt, &nt);
+  const Work wk = decode_work(p);
+  const int mt = wk.mt, nt = wk.nt, nk = wk.kt1 - wk.kt0;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread staging coordinates ----
@@ -129,8 +135,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 
   f32x4 ra[A_PER], rb[B_PER];
   KIter it;
-  it.tap = 0; it.ky = 0; it.kx = 0; it.cbase = 0;  // channel chunk outer, filter tap inner
-  it.wtile = p.w + (size_t)nt * p.nkt * (BN * BK);
+  it.tap = wk.kt0 % p.ntaps;                       // channel chunk outer, filter tap inner
+  it.cbase = (wk.kt0 / p.ntaps) * BK;
+  it.ky = it.tap / p.kw;
+  it.kx = it.tap - it.ky * p.kw;
+  it.wtile = p.w + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
 
 #define PEANUT_LOAD_TILES() load_tiles<BN, BK, A_PER, B_PER>(p, it, a_iy0, a_ix0, a_pix, a_c4, tid, ra, rb)
 #define PEANUT_STORE_TILES(stage) store_tiles<BM, BN, BK, A_PER, B_PER>(stage, tid, ra, rb)
@@ -153,14 +162,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   // ---- pipeline prologue ----
   PEANUT_LOAD_TILES();
   PEANUT_STORE_TILES(smem);
-  if (p.nkt > 1) PEANUT_LOAD_TILES();
+  if (nk > 1) PEANUT_LOAD_TILES();
   __syncthreads();
 
-  for (int kt = 0; kt < p.nkt; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     const float* cur = smem + (kt & 1) * STAGE;
-    if (kt + 1 < p.nkt) {
+    if (kt + 1 < nk) {
       PEANUT_STORE_TILES(smem + ((kt + 1) & 1) * STAGE);   // k-tile kt+1 (loaded one iteration ago)
-      if (kt + 2 < p.nkt) PEANUT_LOAD_TILES();             // k-tile kt+2 flies during the MFMAs below
+      if (kt + 2 < nk) PEANUT_LOAD_TILES();             // k-tile kt+2 flies during the MFMAs below
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 8; ++ks) {
@@ -189,16 +198,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   // handles 16-byte pieces (4 consecutive channels) -- a wave reads the residual and writes the
   // output as 512-byte (BN=128) contiguous row segments instead of 64 scalar accesses per lane.
   // (The k-loop's last barrier has retired every LDS read, so the pipeline buffers are free.)
-#pragma unroll
-  for (int t = 0; t < MI; ++t)
-#pragma unroll
-    for (int u = 0; u < NI; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        smem[row * CS + wn * TN + u * 32 + li] = acc[t][u][r];
-      }
-  __syncthreads();
   constexpr int NV = BN / 4;               // float4 per output row of the tile
   constexpr int ROWS_PER_PASS = 256 / NV;  // rows covered by the 256 threads per pass
   const int c4 = (tid % NV) * 4, r0 = tid / NV;
@@ -206,36 +205,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);   // scale/shift are padded to cout_pad
   const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
   const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
-#pragma unroll 4
-  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
-    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
-    v = v * sc + sh;
-    const size_t o = (size_t)m * p.cout + n;
-    if (vec_ok) {
-      if (n < p.cout) {
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(p.y + o) = v;
-      }
-    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e < p.cout) {
-          float x = v[e];
-          if (p.res) x += p.res[o + e];
-          if (p.relu) x = fmaxf(x, 0.f);
-          p.y[o + e] = x;
+  for (int ep = 0; ep < EP; ++ep) {
+    if (EP == 1 || wm == ep) {
+#pragma unroll
+      for (int t = 0; t < MI; ++t)
+#pragma unroll
+        for (int u = 0; u < NI; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi - ep * ER;
+            smem[row * CS + wn * TN + u * 32 + li] = acc[t][u][r];
+          }
+    }
+    __syncthreads();
+    if (wk.item >= 0) {   // split-K part: raw accumulators, summed + finished by conv_splitk_reduce_kernel
+      float* dst = p.partial + (size_t)wk.item * (BM * BN) + (size_t)ep * ER * BN;
+      for (int row = r0; row < ER; row += ROWS_PER_PASS)
+        *reinterpret_cast<f32x4*>(dst + row * BN + c4) = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+    } else {
+#pragma unroll 4
+      for (int row = r0; row < ER; row += ROWS_PER_PASS) {
+        const int m = m0 + ep * ER + row;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+        v = v * sc + sh;
+        const size_t o = (size_t)m * p.cout + n;
+        if (vec_ok) {
+          if (n < p.cout) {
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(p.y + o) = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < p.cout) {
+              float x = v[e];
+              if (p.res) x += p.res[o + e];
+              if (p.relu) x = fmaxf(x, 0.f);
+              p.y[o + e] = x;
+            }
+          }
         }
       }
     }
+    if (ep + 1 < EP) __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk) {
+  static const int forced_bk = [] { const char* e = getenv("PEANUT_FP32_BK"); return e ? atoi(e) : 0; }();
   *bk = (cin_pad % 32 == 0) ? 32 : 16;
+  if (forced_bk == 16) *bk = 16;   // experiment knob: 3 workgroups/CU instead of 2 in the fp32 kernel
   *bn_tile = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
 }
 
@@ -265,13 +288,10 @@ void pack_conv_weights(const float* w, int cout, int cin_real, int cin_pad, int 
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-static int launch_t(const ConvKParams& p, hipStream_t stream) {
-  const int mtiles = (p.M + BM - 1) / BM;
-  const dim3 grid((unsigned)(mtiles * p.ntiles));
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));
-  return 0;
+static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
+  static int slots = 0;
+  return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN>), BM, BN>(
+      &conv_igemm_kernel<BM, BN, BK, WM, WN>, p, ws, ws_floats, stream, &slots);
 }
 
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
@@ -289,18 +309,19 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.M = (int)M;
   p.nkt = (d.cin / d.bk) * p.ntaps;
   p.ntiles = d.cout_pad / d.bn_tile;
+  p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
   if (d.mode != 0) {
     if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
-    return launch_conv_split(p, d.bn_tile, d.mode == 2, stream);
+    return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);
   }
   if (d.bk == 32) {
-    if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, stream);
-    if (d.bn_tile == 64) return launch_t<128, 64, 32, 2, 2>(p, stream);
-    if (d.bn_tile == 32) return launch_t<128, 32, 32, 4, 1>(p, stream);
+    if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, a.ws, a.ws_floats, stream);
+    if (d.bn_tile == 64) return launch_t<128, 64, 32, 2, 2>(p, a.ws, a.ws_floats, stream);
+    if (d.bn_tile == 32) return launch_t<128, 32, 32, 4, 1>(p, a.ws, a.ws_floats, stream);
   } else if (d.bk == 16) {
-    if (d.bn_tile == 128) return launch_t<128, 128, 16, 2, 2>(p, stream);
-    if (d.bn_tile == 64) return launch_t<128, 64, 16, 2, 2>(p, stream);
-    if (d.bn_tile == 32) return launch_t<128, 32, 16, 4, 1>(p, stream);
+    if (d.bn_tile == 128) return launch_t<128, 128, 16, 2, 2>(p, a.ws, a.ws_floats, stream);
+    if (d.bn_tile == 64) return launch_t<128, 64, 16, 2, 2>(p, a.ws, a.ws_floats, stream);
+    if (d.bn_tile == 32) return launch_t<128, 32, 16, 4, 1>(p, a.ws, a.ws_floats, stream);
   }
   return fail(-2, "launch_conv: unsupported tile configuration");
 }

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
 
   const int tid = threadIdx.x;
-  int mt, nt;
-  xcd_tile(p.ntiles, &mt, &nt);
+  const Work wk = decode_work(p);
+  const int mt = wk.mt, nt = wk.nt, nk = wk.kt1 - wk.kt0;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread staging coordinates (A) ----
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
 
   f32x4 ra[A_PER];
   u32x4 rb[B_PER];
-  int tap = 0, ky = 0, kx = 0, cbase = 0;
-  const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) + (size_t)nt * p.nkt * (BN * BK * 4);
+  int tap = wk.kt0 % p.ntaps, cbase = (wk.kt0 / p.ntaps) * BK;
+  int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK * 4);
 
 #define SPLIT_LOAD_TILES()                                                                              \
   {                                                                                                     \
@@ -188,14 +189,14 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
 
   SPLIT_LOAD_TILES();
   SPLIT_STORE_TILES(smem_raw);
-  if (p.nkt > 1) SPLIT_LOAD_TILES();
+  if (nk > 1) SPLIT_LOAD_TILES();
   __syncthreads();
 
-  for (int kt = 0; kt < p.nkt; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* cur = smem_raw + (kt & 1) * STAGE;
-    if (kt + 1 < p.nkt) {
+    if (kt + 1 < nk) {
       SPLIT_STORE_TILES(smem_raw + ((kt + 1) & 1) * STAGE);
-      if (kt + 2 < p.nkt) SPLIT_LOAD_TILES();
+      if (kt + 2 < nk) SPLIT_LOAD_TILES();
     }
 #pragma unroll
     for (int step = 0; step < BK / 16; ++step) {
@@ -245,6 +246,12 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
   const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
   const bool vec_ok = (p.cout & 3) == 0;
+  if (wk.item >= 0) {   // split-K part: raw accumulators (conv_splitk_reduce_kernel finishes the tile)
+    float* dst = p.partial + (size_t)wk.item * (BM * BN);
+    for (int row = r0; row < BM; row += ROWS_PER_PASS)
+      *reinterpret_cast<f32x4*>(dst + row * BN + c4) = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+    return;
+  }
 #pragma unroll 4
   for (int row = r0; row < BM; row += ROWS_PER_PASS) {
     const int m = m0 + row;
@@ -330,24 +337,21 @@ void pack_conv_weights_split(const float* w, int cout, int cin_real, int cin_pad
 }
 
 template <int BM, int BN, int WM, int WN, bool FP16>
-static int launch_split_t(const ConvKParams& p, hipStream_t stream) {
-  const int mtiles = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, FP16>), dim3((unsigned)(mtiles * p.ntiles)), dim3(256), 0,
-                     stream, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(-3, std::string("split conv launch: ") + hipGetErrorString(e));
-  return 0;
+static int launch_split_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
+  static int slots = 0;
+  return launch_with_tail_split<decltype(&conv_igemm_split_kernel<BM, BN, WM, WN, FP16>), BM, BN>(
+      &conv_igemm_split_kernel<BM, BN, WM, WN, FP16>, p, ws, ws_floats, stream, &slots);
 }
 
-int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, hipStream_t stream) {
+int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, float* ws, size_t ws_floats, hipStream_t stream) {
   if (fp16) {
-    if (bn_tile == 128) return launch_split_t<128, 128, 2, 2, true>(p, stream);
-    if (bn_tile == 64) return launch_split_t<128, 64, 2, 2, true>(p, stream);
-    if (bn_tile == 32) return launch_split_t<128, 32, 4, 1, true>(p, stream);
+    if (bn_tile == 128) return launch_split_t<128, 128, 2, 2, true>(p, ws, ws_floats, stream);
+    if (bn_tile == 64) return launch_split_t<128, 64, 2, 2, true>(p, ws, ws_floats, stream);
+    if (bn_tile == 32) return launch_split_t<128, 32, 4, 1, true>(p, ws, ws_floats, stream);
   } else {
-    if (bn_tile == 128) return launch_split_t<128, 128, 2, 2, false>(p, stream);
-    if (bn_tile == 64) return launch_split_t<128, 64, 2, 2, false>(p, stream);
-    if (bn_tile == 32) return launch_split_t<128, 32, 4, 1, false>(p, stream);
+    if (bn_tile == 128) return launch_split_t<128, 128, 2, 2, false>(p, ws, ws_floats, stream);
+    if (bn_tile == 64) return launch_split_t<128, 64, 2, 2, false>(p, ws, ws_floats, stream);
+    if (bn_tile == 32) return launch_split_t<128, 32, 4, 1, false>(p, ws, ws_floats, stream);
   }
   return fail(-2, "launch_conv_split: unsupported tile configuration");
 }

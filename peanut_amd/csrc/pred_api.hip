@@ -58,6 +58,7 @@ int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const flo
   d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
   conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
+  if (precision != 0 && cin_pad % 32 == 0) d.bk = 32;        // split kernels are BK = 32 only
   d.mode = (precision != 0 && d.bk == 32) ? precision : 0;   // 16-channel (stem.0) layers stay fp32
   L.cin_real = cin;
   const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);   // same byte count in every mode
@@ -142,6 +143,7 @@ struct Op {
 
 struct Plan {
   int B = 0, H = 0, W = 0;
+  Act splitk;   // scratch for tail split-K partial tiles, alive for the whole forward
   bool keep_all = false;
   size_t bytes = 0;
   std::vector<Op> ops;
@@ -155,6 +157,7 @@ using namespace peanut;
 
 struct peanut_conv {
   ConvLayer L;
+  DevBuf ws;   // tail split-K scratch, allocated on first forward
 };
 
 struct peanut_pred {
@@ -277,6 +280,9 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   ar.keep_all = h->keep_all;
   auto rel = [&](const Act& t) { ar.release(t.off, t.bytes); };
 
+  pl->splitk.bytes = kSplitKScratchFloats * sizeof(float);
+  pl->splitk.off = ar.alloc(pl->splitk.bytes);
+  pl->splitk.B = pl->splitk.H = pl->splitk.W = 1; pl->splitk.C = 0;
   // input layout change: NCHW -> NHWC, channels zero-padded to a multiple of 16
   Act x = make_act(ar, B, H, W, h->cin_pad);
   { Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.kernel = "nchw_to_nhwc"; op.out = x; pl->ops.push_back(op); }
@@ -410,6 +416,7 @@ static size_t plan_high_water(const Plan& pl) {
   auto upd = [&](const Act& a) { if (a.bytes && a.off + Arena::round_up(a.bytes) > hw) hw = a.off + Arena::round_up(a.bytes); };
   for (const auto& op : pl.ops) { upd(op.in); upd(op.in2); upd(op.res); upd(op.out); }
   for (const auto& kv : pl.named) upd(kv.second);
+  upd(pl.splitk);
   return hw;
 }
 
@@ -441,6 +448,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       a.B = op.in.B; a.H = op.in.H; a.W = op.in.W;
       a.c1 = op.in.C; a.c2 = op.has_in2 ? op.in2.C : 0;
       a.Ho = op.out.H; a.Wo = op.out.W;
+      a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
       return launch_conv(op.conv->d, a, s);
     }
     case OP_MAXPOOL:
@@ -698,6 +706,8 @@ int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c
   a.Ho = conv_out_dim(H, d.kh, d.stride, d.pad, d.dil);
   a.Wo = conv_out_dim(W, d.kw, d.stride, d.pad, d.dil);
   if (a.Ho < 1 || a.Wo < 1) return fail(PEANUT_EINVAL, "peanut_conv_forward: empty output");
+  if (int rc = c->ws.ensure(kSplitKScratchFloats * sizeof(float))) return rc;
+  a.ws = (float*)c->ws.p; a.ws_floats = kSplitKScratchFloats;
   return launch_conv(d, a, (hipStream_t)stream);
 }
 

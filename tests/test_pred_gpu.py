@@ -103,15 +103,22 @@ def test_get_prediction_signature(model_and_sd):
 
 
 def test_batch_independence_and_determinism(model_and_sd):
-    """A map's prediction does not depend on its batch neighbours, and repeated calls are
-    bit-identical (fixed tile->k order, no atomics)."""
+    """Repeated calls are bit-identical (fixed tile -> k order, split-K partials summed in a fixed order,
+    no atomics).  A map's prediction does not depend on its batch neighbours; it may differ from the
+    batch-1 result in the last fp32 bits only, because the tail split-K plan (how the K range of the last
+    few tiles is cut) depends on the tile count."""
     m, sd, cfg = model_and_sd
     x = _inputs(4, cfg.in_channels, 96, 96, seed=3).cuda()
     full = m.get_prediction_batch(x, apply_sigmoid=False)
     again = m.get_prediction_batch(x, apply_sigmoid=False)
     assert torch.equal(full, again)
     single = m.get_prediction_batch(x[2:3].contiguous(), apply_sigmoid=False)
-    assert torch.equal(single[0], full[2])
+    assert (single[0] - full[2]).abs().max().item() <= 2e-5
+    y = x.clone()
+    y[0] = 0.0
+    y[3] = 1.0
+    other = m.get_prediction_batch(y, apply_sigmoid=False)
+    assert torch.equal(other[2], full[2])          # same batch shape -> same plan -> bit-identical
 
 
 def test_golden_vectors(model_and_sd, golden_dir):
