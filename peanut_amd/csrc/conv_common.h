@@ -97,26 +97,26 @@ inline int plan_tail_split(int T, int S, int nkt, size_t tile_floats, size_t ws_
   return t;
 }
 
-// sum the split_p partial tiles of every tail tile in order and apply the fused epilogue
+// sum the split_p partial tiles of every tail tile in order and apply the fused epilogue.
+// grid = (tail tiles, BM / 16): each workgroup finishes a 16-row slab, so even a 16-tile tail spreads
+// over 128 workgroups and the p partial reads of a slab are issued back to back.
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKParams p) {
   const int j = blockIdx.x;                    // tail tile
   const int tile = p.n_full + j;
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
-  constexpr int NV = BN / 4, ROWS_PER_PASS = 256 / NV;
-  const int tid = threadIdx.x;
-  const int c4 = (tid % NV) * 4, r0 = tid / NV;
-  const int n = n0 + c4;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-  const bool vec_ok = (p.cout & 3) == 0;
+  constexpr int NV = BN / 4, SLAB = 16;
   const float* base = p.partial + (size_t)j * p.split_p * (BM * BN);
-  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
+  const bool vec_ok = (p.cout & 3) == 0;
+  for (int i = threadIdx.x; i < SLAB * NV; i += 256) {
+    const int row = blockIdx.y * SLAB + i / NV, c4 = (i % NV) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= p.M) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(base + row * BN + c4);
     for (int s = 1; s < p.split_p; ++s) v += *reinterpret_cast<const f32x4*>(base + (size_t)s * (BM * BN) + row * BN + c4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
     v = v * sc + sh;
     const size_t o = (size_t)m * p.cout + n;
     if (vec_ok) {
@@ -159,7 +159,7 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   p.n_full = T - t;
   p.partial = ws;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(256), 0, stream, p);
-  if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t), dim3(256), 0, stream, p);
+  if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));
   return 0;

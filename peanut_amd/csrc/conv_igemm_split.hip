@@ -213,14 +213,20 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
         bh[u] = *reinterpret_cast<const V8*>(cur + off);
         bl[u] = *reinterpret_cast<const V8*>(cur + PLANE_B + off);
       }
+      // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent MFMA on the same
+      // accumulator would wait out the previous one's full latency)
 #pragma unroll
       for (int t = 0; t < MI; ++t)
 #pragma unroll
-        for (int u = 0; u < NI; ++u) {
-          acc[t][u] = Half<FP16>::mfma(al[t], bh[u], acc[t][u]);
-          acc[t][u] = Half<FP16>::mfma(ah[t], bl[u], acc[t][u]);
-          acc[t][u] = Half<FP16>::mfma(ah[t], bh[u], acc[t][u]);
-        }
+        for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(al[t], bh[u], acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MI; ++t)
+#pragma unroll
+        for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(ah[t], bl[u], acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MI; ++t)
+#pragma unroll
+        for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(ah[t], bh[u], acc[t][u]);
     }
     __syncthreads();
   }

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Config 4 of BASELINE.json on synthetic frames: the full per-step perception loop of the agent
+(instance-mask accumulation -> observation formatting -> map projection -> every update_goal_freq steps
+the 720x720 map-prediction forward), one episode per rank, episodes sharded over the GPUs of the node
+like the reference's --start_ep/--end_ep.  The Mask R-CNN network itself (detectron2) is not part of
+this build: frames carry synthetic instance masks/classes/scores in its output format.
+
+    python tools/bench_pipeline.py [--episodes 8] [--frames 100]
+    python -m torch.distributed.run --nproc-per-node N tools/bench_pipeline.py ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from peanut_amd import dist as pdist  # noqa: E402
+from peanut_amd.agent_state import Agent_State  # noqa: E402
+from peanut_amd.replay import episode_shard, run_episode  # noqa: E402
+from peanut_amd.weights import PredCfg, make_seeded_state_dict  # noqa: E402
+
+
+def synth_episode(seed, n_frames, dev):
+    g = torch.Generator().manual_seed(seed)
+    frames = []
+    for i in range(n_frames):
+        depth = torch.full((480, 640, 1), 0.35) + torch.rand((480, 640, 1), generator=g) * 0.02
+        depth[200:330, 150:330] = 0.15 + 0.01 * torch.rand((130, 180, 1), generator=g)       # a closer box
+        masks = torch.zeros((4, 480, 640), dtype=torch.bool)
+        masks[0, 260:420, 80:260] = True
+        masks[1, 200:330, 150:330] = True
+        masks[2, 300:460, 400:560] = True
+        masks[3, 20:90, 500:620] = True
+        frames.append(dict(rgb=torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).to(dev),
+                           depth=depth.to(dev), masks=masks.to(dev), classes=torch.tensor([0, 3, 5, 8]).to(dev),
+                           scores=torch.tensor([0.99, 0.97, 0.96, 0.4]).to(dev),
+                           sensor_pose=[0.25 if i % 4 else 0.0, 0.0, 0.0 if i % 4 else 0.5236]))
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--episodes", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--precision", default="fp32")
+    a = ap.parse_args()
+    rank, local_rank, world = pdist.init_process_group()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from oracle.agent_ref import agent_args   # argument defaults only (nav/arguments.py values)
+    args = agent_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=a.precision)
+    st = Agent_State(args, state_dict=make_seeded_state_dict(PredCfg(), 0))
+    mine = episode_shard(a.episodes)
+    eps = {e: synth_episode(1000 + e, a.frames, dev) for e in mine}
+    if mine:
+        run_episode(st, eps[mine[0]][:12], goal_cat=3)     # warm-up (plans, workspaces)
+    torch.cuda.synchronize()
+    pdist.barrier()
+    t0 = time.perf_counter()
+    n_pred = 0
+    for e in mine:
+        n_pred += run_episode(st, eps[e], goal_cat=3)
+    torch.cuda.synchronize()
+    pdist.barrier()
+    dt = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if rank == 0:
+        steps = a.episodes * a.frames
+        print(json.dumps({"workload": f"config 4: {a.episodes} synthetic episodes x {a.frames} frames, seg-accumulate + "
+                                      "obs formatting + map projection per step, 720x720 map prediction every 10 steps",
+                          "n_gpus": world, "steps_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                          "predictions_rank0": n_pred, "precision": a.precision}))
+
+
+if __name__ == "__main__":
+    main()
