@@ -14,6 +14,7 @@ struct ConvKParams {
   const float* scale;
   const float* shift;
   const float* res;
+  const float* zeros;   // >= 16 bytes of zeros on the device (target of out-of-range loads)
   float* y;
   int H, W, c1, c2, Ho, Wo, cout;
   int kw, ntaps, stride, pad, dil, relu;
@@ -39,6 +40,7 @@ struct KIter {
 };
 
 
+const float* zero_page();   // per-device 4 KiB of zeros (allocated on first use)
 int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, float* ws, size_t ws_floats, hipStream_t stream);
 
 // Work decomposition of one launch.

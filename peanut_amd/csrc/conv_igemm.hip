@@ -32,40 +32,58 @@
 
 namespace peanut {
 
-// Issue the global loads of one k-tile (A gathered from the shifted input pixels, W linear) into
-// registers and advance the k-tile iterator.
-template <int BN, int BK, int A_PER, int B_PER>
-__device__ __forceinline__ void load_tiles(const ConvKParams& p, KIter& it, const int (&a_iy0)[A_PER],
-                                           const int (&a_ix0)[A_PER], const int (&a_pix)[A_PER], int a_c4,
-                                           int tid, f32x4 (&ra)[A_PER], f32x4 (&rb)[B_PER]) {
-  constexpr int B_F4 = BN * (BK / 4);
-  const float* src = p.x;
-  int C = p.c1, cb = it.cbase;
-  if (cb >= p.c1) { src = p.x2; cb -= p.c1; C = p.c2; }
+// Software-pipelined staging, split in two so that address arithmetic never sits between a load and its
+// issue slot:
+//   prep_addr   -- addresses of the NEXT k-tile to be loaded (A gathered from the shifted input pixels, W
+//                  linear) + iterator advance.  Pure ALU, scheduled anywhere in the MFMA shadow.
+//   issue_loads -- the global loads themselves, from addresses computed one iteration earlier, so they go
+//                  out at the top of the iteration and have a whole MFMA phase to land.
+// Branch-free on purpose: out-of-image taps / rows read a 16-byte zero page instead of being predicated
+// (arithmetic select of the address -- a ?: on pointers is lowered to exec-masked code) and the iterator
+// advances with selects, so the steady-state k-loop body is ONE basic block.
+template <int BN, int BK, int A_PER>
+__device__ __forceinline__ void prep_addr(const ConvKParams& p, KIter& it, const int (&a_iy0)[A_PER],
+                                          const int (&a_ix0)[A_PER], const int (&a_pix)[A_PER], int a_c4,
+                                          unsigned long long (&a_addr)[A_PER], const float*& b_tile) {
+  const bool second = it.cbase >= p.c1;
+  const float* src = second ? p.x2 : p.x;
+  const int C = second ? p.c2 : p.c1, cb = second ? it.cbase - p.c1 : it.cbase;
   const int dy = it.ky * p.dil, dx = it.kx * p.dil;
   static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
     constexpr int j = decltype(J)::value;
     const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
     const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     const float* ptr = src + (size_t)(a_pix[j] + iy * p.W + ix) * C + cb + a_c4;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ok) v = *reinterpret_cast<const f32x4*>(ptr);
-    ra[j] = v;
+    const unsigned long long m = ok ? ~0ull : 0ull;
+    a_addr[j] = ((unsigned long long)ptr & m) | ((unsigned long long)p.zeros & ~m);
+  });
+  b_tile = it.wtile;
+  it.wtile += BN * BK;
+  const int tap1 = it.tap + 1, kx1 = it.kx + 1;
+  const bool wrap = tap1 == p.ntaps, kxw = kx1 == p.kw;
+  it.tap = wrap ? 0 : tap1;
+  it.ky = wrap ? 0 : (kxw ? it.ky + 1 : it.ky);
+  it.kx = (wrap || kxw) ? 0 : kx1;
+  it.cbase += wrap ? BK : 0;
+}
+
+template <int BN, int BK, int A_PER, int B_PER>
+__device__ __forceinline__ void issue_loads(const ConvKParams& p, const unsigned long long (&a_addr)[A_PER],
+                                            const float* b_tile, int tid, f32x4 (&ra)[A_PER], f32x4 (&rb)[B_PER]) {
+  constexpr int B_F4 = BN * (BK / 4);
+  static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
+    ra[j] = *reinterpret_cast<const f32x4*>(a_addr[j]);
   });
   static_for<B_PER>([&](auto J) __attribute__((always_inline)) {
     constexpr int j = decltype(J)::value;
     const int idx = tid + 256 * j;
     if constexpr (B_F4 % 256 == 0) {
-      rb[j] = *reinterpret_cast<const f32x4*>(it.wtile + idx * 4);
+      rb[j] = *reinterpret_cast<const f32x4*>(b_tile + idx * 4);
     } else {
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < B_F4) v = *reinterpret_cast<const f32x4*>(it.wtile + idx * 4);
-      rb[j] = v;
+      rb[j] = *reinterpret_cast<const f32x4*>(idx < B_F4 ? b_tile + idx * 4 : p.zeros);
     }
   });
-  it.wtile += BN * BK;
-  if (++it.tap == p.ntaps) { it.tap = 0; it.ky = 0; it.kx = 0; it.cbase += BK; }
-  else if (++it.kx == p.kw) { it.kx = 0; ++it.ky; }
 }
 
 template <int BM, int BN, int BK, int A_PER, int B_PER>
@@ -141,7 +159,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   it.kx = it.tap - it.ky * p.kw;
   it.wtile = p.w + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
 
-#define PEANUT_LOAD_TILES() load_tiles<BN, BK, A_PER, B_PER>(p, it, a_iy0, a_ix0, a_pix, a_c4, tid, ra, rb)
+  unsigned long long a_addr[A_PER];
+  const float* b_tile;
+#define PEANUT_PREP_ADDR() prep_addr<BN, BK, A_PER>(p, it, a_iy0, a_ix0, a_pix, a_c4, a_addr, b_tile)
+#define PEANUT_ISSUE_LOADS() issue_loads<BN, BK, A_PER, B_PER>(p, a_addr, b_tile, tid, ra, rb)
 #define PEANUT_STORE_TILES(stage) store_tiles<BM, BN, BK, A_PER, B_PER>(stage, tid, ra, rb)
 
   // ---- MFMA fragment coordinates ----
@@ -160,38 +181,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
   // ---- pipeline prologue ----
-  PEANUT_LOAD_TILES();
+  PEANUT_PREP_ADDR();
+  PEANUT_ISSUE_LOADS();              // k-tile 0
   PEANUT_STORE_TILES(smem);
-  if (nk > 1) PEANUT_LOAD_TILES();
+  PEANUT_PREP_ADDR();
+  if (nk > 1) PEANUT_ISSUE_LOADS();  // k-tile 1
+  PEANUT_PREP_ADDR();                // addresses of k-tile 2
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const float* cur = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk) {
-      PEANUT_STORE_TILES(smem + ((kt + 1) & 1) * STAGE);   // k-tile kt+1 (loaded one iteration ago)
-      if (kt + 2 < nk) PEANUT_LOAD_TILES();             // k-tile kt+2 flies during the MFMAs below
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 8; ++ks) {
-      f32x4 af[MI], bf[NI];
-#pragma unroll
-      for (int t = 0; t < MI; ++t) af[t] = *reinterpret_cast<const f32x4*>(cur + a_off + t * 32 * LS + ks * 8);
-#pragma unroll
-      for (int u = 0; u < NI; ++u) bf[u] = *reinterpret_cast<const f32x4*>(cur + b_off + u * 32 * LS + ks * 8);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-        for (int t = 0; t < MI; ++t)
-#pragma unroll
-          for (int u = 0; u < NI; ++u) {
-            const float av = kk == 0 ? af[t].x : kk == 1 ? af[t].y : kk == 2 ? af[t].z : af[t].w;
-            const float bv = kk == 0 ? bf[u].x : kk == 1 ? bf[u].y : kk == 2 ? bf[u].z : bf[u].w;
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][u], 0, 0, 0);
-          }
-      }
-    }
+#define PEANUT_COMPUTE(cur)                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < BK / 8; ++ks) {                                                \
+    f32x4 af[MI], bf[NI];                                                                                \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                       \
+      af[t] = *reinterpret_cast<const f32x4*>((cur) + a_off + t * 32 * LS + ks * 8);                     \
+    _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                       \
+      bf[u] = *reinterpret_cast<const f32x4*>((cur) + b_off + u * 32 * LS + ks * 8);                     \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
+      _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                     \
+        _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                   \
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][kk], bf[u][kk], acc[t][u], 0, 0, 0);    \
+  }
+
+  // steady state (no conditionals inside): stage k-tile kt+1 from registers to the other LDS buffer, issue
+  // the loads of k-tile kt+2 (addresses ready since the previous iteration), then -- fenced below them --
+  // the 64 MFMAs of k-tile kt with the address arithmetic of k-tile kt+3 in their shadow
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) {
+    float* const nxt = smem + ((kt + 1) & 1) * STAGE;
+    const float* const cur = smem + (kt & 1) * STAGE;
+    PEANUT_STORE_TILES(nxt);
+    PEANUT_ISSUE_LOADS();
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_PREP_ADDR();
+    PEANUT_COMPUTE(cur);
     __syncthreads();
   }
+  if (kt + 1 < nk) {   // second-to-last k-tile: nothing left to load
+    PEANUT_STORE_TILES(smem + ((kt + 1) & 1) * STAGE);
+    PEANUT_COMPUTE(smem + (kt & 1) * STAGE);
+    __syncthreads();
+    ++kt;
+  }
+  PEANUT_COMPUTE(smem + (kt & 1) * STAGE);   // last k-tile
+  __syncthreads();
+#undef PEANUT_COMPUTE
 
   // ---- epilogue: y = relu(acc * scale[n] + shift[n] + res) ----
   // The accumulators go through LDS once so that global traffic is whole rows: each thread then
@@ -255,6 +288,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+const float* zero_page() {
+  static float* pages[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!pages[dev]) {
+    float* ptr = nullptr;
+    if (hipMalloc(&ptr, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(ptr, 0, 4096) != hipSuccess) return nullptr;
+    pages[dev] = ptr;
+  }
+  return pages[dev];
+}
+
 void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk) {
   static const int forced_bk = [] { const char* e = getenv("PEANUT_FP32_BK"); return e ? atoi(e) : 0; }();
   *bk = (cin_pad % 32 == 0) ? 32 : 16;
@@ -300,6 +346,8 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   ConvKParams p;
   p.x = a.x; p.x2 = a.x2 ? a.x2 : a.x; p.w = d.w_packed; p.scale = d.scale; p.shift = d.shift;
   p.res = a.res; p.y = a.y;
+  p.zeros = zero_page();
+  if (!p.zeros) return fail(-3, "launch_conv: zero page allocation failed");
   p.H = a.H; p.W = a.W; p.c1 = a.c1; p.c2 = a.c2; p.Ho = a.Ho; p.Wo = a.Wo; p.cout = d.cout;
   p.kw = d.kw; p.ntaps = d.kh * d.kw; p.stride = d.stride; p.pad = d.pad; p.dil = d.dil; p.relu = d.relu;
   p.HoWo = a.Ho * a.Wo;
