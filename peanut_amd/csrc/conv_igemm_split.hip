@@ -120,28 +120,45 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
   int ky = tap / p.kw, kx = tap - ky * p.kw;
   const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK * 4);
 
-#define SPLIT_LOAD_TILES()                                                                              \
+  // Staging is software-pipelined and branch-free exactly like conv_igemm.hip: addresses of the next
+  // k-tile are prepared one iteration ahead (pure ALU in the MFMA shadow), out-of-range taps read the zero
+  // page through an arithmetic address select, the iterator advances with selects.
+  unsigned long long a_addr[A_PER];
+  const unsigned char* b_tile;
+#define SPLIT_PREP_ADDR()                                                                               \
   {                                                                                                     \
-    const float* src = p.x;                                                                             \
-    int C = p.c1, cb = cbase;                                                                           \
-    if (cb >= p.c1) { src = p.x2; cb -= p.c1; C = p.c2; }                                               \
+    const bool second_ = cbase >= p.c1;                                                                 \
+    const float* src = second_ ? p.x2 : p.x;                                                            \
+    const int C = second_ ? p.c2 : p.c1, cb = second_ ? cbase - p.c1 : cbase;                           \
     const int dy = ky * p.dil, dx = kx * p.dil;                                                         \
     static_for<A_PER>([&](auto J) __attribute__((always_inline)) {                                      \
       constexpr int j = decltype(J)::value;                                                             \
       const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;                                                 \
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                     \
       const float* ptr = src + (size_t)(a_pix[j] + iy * p.W + ix) * C + cb + a_c4;                      \
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                              \
-      if (ok) v = *reinterpret_cast<const f32x4*>(ptr);                                                 \
-      ra[j] = v;                                                                                        \
+      const unsigned long long m_ = ok ? ~0ull : 0ull;                                                  \
+      a_addr[j] = ((unsigned long long)ptr & m_) | ((unsigned long long)p.zeros & ~m_);                 \
+    });                                                                                                 \
+    b_tile = wtile;                                                                                     \
+    wtile += BN * BK * 4;                                                                               \
+    const int tap1_ = tap + 1, kx1_ = kx + 1;                                                           \
+    const bool wrap_ = tap1_ == p.ntaps, kxw_ = kx1_ == p.kw;                                           \
+    tap = wrap_ ? 0 : tap1_;                                                                            \
+    ky = wrap_ ? 0 : (kxw_ ? ky + 1 : ky);                                                              \
+    kx = (wrap_ || kxw_) ? 0 : kx1_;                                                                    \
+    cbase += wrap_ ? BK : 0;                                                                            \
+  }
+
+#define SPLIT_ISSUE_LOADS()                                                                             \
+  {                                                                                                     \
+    static_for<A_PER>([&](auto J) __attribute__((always_inline)) {                                      \
+      constexpr int j = decltype(J)::value;                                                             \
+      ra[j] = *reinterpret_cast<const f32x4*>(a_addr[j]);                                               \
     });                                                                                                 \
     static_for<B_PER>([&](auto J) __attribute__((always_inline)) {                                      \
       constexpr int j = decltype(J)::value;                                                             \
-      rb[j] = *reinterpret_cast<const u32x4*>(wtile + (size_t)(tid + 256 * j) * 16);                    \
+      rb[j] = *reinterpret_cast<const u32x4*>(b_tile + (size_t)(tid + 256 * j) * 16);                   \
     });                                                                                                 \
-    wtile += BN * BK * 4;                                                                               \
-    if (++tap == p.ntaps) { tap = 0; ky = 0; kx = 0; cbase += BK; }                                     \
-    else if (++kx == p.kw) { kx = 0; ++ky; }                                                            \
   }
 
 #define SPLIT_STORE_TILES(stage)                                                                        \
@@ -187,50 +204,58 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
-  SPLIT_LOAD_TILES();
+#define SPLIT_COMPUTE(cur)                                                                              \
+  _Pragma("unroll") for (int step = 0; step < BK / 16; ++step) {                                        \
+    V8 ah[MI], al[MI], bh[NI], bl[NI];                                                                  \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t) {                                                    \
+      const int off = a_rd[t] + ((((2 * step + hi) ^ a_sw[t]) & 3) << 4);                               \
+      ah[t] = *reinterpret_cast<const V8*>((cur) + off);                                                \
+      al[t] = *reinterpret_cast<const V8*>((cur) + PLANE_A + off);                                      \
+    }                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NI; ++u) {                                                    \
+      const int off = b_rd[u] + ((((2 * step + hi) ^ b_sw[u]) & 3) << 4);                               \
+      bh[u] = *reinterpret_cast<const V8*>((cur) + off);                                                \
+      bl[u] = *reinterpret_cast<const V8*>((cur) + PLANE_B + off);                                      \
+    }                                                                                                   \
+    /* term-major order: consecutive MFMAs hit DIFFERENT accumulators */                                \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                      \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(al[t], bh[u], acc[t][u]); \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                      \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(ah[t], bl[u], acc[t][u]); \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                      \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(ah[t], bh[u], acc[t][u]); \
+  }
+
+  SPLIT_PREP_ADDR();
+  SPLIT_ISSUE_LOADS();                 // k-tile 0
   SPLIT_STORE_TILES(smem_raw);
-  if (nk > 1) SPLIT_LOAD_TILES();
+  SPLIT_PREP_ADDR();
+  if (nk > 1) SPLIT_ISSUE_LOADS();     // k-tile 1
+  SPLIT_PREP_ADDR();                   // addresses of k-tile 2
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* cur = smem_raw + (kt & 1) * STAGE;
-    if (kt + 1 < nk) {
-      SPLIT_STORE_TILES(smem_raw + ((kt + 1) & 1) * STAGE);
-      if (kt + 2 < nk) SPLIT_LOAD_TILES();
-    }
-#pragma unroll
-    for (int step = 0; step < BK / 16; ++step) {
-      V8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-      for (int t = 0; t < MI; ++t) {
-        const int off = a_rd[t] + ((((2 * step + hi) ^ a_sw[t]) & 3) << 4);
-        ah[t] = *reinterpret_cast<const V8*>(cur + off);
-        al[t] = *reinterpret_cast<const V8*>(cur + PLANE_A + off);
-      }
-#pragma unroll
-      for (int u = 0; u < NI; ++u) {
-        const int off = b_rd[u] + ((((2 * step + hi) ^ b_sw[u]) & 3) << 4);
-        bh[u] = *reinterpret_cast<const V8*>(cur + off);
-        bl[u] = *reinterpret_cast<const V8*>(cur + PLANE_B + off);
-      }
-      // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent MFMA on the same
-      // accumulator would wait out the previous one's full latency)
-#pragma unroll
-      for (int t = 0; t < MI; ++t)
-#pragma unroll
-        for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(al[t], bh[u], acc[t][u]);
-#pragma unroll
-      for (int t = 0; t < MI; ++t)
-#pragma unroll
-        for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(ah[t], bl[u], acc[t][u]);
-#pragma unroll
-      for (int t = 0; t < MI; ++t)
-#pragma unroll
-        for (int u = 0; u < NI; ++u) acc[t][u] = Half<FP16>::mfma(ah[t], bh[u], acc[t][u]);
-    }
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) {          // steady state: no conditionals inside
+    unsigned char* const nxt = smem_raw + ((kt + 1) & 1) * STAGE;
+    const unsigned char* const cur = smem_raw + (kt & 1) * STAGE;
+    SPLIT_STORE_TILES(nxt);
+    SPLIT_ISSUE_LOADS();
+    __builtin_amdgcn_sched_barrier(0);
+    SPLIT_PREP_ADDR();
+    SPLIT_COMPUTE(cur);
     __syncthreads();
   }
-#undef SPLIT_LOAD_TILES
+  if (kt + 1 < nk) {
+    SPLIT_STORE_TILES(smem_raw + ((kt + 1) & 1) * STAGE);
+    SPLIT_COMPUTE(smem_raw + (kt & 1) * STAGE);
+    __syncthreads();
+    ++kt;
+  }
+  SPLIT_COMPUTE(smem_raw + (kt & 1) * STAGE);
+  __syncthreads();
+#undef SPLIT_COMPUTE
+#undef SPLIT_PREP_ADDR
+#undef SPLIT_ISSUE_LOADS
 #undef SPLIT_STORE_TILES
 
   // ---- epilogue (identical to conv_igemm.hip): accumulators -> LDS -> 16-byte row pieces ----
