@@ -153,6 +153,46 @@ int peanut_map_dims(peanut_map_t* h, int dims[4]);
 int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
                        float* poses_inout, float* fp_map_pred, float* map_pred, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Stage 1 -- Mask R-CNN front end (preprocessing + ResNet-FPN backbone + RPN head)
+ *
+ * Replaces the dense-convolution part of detectron2's DefaultPredictor as built by
+ * SemanticPredMaskRCNN.__init__ (nav/agent/utils/segmentation.py:30-38) from
+ * COCO-InstSeg/mask_rcnn_R_101_cat9.yaml.  detectron2 is third party and absent from the reference
+ * checkout: the module graph follows its published v0.6 definitions, parity is pinned only against
+ * the restatement in oracle/rcnn_ref.py.  Proposal selection, NMS, ROIAlign, box/mask heads and mask
+ * pasting are not part of this library yet.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct peanut_rcnn_cfg {
+  int depth;               /* RESNETS.DEPTH (101) */
+  int stem_out;            /* RESNETS.STEM_OUT_CHANNELS (64) */
+  int res2_out;            /* RESNETS.RES2_OUT_CHANNELS (256) */
+  int stride_in_1x1;       /* RESNETS.STRIDE_IN_1X1 (true) */
+  int fpn_out;             /* FPN.OUT_CHANNELS (256) */
+  int num_anchors;         /* len(ANCHOR_GENERATOR.ASPECT_RATIOS[0]) (3) */
+  int min_size, max_size;  /* INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST (800, 1333) */
+  int size_divisibility;   /* 32 */
+  float pixel_mean[3], pixel_std[3]; /* BGR (103.53, 116.28, 123.675), (1, 1, 1) */
+  float bn_eps;            /* FrozenBatchNorm2d eps 1e-5 */
+  int precision;           /* PEANUT_PREC_* */
+} peanut_rcnn_cfg;
+
+typedef struct peanut_rcnn peanut_rcnn_t;
+
+/* tensors: detectron2 state-dict entries (host fp32), names like "backbone.bottom_up.res4.7.conv2.weight",
+ * "....conv2.norm.running_var", "backbone.fpn_lateral3.bias", "proposal_generator.rpn_head.conv.weight". */
+int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const peanut_tensor* tensors, int n_tensors);
+void peanut_rcnn_destroy(peanut_rcnn_t* h);
+/* Geometry of a (B,H,W) input: resized (h,w), zero-padded (h,w), the 5 pyramid level sizes p2..p6 as
+ * level_hw = {h2,w2,...,h6,w6}, workspace bytes, conv FLOPs per image.  Any output may be NULL. */
+int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], int padded_hw[2], int level_hw[10],
+                     size_t* workspace_bytes, double* flops_per_image);
+/* img_bgr: device uint8 [B,H,W,3] (what DefaultPredictor receives, segmentation.py:44-45).  Outputs
+ * (device fp32 NHWC, each array has 5 entries for p2..p6, entries or whole arrays may be NULL):
+ * pyramid[l] [B,h_l,w_l,fpn_out], objectness[l] [B,h_l,w_l,A], deltas[l] [B,h_l,w_l,4A]. */
+int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
+                              float* const* objectness, float* const* deltas, void* stream);
+
 /* Observation formatting, Agent_Helper._preprocess_obs/_preprocess_depth
  * (nav/agent/agent_helper.py:175-217): per-column invalid-depth fill, >0.99 -> far, metres -> cm
  * (min_d*100 + d*(max_d-min_d)*100 in fp32), then rows/cols ds//2::ds of RGB (the reference's PIL

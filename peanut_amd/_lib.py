@@ -43,6 +43,15 @@ class MapCfgC(C.Structure):
     ]
 
 
+class RcnnCfgC(C.Structure):
+    _fields_ = [
+        ("depth", C.c_int), ("stem_out", C.c_int), ("res2_out", C.c_int), ("stride_in_1x1", C.c_int),
+        ("fpn_out", C.c_int), ("num_anchors", C.c_int), ("min_size", C.c_int), ("max_size", C.c_int),
+        ("size_divisibility", C.c_int), ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3),
+        ("bn_eps", C.c_float), ("precision", C.c_int),
+    ]
+
+
 class TensorC(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
 
@@ -68,6 +77,12 @@ SIGNATURES = {
     "peanut_map_destroy": (None, [_P]),
     "peanut_map_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),
     "peanut_map_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "peanut_rcnn_create": (C.c_int, [C.POINTER(_P), C.POINTER(RcnnCfgC), C.POINTER(TensorC), C.c_int]),
+    "peanut_rcnn_destroy": (None, [_P]),
+    "peanut_rcnn_plan": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 2), C.POINTER(C.c_int * 2),
+                                   C.POINTER(C.c_int * 10), C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
+    "peanut_rcnn_forward_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P),
+                                            C.POINTER(_P), _P]),
     "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_int, _P, _P]),

@@ -15,8 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/peanut_hip.h"
-#include "common.h"
+#include "net_common.h"
 
 namespace peanut {
 
@@ -28,106 +27,6 @@ int fail(int code, const std::string& msg) {
 }
 
 namespace {
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int ensure(size_t n) {
-    if (n <= bytes) return 0;
-    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
-    bytes = n;
-    return 0;
-  }
-};
-
-// A conv layer resident on the device.
-struct ConvLayer {
-  std::string name;
-  ConvDesc d{};
-  int cin_real = 0;
-  DevBuf w, ss;  // packed weights; scale||shift
-};
-
-int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
-                int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision) {
-  if (cin_pad % 16 != 0 || cin_pad < cin) return fail(PEANUT_EINVAL, L.name + ": cin_pad must be a multiple of 16 and >= cin");
-  ConvDesc& d = L.d;
-  d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
-  conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
-  d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
-  if (precision != 0 && cin_pad % 32 == 0) d.bk = 32;        // split kernels are BK = 32 only
-  d.mode = (precision != 0 && d.bk == 32) ? precision : 0;   // 16-channel (stem.0) layers stay fp32
-  L.cin_real = cin;
-  const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);   // same byte count in every mode
-  std::vector<float> packed(nw);
-  if (d.mode == 0) pack_conv_weights(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.bk, packed.data());
-  else pack_conv_weights_split(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.mode == 2, packed.data());
-  std::vector<float> ss(2 * (size_t)d.cout_pad, 0.f);
-  for (int n = 0; n < cout; ++n) {
-    ss[n] = scale ? scale[n] : 1.f;
-    ss[d.cout_pad + n] = shift ? shift[n] : 0.f;
-  }
-  int rc;
-  if ((rc = L.w.ensure(nw * sizeof(float)))) return rc;
-  if ((rc = L.ss.ensure(ss.size() * sizeof(float)))) return rc;
-  PEANUT_HIP_CHECK(hipMemcpy(L.w.p, packed.data(), nw * sizeof(float), hipMemcpyHostToDevice));
-  PEANUT_HIP_CHECK(hipMemcpy(L.ss.p, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
-  d.w_packed = (const float*)L.w.p;
-  d.scale = (const float*)L.ss.p;
-  d.shift = (const float*)L.ss.p + d.cout_pad;
-  return 0;
-}
-
-// ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----
-struct Arena {
-  size_t top = 0;
-  bool keep_all = false;
-  std::vector<std::pair<size_t, size_t>> free_list;  // (offset, size)
-  static size_t round_up(size_t n) { return (n + 255) & ~(size_t)255; }
-  size_t alloc(size_t bytes) {
-    bytes = round_up(bytes);
-    int best = -1;
-    for (size_t i = 0; i < free_list.size(); ++i)
-      if (free_list[i].second >= bytes && (best < 0 || free_list[i].second < free_list[best].second)) best = (int)i;
-    if (best >= 0) {
-      const size_t off = free_list[best].first, sz = free_list[best].second;
-      free_list.erase(free_list.begin() + best);
-      if (sz > bytes) free_list.push_back({off + bytes, sz - bytes});
-      return off;
-    }
-    const size_t off = top;
-    top += bytes;
-    return off;
-  }
-  void release(size_t off, size_t bytes) {
-    if (keep_all) return;
-    bytes = round_up(bytes);
-    // coalesce with neighbours so the big stem buffers can be recycled for later stages
-    for (bool merged = true; merged;) {
-      merged = false;
-      for (size_t i = 0; i < free_list.size(); ++i) {
-        if (free_list[i].first + free_list[i].second == off) {
-          off = free_list[i].first; bytes += free_list[i].second;
-          free_list.erase(free_list.begin() + i); merged = true; break;
-        }
-        if (off + bytes == free_list[i].first) {
-          bytes += free_list[i].second;
-          free_list.erase(free_list.begin() + i); merged = true; break;
-        }
-      }
-    }
-    if (off + bytes == top) { top = off; return; }
-    free_list.push_back({off, bytes});
-  }
-};
-
-struct Act {  // an NHWC activation inside the workspace
-  size_t off = 0, bytes = 0;
-  int B = 0, H = 0, W = 0, C = 0;
-};
 
 enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE };
 
@@ -192,34 +91,8 @@ struct peanut_pred {
 
 namespace {
 
-struct TensorMap {
-  std::map<std::string, const peanut_tensor*> m;
-  const peanut_tensor* get(const std::string& k, int ndim, const int64_t* shape, int* rc) const {
-    auto it = m.find(k);
-    if (it == m.end()) { *rc = fail(PEANUT_EWEIGHTS, "state dict is missing '" + k + "'"); return nullptr; }
-    const peanut_tensor* t = it->second;
-    bool ok = t->ndim == ndim && t->data != nullptr;
-    for (int i = 0; ok && i < ndim; ++i) ok = t->shape[i] == shape[i];
-    if (!ok) { *rc = fail(PEANUT_EWEIGHTS, "'" + k + "' has an unexpected shape"); return nullptr; }
-    return t;
-  }
-};
-
-// BN(eval) as y = x*alpha + beta, alpha = weight/sqrt(var+eps), beta = bias - mean*alpha (fp32).
 int bn_fold(peanut_pred* h, const TensorMap& tm, const std::string& bn, int cout, float* scale, float* shift) {
-  int rc = 0;
-  const int64_t cshape[1] = {cout};
-  const peanut_tensor* g = tm.get(bn + ".weight", 1, cshape, &rc); if (!g) return rc;
-  const peanut_tensor* b = tm.get(bn + ".bias", 1, cshape, &rc); if (!b) return rc;
-  const peanut_tensor* mu = tm.get(bn + ".running_mean", 1, cshape, &rc); if (!mu) return rc;
-  const peanut_tensor* var = tm.get(bn + ".running_var", 1, cshape, &rc); if (!var) return rc;
-  for (int n = 0; n < cout; ++n) {
-    const float invstd = 1.0f / sqrtf(var->data[n] + h->cfg.bn_eps);
-    const float alpha = invstd * g->data[n];
-    scale[n] = alpha;
-    shift[n] = b->data[n] - mu->data[n] * alpha;
-  }
-  return 0;
+  return bn_fold_eps(tm, bn, cout, h->cfg.bn_eps, scale, shift);
 }
 
 // conv weight + (BatchNorm | bias) -> ConvLayer with folded scale/shift.
@@ -247,18 +120,6 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
-}
-
-Act make_act(Arena& a, int B, int H, int W, int C) {
-  Act t;
-  t.B = B; t.H = H; t.W = W; t.C = C;
-  t.bytes = (size_t)B * H * W * C * sizeof(float);
-  t.off = a.alloc(t.bytes);
-  return t;
-}
-
-double conv_flops(const ConvLayer* L, const Act& out) {
-  return 2.0 * (double)out.B * out.H * out.W * L->d.cout * L->cin_real * L->d.kh * L->d.kw;
 }
 
 void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out) {

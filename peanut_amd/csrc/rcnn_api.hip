@@ -1,0 +1,431 @@
+// Stage 1 front end: the part of detectron2's Mask R-CNN (R-101-FPN) inference that is dense convolution --
+// test-time preprocessing, ResNet-101 bottom-up path, FPN top-down path, RPN head -- as one static launch
+// sequence on the fused implicit-GEMM conv kernels, plus three small streaming kernels.
+//
+// Reference boundary: SemanticPredMaskRCNN.__init__/get_prediction build and call detectron2's
+// DefaultPredictor (nav/agent/utils/segmentation.py:31-38,45) with
+// nav/agent/utils/COCO-InstSeg/mask_rcnn_R_101_cat9.yaml.  detectron2 itself is not in the reference
+// checkout, so the module graph below follows detectron2 v0.6's published definitions under that yaml
+// (BasicStem, BottleneckBlock with STRIDE_IN_1X1, FrozenBatchNorm2d folded to scale/shift, FPN with sum
+// fusion and LastLevelMaxPool, StandardRPNHead).  Proposal selection / NMS / ROIAlign / box + mask heads
+// are the next rows and are NOT here.  Parity is pinned only against the torch
+// restatement oracle/rcnn_ref.py ("parity unpinned" w.r.t. the reference).
+#include <string.h>
+
+#include "net_common.h"
+
+namespace peanut {
+namespace {
+
+// ---- uint8 BGR [B,H,W,3] -> bilinear resize -> round to 8-bit -> (x - mean) / std -> NHWC [B,Hp,Wp,16] ----
+// (zero in the padded border and in channels 3..15).  One thread per output pixel.
+struct Norm3 { float mean[3], inv_std[3]; };
+
+__global__ __launch_bounds__(256) void rcnn_preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
+                                                              int H, int W, int nh, int nw, int Hp, int Wp, Norm3 nm,
+                                                              long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long long t = i / Wp;
+    const int y = (int)(t % Hp);
+    const long long b = t / Hp;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < nh && x < nw) {
+      // F.interpolate(bilinear, align_corners=False): src = (dst + 0.5) * in/out - 0.5, clamped at 0
+      const float sy = fmaxf(((float)y + 0.5f) * ((float)H / (float)nh) - 0.5f, 0.f);
+      const float sx = fmaxf(((float)x + 0.5f) * ((float)W / (float)nw) - 0.5f, 0.f);
+      int y0 = (int)sy, x0 = (int)sx;
+      if (y0 > H - 1) y0 = H - 1;
+      if (x0 > W - 1) x0 = W - 1;
+      const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+      const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+      const uint8_t* p00 = img + ((b * H + y0) * W + x0) * 3;
+      const uint8_t* p01 = img + ((b * H + y0) * W + x1) * 3;
+      const uint8_t* p10 = img + ((b * H + y1) * W + x0) * 3;
+      const uint8_t* p11 = img + ((b * H + y1) * W + x1) * 3;
+      float c[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float f = hy * (hx * (float)p00[k] + lx * (float)p01[k]) + ly * (hx * (float)p10[k] + lx * (float)p11[k]);
+        const float u8 = fminf(fmaxf(floorf(f + 0.5f), 0.f), 255.f);   // the resized image is uint8 again
+        c[k] = (u8 - nm.mean[k]) * nm.inv_std[k];
+      }
+      v[0] = make_float4(c[0], c[1], c[2], 0.f);
+    }
+    float4* o = reinterpret_cast<float4*>(out + (size_t)i * 16);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+}
+
+// ---- FPN top-down: y[b,h,w,c] += top[b,h/2,w/2,c]  (F.interpolate(scale_factor=2, nearest) + add) ----
+__global__ __launch_bounds__(256) void add_upsampled2x_kernel(float* __restrict__ y, const float* __restrict__ top, int H,
+                                                              int W, int C, long long total) {
+  const int groups = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    long long pix = i / groups;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int yy = (int)(pix % H);
+    const long long b = pix / H;
+    const float4 t = *reinterpret_cast<const float4*>(top + (((b * (H / 2) + yy / 2) * (W / 2)) + x / 2) * C + g * 4);
+    float4* d = reinterpret_cast<float4*>(y + i * 4);
+    float4 v = *d;
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    *d = v;
+  }
+}
+
+// ---- LastLevelMaxPool: max_pool2d(kernel 1, stride 2) = take every second pixel ----
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                         int C, int Ho, int Wo, long long total) {
+  const int groups = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    long long pix = i / groups;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const long long b = pix / Ho;
+    *reinterpret_cast<float4*>(y + i * 4) =
+        *reinterpret_cast<const float4*>(x + ((b * H + oy * 2) * W + ox * 2) * C + g * 4);
+  }
+}
+
+inline unsigned grid_for(long long items) {
+  long long g = (items + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+enum ROpKind { R_PREPROCESS, R_CONV, R_MAXPOOL, R_ADD_UP, R_SUBSAMPLE };
+
+struct ROp {
+  ROpKind kind;
+  std::string name, kernel;
+  const ConvLayer* conv = nullptr;
+  Act in, res, out;
+  bool has_res = false;
+  double flops = 0;
+  float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
+  int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
+};
+
+struct RPlan {
+  int B = 0, H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
+  Act splitk;
+  size_t bytes = 0;
+  std::vector<ROp> ops;
+  int lvl_h[5] = {0}, lvl_w[5] = {0};
+};
+
+}  // namespace
+}  // namespace peanut
+
+using namespace peanut;
+
+struct peanut_rcnn {
+  peanut_rcnn_cfg cfg{};
+  std::vector<std::unique_ptr<ConvLayer>> convs;
+  ConvLayer* stem = nullptr;
+  struct Block { ConvLayer *shortcut, *c1, *c2, *c3; };
+  std::vector<std::vector<Block>> stages;
+  ConvLayer *lateral[4] = {nullptr}, *output[4] = {nullptr};   // levels 2..5
+  ConvLayer *rpn_conv = nullptr, *rpn_obj = nullptr, *rpn_delta = nullptr;
+  std::map<std::string, std::unique_ptr<RPlan>> plans;
+  DevBuf ws;
+};
+
+namespace {
+
+int add_rconv(peanut_rcnn* h, const TensorMap& tm, const std::string& name, int cin, int cin_pad, int cout, int k,
+              int stride, int pad, bool norm, int relu, ConvLayer** out) {
+  int rc = 0;
+  const int64_t wshape[4] = {cout, cin, k, k};
+  const peanut_tensor* w = tm.get(name + ".weight", 4, wshape, &rc);
+  if (!w) return rc;
+  std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+  if (norm) {
+    if ((rc = bn_fold_eps(tm, name + ".norm", cout, h->cfg.bn_eps, scale.data(), shift.data()))) return rc;
+  } else {
+    const int64_t cshape[1] = {cout};
+    const peanut_tensor* b = tm.get(name + ".bias", 1, cshape, &rc);
+    if (!b) return rc;
+    for (int n = 0; n < cout; ++n) shift[n] = b->data[n];
+  }
+  auto L = std::make_unique<ConvLayer>();
+  L->name = name;
+  if ((rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, 1, relu,
+                        h->cfg.precision)))
+    return rc;
+  *out = L.get();
+  h->convs.push_back(std::move(L));
+  return 0;
+}
+
+void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
+  // detectron2 ResizeShortestEdge.get_output_shape
+  const double size = (double)c.min_size;
+  const double scale = size / (h < w ? h : w);
+  double newh = h < w ? size : scale * h, neww = h < w ? scale * w : size;
+  const double mx = newh > neww ? newh : neww;
+  if (mx > c.max_size) {
+    const double s = (double)c.max_size / mx;
+    newh *= s;
+    neww *= s;
+  }
+  *nh = (int)(newh + 0.5);
+  *nw = (int)(neww + 0.5);
+}
+
+void push_rconv(RPlan& pl, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
+  ROp op;
+  op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
+  op.kernel = std::string(L->d.mode == 0 ? "conv_igemm_128x" : (L->d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
+              std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
+  if (res) { op.res = *res; op.has_res = true; }
+  op.flops = conv_flops(L, out);
+  op.ext_slot = ext_slot;
+  pl.ops.push_back(op);
+}
+
+Act conv_out_act(Arena& ar, const ConvLayer* L, const Act& in) {
+  const ConvDesc& d = L->d;
+  return make_act(ar, in.B, conv_out_dim(in.H, d.kh, d.stride, d.pad, d.dil), conv_out_dim(in.W, d.kw, d.stride, d.pad, d.dil),
+                  d.cout);
+}
+
+std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
+  auto pl = std::make_unique<RPlan>();
+  pl->B = B; pl->H = H; pl->W = W;
+  resized_hw(h->cfg, H, W, &pl->nh, &pl->nw);
+  const int d = h->cfg.size_divisibility;
+  pl->Hp = (pl->nh + d - 1) / d * d;
+  pl->Wp = (pl->nw + d - 1) / d * d;
+  Arena ar;
+  auto rel = [&](const Act& t) { ar.release(t.off, t.bytes); };
+  pl->splitk.bytes = kSplitKScratchFloats * sizeof(float);
+  pl->splitk.off = ar.alloc(pl->splitk.bytes);
+  Act x = make_act(ar, B, pl->Hp, pl->Wp, 16);
+  { ROp op; op.kind = R_PREPROCESS; op.name = "preprocess"; op.kernel = "rcnn_preprocess"; op.out = x; pl->ops.push_back(op); }
+  // BasicStem
+  Act s = conv_out_act(ar, h->stem, x);
+  push_rconv(*pl, h->stem, x, nullptr, s);
+  rel(x);
+  Act cur = make_act(ar, B, conv_out_dim(s.H, 3, 2, 1, 1), conv_out_dim(s.W, 3, 2, 1, 1), s.C);
+  { ROp op; op.kind = R_MAXPOOL; op.name = "stem.maxpool"; op.kernel = "maxpool"; op.in = s; op.out = cur; pl->ops.push_back(op); }
+  rel(s);
+  // res2..res5
+  Act feats[4];
+  for (size_t si = 0; si < h->stages.size(); ++si) {
+    for (const auto& blk : h->stages[si]) {
+      Act idn = cur;
+      bool own = false;
+      if (blk.shortcut) {
+        idn = conv_out_act(ar, blk.shortcut, cur);
+        push_rconv(*pl, blk.shortcut, cur, nullptr, idn);
+        own = true;
+      }
+      Act t1 = conv_out_act(ar, blk.c1, cur);
+      push_rconv(*pl, blk.c1, cur, nullptr, t1);
+      Act t2 = conv_out_act(ar, blk.c2, t1);
+      push_rconv(*pl, blk.c2, t1, nullptr, t2);
+      rel(t1);
+      Act y = conv_out_act(ar, blk.c3, t2);
+      push_rconv(*pl, blk.c3, t2, &idn, y);        // + shortcut, ReLU fused
+      rel(t2);
+      if (own) rel(idn);
+      // the block input dies here unless it is a stage output that the FPN laterals still need
+      bool is_feat = false;
+      for (size_t q = 0; q < si; ++q) is_feat |= (cur.off == feats[q].off && cur.bytes == feats[q].bytes);
+      if (!is_feat) rel(cur);
+      cur = y;
+    }
+    feats[si] = cur;
+  }
+  // FPN top-down (levels 5 -> 2)
+  Act prev{};
+  Act p[5];
+  for (int lvl = 3; lvl >= 0; --lvl) {
+    Act lat = conv_out_act(ar, h->lateral[lvl], feats[lvl]);
+    push_rconv(*pl, h->lateral[lvl], feats[lvl], nullptr, lat);
+    rel(feats[lvl]);
+    if (lvl < 3) {
+      ROp op; op.kind = R_ADD_UP; op.name = "fpn_topdown" + std::to_string(lvl + 2); op.kernel = "add_upsampled2x";
+      op.in = prev; op.out = lat; pl->ops.push_back(op);
+      rel(prev);
+    }
+    prev = lat;
+    p[lvl] = conv_out_act(ar, h->output[lvl], prev);
+    push_rconv(*pl, h->output[lvl], prev, nullptr, p[lvl], lvl);
+  }
+  rel(prev);
+  p[4] = make_act(ar, B, (p[3].H - 1) / 2 + 1, (p[3].W - 1) / 2 + 1, p[3].C);
+  { ROp op; op.kind = R_SUBSAMPLE; op.name = "p6"; op.kernel = "subsample2"; op.in = p[3]; op.out = p[4]; op.ext_slot = 4; pl->ops.push_back(op); }
+  // RPN head on p2..p6
+  for (int lvl = 0; lvl < 5; ++lvl) {
+    pl->lvl_h[lvl] = p[lvl].H; pl->lvl_w[lvl] = p[lvl].W;
+    Act t = conv_out_act(ar, h->rpn_conv, p[lvl]);
+    push_rconv(*pl, h->rpn_conv, p[lvl], nullptr, t);
+    Act o = conv_out_act(ar, h->rpn_obj, t);
+    push_rconv(*pl, h->rpn_obj, t, nullptr, o, 5 + lvl);
+    Act dl = conv_out_act(ar, h->rpn_delta, t);
+    push_rconv(*pl, h->rpn_delta, t, nullptr, dl, 10 + lvl);
+    rel(t); rel(o); rel(dl);
+  }
+  size_t hw = pl->splitk.off + Arena::round_up(pl->splitk.bytes);
+  for (const auto& op : pl->ops)
+    for (const Act* a : {&op.in, &op.res, &op.out})
+      if (a->bytes && a->off + Arena::round_up(a->bytes) > hw) hw = a->off + Arena::round_up(a->bytes);
+  pl->bytes = hw;
+  return pl;
+}
+
+RPlan* get_rplan(peanut_rcnn* h, int B, int H, int W) {
+  if (B <= 0 || H < 32 || W < 32) { set_error("rcnn: need B >= 1 and H, W >= 32"); return nullptr; }
+  const std::string key = std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W);
+  auto it = h->plans.find(key);
+  if (it == h->plans.end()) it = h->plans.emplace(key, build_rplan(h, B, H, W)).first;
+  return it->second.get();
+}
+
+}  // namespace
+
+extern "C" {
+
+int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const peanut_tensor* tensors, int n) {
+  if (!out || !cfg || (!tensors && n > 0)) return fail(PEANUT_EINVAL, "peanut_rcnn_create: null argument");
+  if (cfg->depth != 50 && cfg->depth != 101 && cfg->depth != 152) return fail(PEANUT_EINVAL, "rcnn: depth must be 50/101/152");
+  if (cfg->fpn_out % 32 || cfg->num_anchors < 1 || cfg->min_size < 32 || cfg->size_divisibility != 32)
+    return fail(PEANUT_EINVAL, "rcnn: unsupported configuration");
+  if (cfg->precision < 0 || cfg->precision > 2) return fail(PEANUT_EINVAL, "rcnn: bad precision");
+  auto h = std::make_unique<peanut_rcnn>();
+  h->cfg = *cfg;
+  TensorMap tm;
+  for (int i = 0; i < n; ++i)
+    if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
+  int rc;
+  if ((rc = add_rconv(h.get(), tm, "backbone.bottom_up.stem.conv1", 3, 16, cfg->stem_out, 7, 2, 3, true, 1, &h->stem))) return rc;
+  const int nblocks[3][4] = {{3, 4, 6, 3}, {3, 4, 23, 3}, {3, 8, 36, 3}};
+  const int* nb = nblocks[cfg->depth == 50 ? 0 : (cfg->depth == 101 ? 1 : 2)];
+  int cin = cfg->stem_out, bott = cfg->res2_out / 4, cout = cfg->res2_out;
+  for (int si = 0; si < 4; ++si) {
+    std::vector<peanut_rcnn::Block> blocks;
+    for (int bi = 0; bi < nb[si]; ++bi) {
+      const std::string p = "backbone.bottom_up.res" + std::to_string(si + 2) + "." + std::to_string(bi);
+      const int s = (bi == 0 && si > 0) ? 2 : 1;
+      const int s1 = cfg->stride_in_1x1 ? s : 1, s3 = cfg->stride_in_1x1 ? 1 : s;
+      peanut_rcnn::Block b{nullptr, nullptr, nullptr, nullptr};
+      if (cin != cout && (rc = add_rconv(h.get(), tm, p + ".shortcut", cin, cin, cout, 1, s, 0, true, 0, &b.shortcut))) return rc;
+      if ((rc = add_rconv(h.get(), tm, p + ".conv1", cin, cin, bott, 1, s1, 0, true, 1, &b.c1))) return rc;
+      if ((rc = add_rconv(h.get(), tm, p + ".conv2", bott, bott, bott, 3, s3, 1, true, 1, &b.c2))) return rc;
+      if ((rc = add_rconv(h.get(), tm, p + ".conv3", bott, bott, cout, 1, 1, 0, true, 1, &b.c3))) return rc;   // ReLU after the add
+      blocks.push_back(b);
+      cin = cout;
+    }
+    h->stages.push_back(blocks);
+    bott *= 2;
+    cout *= 2;
+  }
+  int c = cfg->res2_out;
+  for (int lvl = 0; lvl < 4; ++lvl, c *= 2) {
+    const std::string l = std::to_string(lvl + 2);
+    if ((rc = add_rconv(h.get(), tm, "backbone.fpn_lateral" + l, c, c, cfg->fpn_out, 1, 1, 0, false, 0, &h->lateral[lvl]))) return rc;
+    if ((rc = add_rconv(h.get(), tm, "backbone.fpn_output" + l, cfg->fpn_out, cfg->fpn_out, cfg->fpn_out, 3, 1, 1, false, 0, &h->output[lvl]))) return rc;
+  }
+  const int f = cfg->fpn_out;
+  if ((rc = add_rconv(h.get(), tm, "proposal_generator.rpn_head.conv", f, f, f, 3, 1, 1, false, 1, &h->rpn_conv))) return rc;
+  if ((rc = add_rconv(h.get(), tm, "proposal_generator.rpn_head.objectness_logits", f, f, cfg->num_anchors, 1, 1, 0, false, 0, &h->rpn_obj))) return rc;
+  if ((rc = add_rconv(h.get(), tm, "proposal_generator.rpn_head.anchor_deltas", f, f, cfg->num_anchors * 4, 1, 1, 0, false, 0, &h->rpn_delta))) return rc;
+  PEANUT_HIP_CHECK(hipDeviceSynchronize());
+  *out = h.release();
+  return 0;
+}
+
+void peanut_rcnn_destroy(peanut_rcnn_t* h) { delete h; }
+
+int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw_out[2], int padded_hw_out[2], int level_hw[10],
+                     size_t* workspace_bytes, double* flops_per_image) {
+  if (!h) return fail(PEANUT_EINVAL, "null handle");
+  RPlan* pl = get_rplan(h, B, H, W);
+  if (!pl) return PEANUT_EINVAL;
+  if (resized_hw_out) { resized_hw_out[0] = pl->nh; resized_hw_out[1] = pl->nw; }
+  if (padded_hw_out) { padded_hw_out[0] = pl->Hp; padded_hw_out[1] = pl->Wp; }
+  if (level_hw) for (int l = 0; l < 5; ++l) { level_hw[2 * l] = pl->lvl_h[l]; level_hw[2 * l + 1] = pl->lvl_w[l]; }
+  if (workspace_bytes) *workspace_bytes = pl->bytes;
+  if (flops_per_image) {
+    double f = 0;
+    for (const auto& op : pl->ops) f += op.flops;
+    *flops_per_image = f / B;
+  }
+  return 0;
+}
+
+int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
+                              float* const* objectness, float* const* deltas, void* stream) {
+  if (!h || !img_bgr) return fail(PEANUT_EINVAL, "peanut_rcnn_forward_front: null argument");
+  RPlan* pl = get_rplan(h, B, H, W);
+  if (!pl) return PEANUT_EINVAL;
+  int rc;
+  if ((rc = h->ws.ensure(pl->bytes))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)h->ws.p;
+  auto P = [&](const Act& a) { return (float*)(base + a.off); };
+  auto ext = [&](int slot) -> float* {
+    if (slot < 0) return nullptr;
+    if (slot < 5) return pyramid ? pyramid[slot] : nullptr;
+    if (slot < 10) return objectness ? objectness[slot - 5] : nullptr;
+    return deltas ? deltas[slot - 10] : nullptr;
+  };
+  for (const auto& op : pl->ops) {
+    switch (op.kind) {
+      case R_PREPROCESS: {
+        Norm3 nm;
+        for (int k = 0; k < 3; ++k) { nm.mean[k] = h->cfg.pixel_mean[k]; nm.inv_std[k] = 1.0f / h->cfg.pixel_std[k]; }
+        const long long total = (long long)B * pl->Hp * pl->Wp;
+        hipLaunchKernelGGL(rcnn_preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, s, img_bgr, P(op.out), H, W, pl->nh,
+                           pl->nw, pl->Hp, pl->Wp, nm, total);
+        break;
+      }
+      case R_CONV: {
+        ConvArgs a{};
+        a.x = P(op.in);
+        a.res = op.has_res ? P(op.res) : nullptr;
+        a.y = P(op.out);
+        a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = op.out.H; a.Wo = op.out.W;
+        a.ws = P(pl->splitk); a.ws_floats = kSplitKScratchFloats;
+        if ((rc = launch_conv(op.conv->d, a, s))) return rc;
+        break;
+      }
+      case R_MAXPOOL:
+        if ((rc = launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s))) return rc;
+        break;
+      case R_ADD_UP: {
+        if (op.out.H != op.in.H * 2 || op.out.W != op.in.W * 2) return fail(PEANUT_EINVAL, "rcnn: FPN levels are not exact 2x multiples");
+        const long long total = (long long)op.out.B * op.out.H * op.out.W * (op.out.C / 4);
+        hipLaunchKernelGGL(add_upsampled2x_kernel, dim3(grid_for(total)), dim3(256), 0, s, P(op.out), P(op.in), op.out.H,
+                           op.out.W, op.out.C, total);
+        break;
+      }
+      case R_SUBSAMPLE: {
+        const long long total = (long long)op.out.B * op.out.H * op.out.W * (op.out.C / 4);
+        hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, P(op.in), P(op.out), op.in.H, op.in.W,
+                           op.in.C, op.out.H, op.out.W, total);
+        break;
+      }
+    }
+    if (float* dst = ext(op.ext_slot))
+      PEANUT_HIP_CHECK(hipMemcpyAsync(dst, P(op.out), op.out.bytes, hipMemcpyDeviceToDevice, s));
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_rcnn_forward_front: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"
