@@ -193,6 +193,28 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], i
 int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
                               float* const* objectness, float* const* deltas, void* stream);
 
+/* The non-convolution operators of Mask R-CNN inference (detectron2 implements them natively in
+ * `detectron2._C` / torchvision: ROIAlign, nms; paste_masks_in_image is a fused resample+threshold).
+ * Restated from detectron2 v0.6's published definitions; parity pinned against oracle/rcnn_ref.py only.
+ *
+ * peanut_roi_align: ROIAlign over up to 4 NHWC pyramid levels in one launch.  feats[l] device [B,h_l,w_l,C],
+ * feat_hw = {h_0,w_0,...}, scales[l] = 1/stride_l; rois device [N,5] = (batch, x0, y0, x1, y1) in input pixels,
+ * levels device int32 [N]; sampling_ratio 0 = adaptive ceil(roi/pooled); aligned = ROIAlignV2's half-pixel
+ * shift; out device [N,pooled,pooled,C]. */
+int peanut_roi_align(const float* const* feats, const int* feat_hw, const float* scales, int n_levels, int C,
+                     const float* rois, const int* levels, int n_rois, int pooled, int sampling_ratio, int aligned,
+                     float* out, void* stream);
+/* Greedy NMS of boxes ALREADY sorted by descending score (device [n,4] x0,y0,x1,y1); categories (device
+ * int32 [n], may be NULL) restrict suppression to equal ids (= torchvision batched_nms); keep device
+ * uint8 [n] (1 = kept); workspace device, peanut_nms_workspace_bytes(n) bytes. */
+size_t peanut_nms_workspace_bytes(int n);
+int peanut_nms(const float* boxes_sorted, const int* categories, int n, float iou_threshold, void* workspace,
+               unsigned char* keep, void* stream);
+/* paste_masks_in_image + threshold: masks device [n,M,M] probabilities, boxes device [n,4] in output-image
+ * pixels -> out device uint8 [n,H,W] (1 where the bilinearly resampled mask >= threshold). */
+int peanut_paste_masks(const float* masks, const float* boxes, int n, int M, int H, int W, float threshold,
+                       unsigned char* out, void* stream);
+
 /* Observation formatting, Agent_Helper._preprocess_obs/_preprocess_depth
  * (nav/agent/agent_helper.py:175-217): per-column invalid-depth fill, >0.99 -> far, metres -> cm
  * (min_d*100 + d*(max_d-min_d)*100 in fp32), then rows/cols ds//2::ds of RGB (the reference's PIL

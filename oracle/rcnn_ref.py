@@ -101,3 +101,265 @@ def forward_front(sd, img_bgr_u8: torch.Tensor, cfg: RcnnCfg):
         p = fpn(sd, bottom_up(sd, x, cfg))
         obj, deltas = rpn_head(sd, p)
     return p, obj, deltas
+
+
+# =========================================================================================================
+# Proposal generator and ROI heads (detectron2 v0.6: RPN.predict_proposals / find_top_rpn_proposals,
+# DefaultAnchorGenerator, Box2BoxTransform, ROIPooler + ROIAlign(aligned=True), FastRCNNConvFCHead,
+# FastRCNNOutputLayers.inference / fast_rcnn_inference_single_image, MaskRCNNConvUpsampleHead,
+# mask_rcnn_inference, detector_postprocess, paste_masks_in_image), restated in plain torch on the CPU.
+# Same "parity unpinned" status as the front end above.
+# =========================================================================================================
+import math
+
+
+def cell_anchors(size: float, ratios):
+    out = []
+    for r in ratios:
+        w = math.sqrt(size * size / r)
+        h = r * w
+        out.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+    return torch.tensor(out, dtype=torch.float32)
+
+
+def grid_anchors(hw, stride: int, size: float, ratios) -> torch.Tensor:
+    """DefaultAnchorGenerator (offset 0): [(h*w*A), 4] ordered (y, x, a)."""
+    h, w = hw
+    sx = torch.arange(0, w * stride, step=stride, dtype=torch.float32)
+    sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+    return (shifts.view(-1, 1, 4) + cell_anchors(size, ratios).view(1, -1, 4)).reshape(-1, 4)
+
+
+SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+def apply_deltas(deltas: torch.Tensor, boxes: torch.Tensor, weights) -> torch.Tensor:
+    """Box2BoxTransform.apply_deltas: deltas [N, k*4], boxes [N, 4]."""
+    deltas = deltas.float()
+    boxes = boxes.to(deltas.dtype)
+    widths = boxes[:, 2] - boxes[:, 0]
+    heights = boxes[:, 3] - boxes[:, 1]
+    ctr_x = boxes[:, 0] + 0.5 * widths
+    ctr_y = boxes[:, 1] + 0.5 * heights
+    wx, wy, ww, wh = weights
+    dx = deltas[:, 0::4] / wx
+    dy = deltas[:, 1::4] / wy
+    dw = torch.clamp(deltas[:, 2::4] / ww, max=SCALE_CLAMP)
+    dh = torch.clamp(deltas[:, 3::4] / wh, max=SCALE_CLAMP)
+    pcx = dx * widths[:, None] + ctr_x[:, None]
+    pcy = dy * heights[:, None] + ctr_y[:, None]
+    pw = torch.exp(dw) * widths[:, None]
+    ph = torch.exp(dh) * heights[:, None]
+    out = torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1)
+    return out.reshape(deltas.shape)
+
+
+def clip_boxes(b: torch.Tensor, hw) -> torch.Tensor:
+    h, w = hw
+    return torch.stack((b[:, 0].clamp(0, w), b[:, 1].clamp(0, h), b[:, 2].clamp(0, w), b[:, 3].clamp(0, h)), dim=1)
+
+
+def nms_sorted(boxes: torch.Tensor, cats: torch.Tensor, thr: float) -> torch.Tensor:
+    """Greedy NMS of score-sorted boxes, suppression only within equal categories; returns keep mask."""
+    n = boxes.shape[0]
+    keep = torch.ones(n, dtype=torch.bool)
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    for i in range(n):
+        if not keep[i]:
+            continue
+        lt = torch.maximum(boxes[i, :2], boxes[i + 1:, :2])
+        rb = torch.minimum(boxes[i, 2:], boxes[i + 1:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, 0] * wh[:, 1]
+        iou = inter / (area[i] + area[i + 1:] - inter)
+        keep[i + 1:] &= ~((iou > thr) & (cats[i + 1:] == cats[i]))
+    return keep
+
+
+def batched_nms(boxes, scores, cats, thr):
+    """torchvision.ops.batched_nms semantics: indices of kept boxes sorted by decreasing score."""
+    order = torch.argsort(scores, descending=True, stable=True)
+    keep = nms_sorted(boxes[order], cats[order], thr)
+    return order[keep]
+
+
+def rpn_proposals(obj: List[torch.Tensor], deltas: List[torch.Tensor], image_hw, cfg: RcnnCfg):
+    """obj[l] [B,A,h,w], deltas[l] [B,4A,h,w] (NCHW as the modules emit them) -> per image (boxes, logits)."""
+    B = obj[0].shape[0]
+    strides = [4, 8, 16, 32, 64]
+    sc, pr, lv = [], [], []
+    for l, (o, d) in enumerate(zip(obj, deltas)):
+        h, w = o.shape[2:]
+        A = o.shape[1]
+        anchors = grid_anchors((h, w), strides[l], cfg.anchor_sizes[l], cfg.aspect_ratios)
+        logits = o.permute(0, 2, 3, 1).flatten(1)                                   # [B, h*w*A]
+        dl = d.view(B, A, 4, h, w).permute(0, 3, 4, 1, 2).flatten(1, -2)            # [B, h*w*A, 4]
+        props = apply_deltas(dl.reshape(-1, 4), anchors.unsqueeze(0).expand(B, -1, -1).reshape(-1, 4),
+                             cfg.rpn_bbox_weights).view(B, -1, 4)
+        k = min(logits.shape[1], cfg.rpn_pre_nms_topk)
+        s, idx = logits.sort(descending=True, dim=1)
+        sc.append(s[:, :k])
+        pr.append(props[torch.arange(B)[:, None], idx[:, :k]])
+        lv.append(torch.full((k,), l, dtype=torch.int64))
+    sc, pr, lv = torch.cat(sc, 1), torch.cat(pr, 1), torch.cat(lv, 0)
+    out = []
+    for n in range(B):
+        boxes, scores, lvl = pr[n], sc[n], lv
+        valid = torch.isfinite(boxes).all(1) & torch.isfinite(scores)
+        boxes, scores, lvl = boxes[valid], scores[valid], lvl[valid]
+        boxes = clip_boxes(boxes, image_hw)
+        ne = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
+        boxes, scores, lvl = boxes[ne], scores[ne], lvl[ne]
+        keep = batched_nms(boxes, scores, lvl, cfg.rpn_nms_thresh)[:cfg.rpn_post_nms_topk]
+        out.append((boxes[keep], scores[keep]))
+    return out
+
+
+def assign_levels(boxes: torch.Tensor, min_level=2, max_level=5, canonical_box_size=224, canonical_level=4):
+    sizes = torch.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))
+    lv = torch.floor(canonical_level + torch.log2(sizes / canonical_box_size + 1e-8))
+    return torch.clamp(lv, min=min_level, max=max_level).to(torch.int64) - min_level
+
+
+def _bilinear(feat, y, x):
+    C, H, W = feat.shape
+    if y < -1.0 or y > H or x < -1.0 or x > W:
+        return torch.zeros(C)
+    y, x = max(y, 0.0), max(x, 0.0)
+    yl, xl = int(y), int(x)
+    if yl >= H - 1:
+        yh = yl = H - 1
+        y = float(yl)
+    else:
+        yh = yl + 1
+    if xl >= W - 1:
+        xh = xl = W - 1
+        x = float(xl)
+    else:
+        xh = xl + 1
+    ly, lx = y - yl, x - xl
+    hy, hx = 1.0 - ly, 1.0 - lx
+    return hy * hx * feat[:, yl, xl] + hy * lx * feat[:, yl, xh] + ly * hx * feat[:, yh, xl] + ly * lx * feat[:, yh, xh]
+
+
+def roi_align(feat: torch.Tensor, rois: torch.Tensor, scale: float, P: int, sampling_ratio=0, aligned=True):
+    """ROIAlign (detectron2/torchvision kernel, loop form): feat [B,C,H,W], rois [N,5] -> [N,C,P,P]."""
+    out = torch.zeros((rois.shape[0], feat.shape[1], P, P))
+    off = 0.5 if aligned else 0.0
+    for n, r in enumerate(rois.tolist()):
+        f = feat[int(r[0])]
+        sw, sh, ew, eh = (np.float32(r[1]) * np.float32(scale) - np.float32(off), np.float32(r[2]) * np.float32(scale) - np.float32(off),
+                          np.float32(r[3]) * np.float32(scale) - np.float32(off), np.float32(r[4]) * np.float32(scale) - np.float32(off))
+        rw, rh = np.float32(ew - sw), np.float32(eh - sh)
+        if not aligned:
+            rw, rh = max(rw, np.float32(1.0)), max(rh, np.float32(1.0))
+        bh, bw = np.float32(rh / np.float32(P)), np.float32(rw / np.float32(P))
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / np.float32(P)))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / np.float32(P)))
+        count = max(gh * gw, 1)
+        for ph in range(P):
+            for pw in range(P):
+                acc = torch.zeros(feat.shape[1])
+                for iy in range(gh):
+                    y = float(np.float32(sh + np.float32(ph) * bh + np.float32(iy + 0.5) * bh / np.float32(gh)))
+                    for ix in range(gw):
+                        x = float(np.float32(sw + np.float32(pw) * bw + np.float32(ix + 0.5) * bw / np.float32(gw)))
+                        acc += _bilinear(f, y, x)
+                out[n, :, ph, pw] = acc / count
+    return out
+
+
+import numpy as np  # noqa: E402  (used by roi_align's fp32 coordinate arithmetic)
+
+
+def roi_pool(pyr: Dict[str, torch.Tensor], rois: torch.Tensor, P: int) -> torch.Tensor:
+    """ROIPooler over p2..p5 (scales 1/4..1/32), ROIAlignV2, sampling_ratio 0."""
+    lv = assign_levels(rois[:, 1:])
+    out = torch.zeros((rois.shape[0], pyr["p2"].shape[1], P, P))
+    for l, k in enumerate(("p2", "p3", "p4", "p5")):
+        inds = torch.nonzero(lv == l).flatten()
+        if len(inds):
+            out[inds] = roi_align(pyr[k], rois[inds], 1.0 / (4 * 2 ** l), P, 0, True)
+    return out
+
+
+def box_head(sd, feats: torch.Tensor):
+    x = feats.flatten(1)
+    x = F.relu(F.linear(x, sd["roi_heads.box_head.fc1.weight"], sd["roi_heads.box_head.fc1.bias"]))
+    x = F.relu(F.linear(x, sd["roi_heads.box_head.fc2.weight"], sd["roi_heads.box_head.fc2.bias"]))
+    scores = F.linear(x, sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"])
+    deltas = F.linear(x, sd["roi_heads.box_predictor.bbox_pred.weight"], sd["roi_heads.box_predictor.bbox_pred.bias"])
+    return scores, deltas
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_hw, cfg: RcnnCfg):
+    """boxes [R, K*4] (decoded), scores [R, K+1] (softmax) -> (boxes [n,4], scores [n], classes [n])."""
+    valid = torch.isfinite(boxes).all(1) & torch.isfinite(scores).all(1)
+    boxes, scores = boxes[valid], scores[valid]
+    scores = scores[:, :-1]
+    K = boxes.shape[1] // 4
+    boxes = clip_boxes(boxes.reshape(-1, 4), image_hw).view(-1, K, 4)
+    mask = scores > cfg.score_thresh_test
+    inds = mask.nonzero()
+    boxes, scores = boxes[mask], scores[mask]
+    keep = batched_nms(boxes, scores, inds[:, 1], cfg.nms_thresh_test)[:cfg.detections_per_image]
+    return boxes[keep], scores[keep], inds[keep][:, 1]
+
+
+def mask_head(sd, feats: torch.Tensor, cfg: RcnnCfg):
+    x = feats
+    for i in range(cfg.num_mask_convs):
+        x = F.relu(F.conv2d(x, sd[f"roi_heads.mask_head.mask_fcn{i + 1}.weight"], sd[f"roi_heads.mask_head.mask_fcn{i + 1}.bias"], padding=1))
+    x = F.relu(F.conv_transpose2d(x, sd["roi_heads.mask_head.deconv.weight"], sd["roi_heads.mask_head.deconv.bias"], stride=2))
+    return F.conv2d(x, sd["roi_heads.mask_head.predictor.weight"], sd["roi_heads.mask_head.predictor.bias"])
+
+
+def paste_values(masks: torch.Tensor, boxes: torch.Tensor, hw) -> torch.Tensor:
+    """_do_paste_mask (skip_empty=False): masks [N,M,M] probs resampled into the image, float [N,H,W]."""
+    H, W = hw
+    N = masks.shape[0]
+    if N == 0:
+        return torch.zeros((0, H, W), dtype=torch.float32)
+    x0, y0, x1, y1 = torch.split(boxes, 1, dim=1)
+    img_y = torch.arange(0, H, dtype=torch.float32) + 0.5
+    img_x = torch.arange(0, W, dtype=torch.float32) + 0.5
+    img_y = (img_y - y0) / (y1 - y0) * 2 - 1
+    img_x = (img_x - x0) / (x1 - x0) * 2 - 1
+    gx = img_x[:, None, :].expand(N, H, W)
+    gy = img_y[:, :, None].expand(N, H, W)
+    return F.grid_sample(masks[:, None].float(), torch.stack([gx, gy], dim=3), align_corners=False)[:, 0]
+
+
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw, thr: float) -> torch.Tensor:
+    """paste_masks_in_image: probabilities -> bool [N,H,W] (threshold 0.5 in detector_postprocess)."""
+    return paste_values(masks, boxes, hw) >= thr
+
+
+def inference(sd, img_bgr_u8: torch.Tensor, cfg: RcnnCfg):
+    """GeneralizedRCNN.inference + detector_postprocess for a batch; list of dicts (pred_boxes, scores,
+    pred_classes, pred_masks bool [n,H,W]) at the ORIGINAL image resolution."""
+    B, H, W, _ = img_bgr_u8.shape
+    nh, nw = resized_hw(H, W, cfg)
+    pyr, obj, deltas = forward_front(sd, img_bgr_u8, cfg)
+    results = []
+    with torch.no_grad():
+        props = rpn_proposals(obj, deltas, (nh, nw), cfg)
+        for n in range(B):
+            pb = props[n][0]
+            rois = torch.cat([torch.full((len(pb), 1), float(n)), pb], 1)
+            scores, dl = box_head(sd, roi_pool(pyr, rois, cfg.box_pooler_resolution))
+            boxes = apply_deltas(dl, pb, cfg.roi_bbox_weights)
+            b, s, c = fast_rcnn_inference_single_image(boxes, F.softmax(scores, dim=-1), (nh, nw), cfg)
+            rois = torch.cat([torch.full((len(b), 1), float(n)), b], 1)
+            logits = mask_head(sd, roi_pool(pyr, rois, cfg.mask_pooler_resolution), cfg)
+            probs = logits[torch.arange(len(b)), c].sigmoid() if len(b) else logits[:, 0]
+            sx, sy = W / nw, H / nh
+            ob = b * torch.tensor([sx, sy, sx, sy])
+            ob = clip_boxes(ob, (H, W))
+            ne = ((ob[:, 2] - ob[:, 0]) > 0) & ((ob[:, 3] - ob[:, 1]) > 0)
+            ob, s, c, probs = ob[ne], s[ne], c[ne], probs[ne]
+            results.append(dict(pred_boxes=ob, scores=s, pred_classes=c, pred_masks=paste_masks(probs, ob, (H, W), cfg.mask_threshold),
+                                proposals=pb, mask_probs=probs))
+    return results

@@ -30,6 +30,25 @@ class RcnnCfg:
     pixel_mean: Tuple[float, float, float] = (103.53, 116.28, 123.675)   # BGR (:82-85)
     pixel_std: Tuple[float, float, float] = (1.0, 1.0, 1.0)              # (:86-89)
     bn_eps: float = 1e-5                               # FrozenBatchNorm2d default
+    # proposal generator (RPN, :224-253) and anchors (:41-57)
+    anchor_sizes: Tuple[int, ...] = (32, 64, 128, 256, 512)
+    aspect_ratios: Tuple[float, ...] = (0.5, 1.0, 2.0)
+    rpn_pre_nms_topk: int = 1000
+    rpn_post_nms_topk: int = 1000
+    rpn_nms_thresh: float = 0.7
+    rpn_bbox_weights: Tuple[float, ...] = (1.0, 1.0, 1.0, 1.0)
+    # ROI heads (:163-223, :312)
+    num_classes: int = 9
+    box_pooler_resolution: int = 7
+    mask_pooler_resolution: int = 14
+    fc_dim: int = 1024
+    mask_conv_dim: int = 256
+    num_mask_convs: int = 4
+    roi_bbox_weights: Tuple[float, ...] = (10.0, 10.0, 5.0, 5.0)
+    score_thresh_test: float = 0.05
+    nms_thresh_test: float = 0.5
+    detections_per_image: int = 100
+    mask_threshold: float = 0.5                        # detector_postprocess default
 
     @property
     def blocks(self) -> Tuple[int, int, int, int]:
@@ -79,6 +98,23 @@ def head_convs(cfg: RcnnCfg) -> List[RConv]:
     return out
 
 
+def roi_head_keys(cfg: RcnnCfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    """StandardROIHeads: FastRCNNConvFCHead (NUM_FC 2), FastRCNNOutputLayers, MaskRCNNConvUpsampleHead."""
+    p, f, k = cfg.box_pooler_resolution, cfg.fc_dim, cfg.num_classes
+    keys = [("roi_heads.box_head.fc1.weight", (f, cfg.fpn_out * p * p)), ("roi_heads.box_head.fc1.bias", (f,)),
+            ("roi_heads.box_head.fc2.weight", (f, f)), ("roi_heads.box_head.fc2.bias", (f,)),
+            ("roi_heads.box_predictor.cls_score.weight", (k + 1, f)), ("roi_heads.box_predictor.cls_score.bias", (k + 1,)),
+            ("roi_heads.box_predictor.bbox_pred.weight", (4 * k, f)), ("roi_heads.box_predictor.bbox_pred.bias", (4 * k,))]
+    c = cfg.mask_conv_dim
+    cin = cfg.fpn_out
+    for i in range(cfg.num_mask_convs):
+        keys += [(f"roi_heads.mask_head.mask_fcn{i + 1}.weight", (c, cin, 3, 3)), (f"roi_heads.mask_head.mask_fcn{i + 1}.bias", (c,))]
+        cin = c
+    keys += [("roi_heads.mask_head.deconv.weight", (c, c, 2, 2)), ("roi_heads.mask_head.deconv.bias", (c,)),
+             ("roi_heads.mask_head.predictor.weight", (k, c, 1, 1)), ("roi_heads.mask_head.predictor.bias", (k,))]
+    return keys
+
+
 def front_keys(cfg: RcnnCfg) -> List[Tuple[str, Tuple[int, ...]]]:
     keys = []
     for c in backbone_convs(cfg) + head_convs(cfg):
@@ -112,6 +148,21 @@ def make_seeded_rcnn_state_dict(cfg: RcnnCfg = RcnnCfg(), seed: int = 0) -> "Ord
             sd[f"{c.name}.norm.running_var"] = torch.rand((c.cout,), generator=g) * 0.5 + 0.75
         else:
             sd[f"{c.name}.bias"] = torch.randn((c.cout,), generator=g) * 0.1
+    for key, shape in roi_head_keys(cfg):
+        if key.endswith(".bias"):
+            sd[key] = torch.randn(shape, generator=g) * 0.1
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            std = (2.0 / fan_in) ** 0.5
+            if "bbox_pred" in key or "anchor" in key:
+                std *= 0.2             # small box refinements
+            if "cls_score" in key:
+                std *= 0.35            # keep the softmax un-saturated: distinct scores, no ties in the sorts
+            if "mask_head.predictor" in key:
+                std *= 2.0             # mask logits of both signs
+            sd[key] = torch.randn(shape, generator=g) * std
     return sd
 
 
@@ -130,3 +181,20 @@ def resized_hw(h: int, w: int, cfg: RcnnCfg) -> Tuple[int, int]:
 def padded_hw(h: int, w: int, cfg: RcnnCfg) -> Tuple[int, int]:
     d = cfg.size_divisibility
     return (h + d - 1) // d * d, (w + d - 1) // d * d
+
+
+def load_detectron2_checkpoint(path: str) -> "OrderedDict[str, torch.Tensor]":
+    """Read the file ``cfg.MODEL.WEIGHTS`` names (segmentation.py:34, arguments.py:32): a torch pickle
+    holding either ``{'model': {...}}`` (DetectionCheckpointer's layout; values may be numpy arrays for
+    converted model-zoo files) or a bare state dict.  Returns fp32 CPU tensors under detectron2's
+    parameter names (``backbone.bottom_up.*``, ``proposal_generator.*``, ``roi_heads.*``)."""
+    import numpy as np
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    sd = blob["model"] if isinstance(blob, dict) and "model" in blob and isinstance(blob["model"], dict) else blob
+    out = OrderedDict()
+    for k, v in sd.items():
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        if torch.is_tensor(v) and v.dtype.is_floating_point:
+            out[k[7:] if k.startswith("module.") else k] = v.float().contiguous()
+    return out

@@ -1,9 +1,9 @@
 """Stage 1 boundary: ``SemanticPredMaskRCNN`` (nav/agent/utils/segmentation.py:28-62).
 
-Only the part of the reference that lives IN the reference is built here: the per-instance score
-gating and mask accumulation (``get_prediction`` :47-60).  The Mask R-CNN itself is detectron2
-(not vendored, not installed, weights not shipped), so the detector is an injected
-callable returning the three tensors ``DefaultPredictor(img)["instances"]`` would provide."""
+``get_prediction`` = detector + per-instance score gating and mask accumulation (:47-60).  The reference
+delegates the detector to detectron2's ``DefaultPredictor`` (not vendored); here it is
+``peanut_amd.rcnn.MaskRCNN`` on HIP by default, or any injected callable returning the three tensors
+``DefaultPredictor(img)["instances"]`` would provide."""
 from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
@@ -36,16 +36,44 @@ def accumulate_instances(pred_masks: torch.Tensor, pred_classes: torch.Tensor, s
     return out
 
 
-class SemanticPredMaskRCNN():
-    """Same call surface as the reference class: ``get_prediction(img_rgb_uint8[H,W,3], depth=None,
-    goal_cat=None) -> (np.float32 [H,W,n_cats+1], img_bgr)``.  ``detector(img_bgr)`` must return
-    ``(pred_masks [n,H,W], pred_classes [n], scores [n])`` as HIP tensors (what
-    ``DefaultPredictor(img)["instances"]`` holds, segmentation.py:45)."""
+class HipDetector:
+    """``DefaultPredictor(cfg)`` stand-in: ``detector(img_bgr uint8 [H,W,3]) -> (pred_masks, pred_classes,
+    scores)`` computed by ``peanut_amd.rcnn.MaskRCNN`` (HIP front end + ROI stages)."""
 
-    def __init__(self, args, detector: Callable[[np.ndarray], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]],
-                 n_cats: int = 9):
+    def __init__(self, cfg, state_dict, device="cuda:0", precision: str = "fp32"):
+        from .rcnn import MaskRCNN
+        self.device = torch.device(device)
+        self.net = MaskRCNN(cfg, state_dict, device=device, precision=precision)
+
+    def batch(self, imgs_bgr: torch.Tensor):
+        """uint8 [B,H,W,3] device tensor -> list of (pred_masks, pred_classes, scores)."""
+        return [(r["pred_masks"], r["pred_classes"], r["scores"]) for r in self.net.inference(imgs_bgr)]
+
+    def __call__(self, img_bgr):
+        x = torch.from_numpy(np.ascontiguousarray(img_bgr)) if isinstance(img_bgr, np.ndarray) else img_bgr
+        return self.batch(x.to(self.device)[None])[0]
+
+
+class SemanticPredMaskRCNN():
+    """Same call surface as the reference class (segmentation.py:28-62): ``SemanticPredMaskRCNN(args)``,
+    ``get_prediction(img_rgb_uint8[H,W,3], depth=None, goal_cat=None) -> (np.float32 [H,W,n_cats+1], img_bgr)``.
+
+    ``args`` carries ``seg_model_wts`` (detectron2 checkpoint), ``sem_pred_prob_thr`` (also the detector's
+    SCORE_THRESH_TEST, segmentation.py:33), ``goal_thr`` and ``sem_gpu_id``.  A different ``detector`` callable
+    returning ``(pred_masks [n,H,W], pred_classes [n], scores [n])`` HIP tensors may be injected instead
+    (what ``DefaultPredictor(img)["instances"]`` holds, segmentation.py:45)."""
+
+    def __init__(self, args, detector: Optional[Callable[[np.ndarray], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]] = None,
+                 n_cats: Optional[int] = None, rcnn_cfg=None, state_dict=None, precision: str = "fp32"):
         self.args = args
-        self.n_cats = n_cats          # cfg.MODEL.ROI_HEADS.NUM_CLASSES (mask_rcnn_R_101_cat9.yaml:193)
+        if detector is None:
+            from dataclasses import replace
+            from .rcnn_weights import RcnnCfg, load_detectron2_checkpoint
+            cfg = replace(rcnn_cfg or RcnnCfg(), score_thresh_test=float(args.sem_pred_prob_thr))
+            sd = state_dict if state_dict is not None else load_detectron2_checkpoint(args.seg_model_wts)
+            detector = HipDetector(cfg, sd, device=f"cuda:{int(getattr(args, 'sem_gpu_id', 0))}", precision=precision)
+            n_cats = cfg.num_classes if n_cats is None else n_cats
+        self.n_cats = 9 if n_cats is None else n_cats   # cfg.MODEL.ROI_HEADS.NUM_CLASSES (mask_rcnn_R_101_cat9.yaml:193)
         self.predictor = detector
 
     def get_prediction(self, img, depth=None, goal_cat=None):

@@ -42,3 +42,191 @@ def test_preprocess_geometry_of_the_agent_frame():
     plan = m.plan(1, 480, 640)
     assert plan["resized"] == (800, 1067) and plan["padded"] == (800, 1088)
     assert plan["levels"] == [(200, 272), (100, 136), (50, 68), (25, 34), (13, 17)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Proposal / ROI stages.  Each stage is fed the ORACLE's upstream tensors so that a last-ulp difference in
+# one stage cannot flip a threshold/NMS decision in the next; the end-to-end test at the bottom then checks
+# the chain as a whole.
+# ---------------------------------------------------------------------------------------------------------
+def _small_cfg(**kw):
+    from peanut_amd.rcnn_weights import RcnnCfg
+    base = dict(depth=50, min_size=128, max_size=256, rpn_pre_nms_topk=60, rpn_post_nms_topk=40, detections_per_image=10)
+    base.update(kw)
+    return RcnnCfg(**base)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+@pytest.fixture(scope="module")
+def small_net():
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import MaskRCNN
+    from peanut_amd.rcnn_weights import make_seeded_rcnn_state_dict, resized_hw
+    cfg = _small_cfg()
+    sd = make_seeded_rcnn_state_dict(cfg, seed=7)
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (2, 96, 128, 3), generator=g, dtype=torch.uint8)
+    pyr, obj, dl = rcnn_ref.forward_front(sd, img, cfg)
+    return dict(cfg=cfg, sd=sd, img=img, pyr=pyr, obj=obj, dl=dl, hw=resized_hw(96, 128, cfg), net=MaskRCNN(cfg, sd))
+
+
+def test_nms_bit_exact():
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import nms_keep
+    g = torch.Generator().manual_seed(0)
+    for n, ncat in ((1, 1), (63, 1), (64, 3), (65, 1), (777, 4), (3000, 2)):
+        xy = torch.rand((n, 2), generator=g) * 200
+        wh = torch.rand((n, 2), generator=g) * 60 + 1
+        boxes = torch.cat([xy, xy + wh], 1)
+        cats = torch.randint(0, ncat, (n,), generator=g)
+        for thr in (0.5, 0.7):
+            ref = rcnn_ref.nms_sorted(boxes, cats, thr)
+            got = nms_keep(boxes.cuda(), cats.cuda(), thr).cpu()
+            assert torch.equal(ref, got), (n, ncat, thr)
+        got = nms_keep(boxes.cuda(), None, 0.5).cpu()
+        assert torch.equal(rcnn_ref.nms_sorted(boxes, torch.zeros(n, dtype=torch.int64), 0.5), got)
+
+
+def test_roi_align_matches_restatement():
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import assign_levels, roi_align_pyramid
+    g = torch.Generator().manual_seed(3)
+    B, Cc = 2, 32
+    pyr = {f"p{l + 2}": torch.randn((B, Cc, 64 >> l, 80 >> l), generator=g) for l in range(4)}
+    n = 50
+    xy = torch.rand((n, 2), generator=g) * torch.tensor([250.0, 200.0])
+    wh = torch.exp(torch.rand((n, 2), generator=g) * 6.0)          # 1 .. 400 px: hits all four levels
+    rois = torch.cat([torch.randint(0, B, (n, 1), generator=g).float(), xy, xy + wh], 1)
+    rois[0, 1:] = torch.tensor([-20.0, -10.0, 30.0, 500.0])        # sticks out of the map on every side
+    rois[1, 3:] = rois[1, 1:3]                                       # degenerate (zero-area) box
+    rois[2, 1:] = torch.tensor([5.0, 3.0, 610.0, 480.0])           # sqrt(area) >= 448 -> p5
+    lv = assign_levels(rois[:, 1:])
+    assert set(lv.tolist()) == {0, 1, 2, 3}
+    for P in (7, 14):
+        ref = rcnn_ref.roi_pool(pyr, rois, P)                                       # [N,C,P,P]
+        got = roi_align_pyramid([_nhwc(pyr[k]) for k in ("p2", "p3", "p4", "p5")], rois.cuda(), lv.cuda(), P)
+        err = (got.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+        # the large boxes average up to ~20x20 bilinear samples per bin, in a different order than the oracle's loop
+        assert err <= 5e-5, f"P={P}: {err:.3e}"
+
+
+def test_paste_masks_matches_restatement():
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import paste_masks
+    g = torch.Generator().manual_seed(5)
+    n, M, H, W = 9, 28, 60, 84
+    probs = torch.rand((n, M, M), generator=g)
+    xy = torch.rand((n, 2), generator=g) * torch.tensor([60.0, 40.0])
+    boxes = torch.cat([xy, xy + torch.rand((n, 2), generator=g) * 40 + 0.5], 1)
+    boxes[0] = torch.tensor([0.0, 0.0, float(W), float(H)])
+    vals = rcnn_ref.paste_values(probs, boxes, (H, W))
+    ref = vals >= 0.5
+    got = paste_masks(probs.cuda(), boxes.cuda(), (H, W), 0.5).cpu()
+    diff = ref != got
+    assert ((vals - 0.5).abs()[diff] < 1e-6).all(), "mask differs away from the threshold"
+    assert diff.float().mean().item() < 1e-4
+    assert paste_masks(probs[:0].cuda(), boxes[:0].cuda(), (H, W), 0.5).shape == (0, H, W)
+
+
+def test_proposals_from_oracle_logits(small_net):
+    from oracle import rcnn_ref
+    s = small_net
+    ref = rcnn_ref.rpn_proposals(s["obj"], s["dl"], s["hw"], s["cfg"])
+    got = s["net"].proposals([_nhwc(o) for o in s["obj"]], [_nhwc(d) for d in s["dl"]], s["hw"])
+    for (rb, rs), (gb, gs) in zip(ref, got):
+        assert 0 < len(rb) <= s["cfg"].rpn_post_nms_topk
+        assert gb.shape == rb.shape
+        assert torch.equal(gs.cpu(), rs)                     # logits pass through untouched -> same selection
+        assert (gb.cpu() - rb).abs().max().item() <= 1e-3
+
+
+def test_box_branch_and_detections(small_net):
+    import torch.nn.functional as F
+    from oracle import rcnn_ref
+    s = small_net
+    cfg, net = s["cfg"], s["net"]
+    props = rcnn_ref.rpn_proposals(s["obj"], s["dl"], s["hw"], cfg)
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(n)), b], 1) for n, (b, _) in enumerate(props)], 0)
+    ref_sc, ref_dl = rcnn_ref.box_head(s["sd"], rcnn_ref.roi_pool(s["pyr"], rois, cfg.box_pooler_resolution))
+    pyr = [_nhwc(s["pyr"][k]) for k in ("p2", "p3", "p4", "p5")]
+    sc, dl = net.box_branch(pyr, rois.cuda())
+    for name, got, ref in (("cls", sc, ref_sc), ("bbox", dl, ref_dl)):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * (1 + ref.abs().max().item()), f"{name}: {err:.3e}"
+    # detection selection on the oracle's own scores/boxes: identical decisions expected
+    nb = len(props[0][0])
+    boxes = rcnn_ref.apply_deltas(ref_dl[:nb], props[0][0], cfg.roi_bbox_weights)
+    pr = F.softmax(ref_sc[:nb], dim=-1)
+    rb, rs, rc = rcnn_ref.fast_rcnn_inference_single_image(boxes, pr, s["hw"], cfg)
+    gb, gs, gc = net.detections(boxes.cuda(), pr.cuda(), s["hw"])
+    assert len(rb) > 0
+    assert torch.equal(gc.cpu(), rc) and torch.equal(gs.cpu(), rs) and torch.equal(gb.cpu(), rb)
+
+
+def test_mask_branch(small_net):
+    from oracle import rcnn_ref
+    s = small_net
+    cfg, net = s["cfg"], s["net"]
+    g = torch.Generator().manual_seed(2)
+    n = 12
+    xy = torch.rand((n, 2), generator=g) * torch.tensor([100.0, 80.0])
+    boxes = torch.cat([xy, xy + torch.rand((n, 2), generator=g) * 120 + 4], 1)
+    rois = torch.cat([torch.randint(0, 2, (n, 1), generator=g).float(), boxes], 1)
+    cls = torch.randint(0, cfg.num_classes, (n,), generator=g)
+    logits = rcnn_ref.mask_head(s["sd"], rcnn_ref.roi_pool(s["pyr"], rois, cfg.mask_pooler_resolution), cfg)
+    ref = logits[torch.arange(n), cls].sigmoid()
+    got = net.mask_branch([_nhwc(s["pyr"][k]) for k in ("p2", "p3", "p4", "p5")], rois.cuda(), cls.cuda()).cpu()
+    assert got.shape == ref.shape == (n, 28, 28)
+    assert (got - ref).abs().max().item() <= 1e-4
+    assert net.mask_branch([_nhwc(s["pyr"][k]) for k in ("p2", "p3", "p4", "p5")], rois[:0].cuda(), cls[:0].cuda()).shape == (0, 28, 28)
+
+
+def test_inference_end_to_end(small_net):
+    """Whole chain, HIP front end included.  Decisions (top-k, NMS, thresholds) act on values that agree to
+    ~1e-5, so the seeded case is expected to give the same detections; boxes within 0.05 px, masks IoU>=0.98."""
+    from oracle import rcnn_ref
+    s = small_net
+    ref = rcnn_ref.inference(s["sd"], s["img"], s["cfg"])
+    got = s["net"].inference(s["img"].cuda())
+    assert len(got) == len(ref) == 2
+    for r, g in zip(ref, got):
+        assert len(r["scores"]) > 0
+        assert g["pred_classes"].cpu().tolist() == r["pred_classes"].tolist()
+        assert (g["scores"].cpu() - r["scores"]).abs().max().item() <= 1e-4
+        assert (g["pred_boxes"].cpu() - r["pred_boxes"]).abs().max().item() <= 5e-2
+        gm, rm = g["pred_masks"].cpu(), r["pred_masks"]
+        assert gm.shape == rm.shape and gm.dtype == torch.bool
+        inter, union = (gm & rm).sum().item(), (gm | rm).sum().item()
+        assert union == 0 or inter / union >= 0.98
+
+
+def test_semantic_pred_maskrcnn_args_constructor(small_net, tmp_path):
+    """segmentation.py:28-62 call surface: SemanticPredMaskRCNN(args).get_prediction(rgb) with a detectron2-format
+    checkpoint on disk; the result equals the oracle detector + the reference's accumulation loop."""
+    from dataclasses import replace
+    from types import SimpleNamespace
+    import numpy as np
+    from oracle import rcnn_ref
+    from peanut_amd.segmentation import SemanticPredMaskRCNN
+    s = small_net
+    ck = tmp_path / "seg.pth"
+    torch.save({"model": {k: v.numpy() for k, v in s["sd"].items()}, "__author__": "test"}, ck)
+    args = SimpleNamespace(seg_model_wts=str(ck), sem_pred_prob_thr=0.55, goal_thr=0.62, sem_gpu_id=0)
+    m = SemanticPredMaskRCNN(args, rcnn_cfg=s["cfg"])
+    rgb = s["img"][0].numpy()[:, :, ::-1].copy()
+    sem, bgr = m.get_prediction(rgb, goal_cat=5)
+    assert np.array_equal(bgr, s["img"][0].numpy()) and sem.shape == (96, 128, 10) and sem.dtype == np.float32
+    cfg = replace(s["cfg"], score_thresh_test=0.55)
+    r = rcnn_ref.inference(s["sd"], s["img"][:1], cfg)[0]
+    want = np.zeros((96, 128, 10), np.float32)
+    for j in range(len(r["scores"])):                      # the reference's loop, segmentation.py:47-60
+        c, sc = int(r["pred_classes"][j]), float(r["scores"][j])
+        if sc < args.sem_pred_prob_thr or (c == 5 and sc < args.goal_thr):
+            continue
+        want[:, :, c] += r["pred_masks"][j].numpy().astype(np.float32)
+    assert len(r["scores"]) > 0 and want.sum() > 0
+    assert np.abs(sem - want).mean() <= 2e-3 * max(1.0, want.mean())
+    assert (sem != want).mean() < 2e-3
