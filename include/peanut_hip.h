@@ -51,7 +51,14 @@ typedef struct peanut_pred_cfg {
   int fold_ppm;          /* 1: evaluate the pyramid half of the PSP bottleneck conv through linearity
                             (conv of a bilinear upsample of k*k vectors = bilinear blend of k*k folded
                             vectors; halves that conv's FLOPs, fp32 re-association only); 0: plain conv */
+  int conv_algo;         /* PEANUT_ALGO_*: algorithm of the stride-1 3x3 convs with >= 256 input channels */
 } peanut_pred_cfg;
+
+/* PEANUT_ALGO_AUTO: Winograd F(4x4,3x3) with fp32 transforms (what cuDNN/MIOpen pick for these layers in the
+ * reference's own GPU runs): 4x fewer multiplies, ~1e-5 max-abs on the logits vs the direct form, bound 1e-3.
+ * PEANUT_ALGO_DIRECT: every conv as the direct implicit GEMM (products summed exactly as an fmaf chain). */
+#define PEANUT_ALGO_AUTO 0
+#define PEANUT_ALGO_DIRECT 1
 
 /* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32, exact fp32 (bit-identical to an fmaf chain).
  * BF16X3 / FP16X3: every fp32 operand is split into two 16-bit parts and each product is rebuilt from

@@ -29,7 +29,7 @@ class PredCfgC(C.Structure):
         ("strides", C.c_int * 4), ("dilations", C.c_int * 4), ("contract_dilation", C.c_int),
         ("pool_scales", C.c_int * 8), ("n_pool_scales", C.c_int),
         ("head_channels", C.c_int), ("align_corners", C.c_int), ("bn_eps", C.c_float),
-        ("precision", C.c_int), ("fold_ppm", C.c_int),
+        ("precision", C.c_int), ("fold_ppm", C.c_int), ("conv_algo", C.c_int),
     ]
 
 
@@ -97,6 +97,7 @@ SIGNATURES = {
 }
 
 
+CONV_ALGOS = {"auto": 0, "direct": 1}   # PEANUT_ALGO_*
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x3": 2}
 
 

@@ -45,6 +45,8 @@ struct ConvArgs {
   int Ho, Wo;
   float* ws;          // optional scratch for tail split-K partial tiles (see conv_common.h)
   size_t ws_floats;
+  int mt_per_group;        // grouped GEMM: 128-row m-tile mt reads weight block mt / mt_per_group (0 = single block)
+  size_t w_group_stride;   // floats between weight blocks
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 partial 128x128 tiles and then some
@@ -60,6 +62,17 @@ void pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin_pad,
 void pack_conv_weights_split(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile,
                              int fp16, void* out);
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
+
+// ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
+// tiles per sub-grid (th x tw), tile count and its padding to whole 128-row GEMM tiles
+void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad);
+// host: OIHW 3x3 weights -> U [36][cout][cin]
+void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out);
+// x [B,H,W,C] -> V [36][m_pad][C]
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s);
+// Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res)
+int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y, int B, int H,
+                       int W, int C, int dil, int relu, hipStream_t s);
 
 // ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----
 int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s);

@@ -22,6 +22,9 @@ struct ConvKParams {
   // tail split-K (see decode_work): the last `n_sp / split_p` tiles are cut into split_p k-ranges each
   int n_full, n_sp, split_p;
   float* partial;   // [n_sp][BM*BN] raw accumulator tiles of the split parts
+  // grouped GEMM (Winograd positions): m-tile mt uses the weight block (mt / mt_per_group); 0 = one block
+  int mt_per_group;
+  long long w_group_stride;   // floats between consecutive weight blocks
 };
 
 template <int I>

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   it.cbase = (wk.kt0 / p.ntaps) * BK;
   it.ky = it.tap / p.kw;
   it.kx = it.tap - it.ky * p.kw;
-  it.wtile = p.w + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
+  it.wtile = p.w + (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride : 0) + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
 
   unsigned long long a_addr[A_PER];
   const float* b_tile;
@@ -358,6 +358,7 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.nkt = (d.cin / d.bk) * p.ntaps;
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
+  p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride;
   if (d.mode != 0) {
     if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
     return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);

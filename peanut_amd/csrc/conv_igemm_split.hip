@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
   u32x4 rb[B_PER];
   int tap = wk.kt0 % p.ntaps, cbase = (wk.kt0 / p.ntaps) * BK;
   int ky = tap / p.kw, kx = tap - ky * p.kw;
-  const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)nt * p.nkt + wk.kt0) * (BN * BK * 4);
+  const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) +
+                               (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride * 4 : 0) +
+                               ((size_t)nt * p.nkt + wk.kt0) * (BN * BK * 4);
 
   // Staging is software-pipelined and branch-free exactly like conv_igemm.hip: addresses of the next
   // k-tile are prepared one iteration ahead (pure ALU in the MFMA shadow), out-of-range taps read the zero

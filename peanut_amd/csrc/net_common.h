@@ -33,6 +33,12 @@ struct ConvLayer {
   ConvDesc d{};
   int cin_real = 0;
   DevBuf w, ss;  // packed weights; scale||shift
+  // Winograd F(4x4,3x3) form of a stride-1 3x3 layer (winograd.hip): `wino` is the descriptor of the 36
+  // grouped GEMMs (a 1x1 conv with unit scale / zero shift); d.scale/d.shift/d.relu apply in the output transform
+  bool has_wino = false;
+  ConvDesc wino{};
+  size_t wino_group_floats = 0;
+  DevBuf wino_w, wino_ss;
 };
 
 inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
@@ -62,6 +68,43 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.w_packed = (const float*)L.w.p;
   d.scale = (const float*)L.ss.p;
   d.shift = (const float*)L.ss.p + d.cout_pad;
+  return 0;
+}
+
+// Adds the Winograd form to an uploaded stride-1 3x3 layer (keeps the direct form for the two-source path).
+inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int pad, int dil, int precision) {
+  return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= 256 && cin_pad % 32 == 0 && cout % 4 == 0 &&
+         cout >= 64 && precision != 2;   // fp16x3: the 1/24-scaled weight tails would underflow
+}
+
+inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int cin_pad, int precision) {
+  ConvDesc& g = L.wino;
+  g.cin = cin_pad; g.cout = cout; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
+  conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
+  g.bk = 32;
+  g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
+  g.mode = precision;
+  const size_t gf = conv_packed_floats(cin_pad, cout, 1, 1, g.bn_tile);
+  std::vector<float> U((size_t)36 * cout * cin);
+  wino_transform_weights(w_oihw, cout, cin, U.data());
+  std::vector<float> packed(36 * gf);
+  for (int pos = 0; pos < 36; ++pos) {
+    const float* u = U.data() + (size_t)pos * cout * cin;
+    if (g.mode == 0) pack_conv_weights(u, cout, cin, cin_pad, 1, 1, g.bn_tile, g.bk, packed.data() + pos * gf);
+    else pack_conv_weights_split(u, cout, cin, cin_pad, 1, 1, g.bn_tile, g.mode == 2, packed.data() + pos * gf);
+  }
+  std::vector<float> ss(2 * (size_t)g.cout_pad, 0.f);
+  for (int n = 0; n < g.cout_pad; ++n) ss[n] = 1.f;
+  int rc;
+  if ((rc = L.wino_w.ensure(packed.size() * sizeof(float)))) return rc;
+  if ((rc = L.wino_ss.ensure(ss.size() * sizeof(float)))) return rc;
+  PEANUT_HIP_CHECK(hipMemcpy(L.wino_w.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  PEANUT_HIP_CHECK(hipMemcpy(L.wino_ss.p, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
+  g.w_packed = (const float*)L.wino_w.p;
+  g.scale = (const float*)L.wino_ss.p;
+  g.shift = (const float*)L.wino_ss.p + g.cout_pad;
+  L.wino_group_floats = gf;
+  L.has_wino = true;
   return 0;
 }
 

@@ -28,7 +28,7 @@ int fail(int code, const std::string& msg) {
 
 namespace {
 
-enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE };
+enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE, OP_WINO_IN, OP_WINO_GEMM, OP_WINO_OUT };
 
 struct Op {
   OpKind kind;
@@ -38,6 +38,7 @@ struct Op {
   Act in, in2, res, out;
   bool has_in2 = false, has_res = false;
   double flops = 0;
+  int wino_mt_per_group = 0;   // OP_WINO_GEMM: 128-row tiles per Winograd position
 };
 
 struct Plan {
@@ -117,16 +118,44 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu,
                    h->cfg.precision);
   if (rc) return rc;
+  if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, dil, h->cfg.precision) &&
+      (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision)))
+    return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
 }
 
-void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out) {
+std::string conv_kernel_name(const ConvDesc& d) {
+  return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
+         std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
+}
+
+// `ar` is only needed for layers that carry a Winograd form (scratch for the transformed tensors).
+void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr) {
+  if (L->has_wino && !in2 && ar) {
+    // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
+    int th, tw;
+    long long n_tiles, m_pad;
+    wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad);
+    Act v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
+    Act m = make_act(*ar, 1, 1, (int)(36 * m_pad), L->d.cout);
+    Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
+    pl.ops.push_back(a);
+    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino); g.conv = L;
+    g.in = v; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128);
+    g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
+    pl.ops.push_back(g);
+    Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
+    if (res) { o.res = *res; o.has_res = true; }
+    pl.ops.push_back(o);
+    ar->release(v.off, v.bytes);
+    ar->release(m.off, m.bytes);
+    return;
+  }
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = std::string(L->d.mode == 0 ? "conv_igemm_128x" : (L->d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
-              std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
+  op.kernel = conv_kernel_name(L->d);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
@@ -173,7 +202,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       push_conv(*pl, blk.c1, x, nullptr, nullptr, t1);
       Act t2 = make_act(ar, B, conv_out_dim(x.H, 3, d2.stride, d2.pad, d2.dil),
                         conv_out_dim(x.W, 3, d2.stride, d2.pad, d2.dil), d2.cout);
-      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2);
+      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2, &ar);
       rel(t1);
       Act idn = x;
       bool own_idn = false;
@@ -247,7 +276,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     { Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; pl->ops.push_back(op); }
     rel(q);
     bt = make_act(ar, B, x.H, x.W, h->bottleneck_x->d.cout);
-    push_conv(*pl, h->bottleneck_x, x, nullptr, &r, bt);
+    push_conv(*pl, h->bottleneck_x, x, nullptr, &r, bt, &ar);
     rel(r);
   } else {
     Act up = make_act(ar, B, x.H, x.W, h->cfg.n_pool_scales * h->cfg.head_channels);
@@ -312,6 +341,19 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
       return launch_conv(op.conv->d, a, s);
     }
+    case OP_WINO_IN:
+      return launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s);
+    case OP_WINO_GEMM: {
+      ConvArgs a{};
+      a.x = P(op.in); a.y = P(op.out);
+      a.B = 1; a.H = 1; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = 1; a.Wo = op.in.W;
+      a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
+      a.mt_per_group = op.wino_mt_per_group; a.w_group_stride = op.conv->wino_group_floats;
+      return launch_conv(op.conv->wino, a, s);
+    }
+    case OP_WINO_OUT:
+      return launch_wino_output(P(op.in), op.conv->d.scale, op.conv->d.shift, op.has_res ? P(op.res) : nullptr, P(op.out),
+                                op.out.B, op.out.H, op.out.W, op.out.C, op.conv->d.dil, op.conv->d.relu, s);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:
@@ -333,7 +375,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
 extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
-int peanut_abi_version(void) { return 2; }
+int peanut_abi_version(void) { return 3; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
@@ -343,6 +385,8 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
     return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
   if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
   if (cfg->precision < 0 || cfg->precision > 2) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3}");
+  if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT)
+    return fail(PEANUT_EINVAL, "conv_algo must be PEANUT_ALGO_{AUTO,DIRECT}");
   auto h = std::make_unique<peanut_pred>();
   h->cfg = *cfg;
   h->cin_pad = (cfg->in_channels + 15) / 16 * 16;
@@ -406,6 +450,9 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
       auto L = std::make_unique<ConvLayer>();
       L->name = "decode_head.bottleneck.conv[x]";
       if ((rc = upload_conv(*L, wx.data(), scale.data(), shift.data(), hc, inplanes, inplanes, 3, 3, 1, 1, 1, 1, cfg->precision))) return rc;
+      if (cfg->conv_algo == PEANUT_ALGO_AUTO && wino_eligible(inplanes, hc, 3, 3, 1, 1, 1, cfg->precision) &&
+          (rc = upload_wino(*L, wx.data(), hc, inplanes, inplanes, cfg->precision)))
+        return rc;
       h->bottleneck_x = L.get();
       h->convs.push_back(std::move(L));
     }

@@ -1,0 +1,218 @@
+// Winograd F(4x4, 3x3) for the stride-1 3x3 convolutions (fp32 transforms around the MFMA GEMM kernel).
+//
+//   Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A        (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf)
+//
+// 36 multiplies per 4x4 output tile and channel pair instead of 144: the contraction over input channels
+// becomes 36 independent GEMMs [tiles x Cin] x [Cin x Cout], which run on conv_igemm's MFMA kernel as one
+// launch (a 1x1 "conv" over 36*m_pad rows whose weight block is selected by the row group).  The two
+// transforms here are HBM-bound streaming kernels: NHWC, one thread per (tile, 4-channel group), every
+// access a 16-byte piece of a contiguous channel run.
+//
+// Dilation d is handled by decomposition: output pixels with equal (y mod d, x mod d) form d*d independent
+// undilated problems on sub-sampled grids (padding 1 in sub-grid units = d in pixels).  Tiles are indexed
+// t = (((b*d + oy)*d + ox)*th + ty)*tw + tx with a uniform th x tw per sub-grid; tiles or tile parts that
+// fall outside the image read zeros and are not written back.
+//
+// Replaces (reference): the 3x3 conv2 of every stride-1 Bottleneck (prediction/mmseg/models/backbones/
+// resnet.py:267-307, dilations 1/2/4) and the PSP bottleneck conv (models/decode_heads/psp_head.py:86-93).
+// Numerics: fp32 throughout; measured 1e-5 max-abs on the seeded PSPNet logits (|logit| <= 6.4) against the
+// reference golden vectors, contract 1e-3.
+#include "common.h"
+#include "conv_common.h"
+
+namespace peanut {
+
+namespace {
+
+// t = B^T d for one 6-vector
+__device__ __forceinline__ void bt6(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4,
+                                    const f32x4 d5, f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3, f32x4& t4, f32x4& t5) {
+  const f32x4 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+  t0 = 4.f * d0 - 5.f * d2 + d4;
+  t1 = a + b;
+  t2 = a - b;
+  t3 = c + e;
+  t4 = c - e;
+  t5 = 4.f * d1 - 5.f * d3 + d5;
+}
+
+// y = A^T m for one 6-vector
+__device__ __forceinline__ void at6(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4,
+                                    const f32x4 m5, f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
+  const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+  y0 = m0 + s12 + s34;
+  y1 = d12 + 2.f * d34;
+  y2 = s12 + 4.f * s34;
+  y3 = d12 + 8.f * d34 + m5;
+}
+
+struct WinoGeom {
+  int B, H, W, C;      // C = channels of the tensor this kernel touches (Cin for input, Cout for output)
+  int d, th, tw;
+  long long n_tiles, m_pad;
+};
+
+__device__ __forceinline__ void decode_tile(const WinoGeom& g, long long t, int& b, int& oy, int& ox, int& ty, int& tx) {
+  tx = (int)(t % g.tw); t /= g.tw;
+  ty = (int)(t % g.th); t /= g.th;
+  ox = (int)(t % g.d); t /= g.d;
+  oy = (int)(t % g.d);
+  b = (int)(t / g.d);
+}
+
+// V[(i*6+j)][tile][c] = (B^T d B)[i][j]
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, const WinoGeom g) {
+  const int groups = g.C >> 2;
+  const long long total = g.n_tiles * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % groups);
+    const long long tile = idx / groups;
+    int b, oy, ox, ty, tx;
+    decode_tile(g, tile, b, oy, ox, ty, tx);
+    const int r0 = oy + g.d * (4 * ty - 1), c0 = ox + g.d * (4 * tx - 1);
+    const float* xb = x + (size_t)b * g.H * g.W * g.C + cg * 4;
+    f32x4 p[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int r = r0 + i * g.d;
+      const bool rok = (unsigned)r < (unsigned)g.H;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int c = c0 + j * g.d;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rok && (unsigned)c < (unsigned)g.W) v = *reinterpret_cast<const f32x4*>(xb + ((size_t)r * g.W + c) * g.C);
+        p[i][j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j)   // columns: p <- B^T p
+      bt6(p[0][j], p[1][j], p[2][j], p[3][j], p[4][j], p[5][j], p[0][j], p[1][j], p[2][j], p[3][j], p[4][j], p[5][j]);
+    float* vb = V + (size_t)tile * g.C + cg * 4;
+    const size_t pos_stride = (size_t)g.m_pad * g.C;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {  // rows: (p B)[i][:]
+      f32x4 t0, t1, t2, t3, t4, t5;
+      bt6(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], t0, t1, t2, t3, t4, t5);
+      float* o = vb + (size_t)(i * 6) * pos_stride;
+      *reinterpret_cast<f32x4*>(o) = t0;
+      *reinterpret_cast<f32x4*>(o + pos_stride) = t1;
+      *reinterpret_cast<f32x4*>(o + 2 * pos_stride) = t2;
+      *reinterpret_cast<f32x4*>(o + 3 * pos_stride) = t3;
+      *reinterpret_cast<f32x4*>(o + 4 * pos_stride) = t4;
+      *reinterpret_cast<f32x4*>(o + 5 * pos_stride) = t5;
+    }
+  }
+}
+
+// y[pixel][n] = relu(scale[n] * (A^T M A)[a][b] + shift[n] + res[pixel][n])
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ res,
+                                                          float* __restrict__ y, const WinoGeom g, int relu) {
+  const int groups = g.C >> 2;
+  const long long total = g.n_tiles * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ng = (int)(idx % groups);
+    const long long tile = idx / groups;
+    int b, oy, ox, ty, tx;
+    decode_tile(g, tile, b, oy, ox, ty, tx);
+    const int r0 = oy + g.d * 4 * ty, c0 = ox + g.d * 4 * tx;
+    if (r0 >= g.H || c0 >= g.W) continue;   // tile entirely outside its sub-grid
+    const float* mb = Mb + (size_t)tile * g.C + ng * 4;
+    const size_t pos_stride = (size_t)g.m_pad * g.C;
+    f32x4 q[6][4];   // M A  (rows i, output columns)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float* s = mb + (size_t)(i * 6) * pos_stride;
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(s);
+      const f32x4 m1 = *reinterpret_cast<const f32x4*>(s + pos_stride);
+      const f32x4 m2 = *reinterpret_cast<const f32x4*>(s + 2 * pos_stride);
+      const f32x4 m3 = *reinterpret_cast<const f32x4*>(s + 3 * pos_stride);
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(s + 4 * pos_stride);
+      const f32x4 m5 = *reinterpret_cast<const f32x4*>(s + 5 * pos_stride);
+      at6(m0, m1, m2, m3, m4, m5, q[i][0], q[i][1], q[i][2], q[i][3]);
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ng * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ng * 4);
+    const size_t img = (size_t)b * g.H * g.W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 o0, o1, o2, o3;
+      at6(q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], o0, o1, o2, o3);
+      const int c = c0 + j * g.d;
+      if (c >= g.W) continue;
+      const f32x4 o[4] = {o0, o1, o2, o3};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = r0 + a * g.d;
+        if (r >= g.H) continue;
+        const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 4;
+        f32x4 v = o[a] * sc + sh;
+        if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(y + off) = v;
+      }
+    }
+  }
+}
+
+int grid_for(long long total) {
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256LL * 64) blocks = 256LL * 64;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad) {
+  const int hs = (H + dil - 1) / dil, wsub = (W + dil - 1) / dil;   // largest sub-grid
+  *th = (hs + 3) / 4;
+  *tw = (wsub + 3) / 4;
+  *n_tiles = (long long)B * dil * dil * *th * *tw;
+  *m_pad = (*n_tiles + 127) / 128 * 128;                             // whole 128-row GEMM tiles per position
+}
+
+// U[(i*6+l)][n][c] = (G g G^T)[i][l], accumulated in double and rounded once
+void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out) {
+  static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const size_t plane = (size_t)cout * cin;
+  for (int n = 0; n < cout; ++n)
+    for (int c = 0; c < cin; ++c) {
+      const float* g = w_oihw + ((size_t)n * cin + c) * 9;
+      double t[6][3];
+      for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < 3; ++k) t[i][k] = G[i][0] * g[0 * 3 + k] + G[i][1] * g[1 * 3 + k] + G[i][2] * g[2 * 3 + k];
+      for (int i = 0; i < 6; ++i)
+        for (int l = 0; l < 6; ++l)
+          out[(size_t)(i * 6 + l) * plane + (size_t)n * cin + c] =
+              (float)(t[i][0] * G[l][0] + t[i][1] * G[l][1] + t[i][2] * G[l][2]);
+    }
+}
+
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s) {
+  if (C % 4) return fail(-2, "wino_input: channels must be a multiple of 4");
+  WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
+  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad);
+  const long long total = g.n_tiles * (C / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-3, std::string("wino_input launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y, int B, int H,
+                       int W, int C, int dil, int relu, hipStream_t s) {
+  if (C % 4) return fail(-2, "wino_output: channels must be a multiple of 4");
+  WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
+  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad);
+  const long long total = g.n_tiles * (C / 4);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-3, std::string("wino_output launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace peanut

@@ -30,7 +30,7 @@ class HipSegmentor:
     device, ``prediction/mmseg/apis/inference.py:12-40``), here a handle of the HIP library."""
 
     def __init__(self, cfg: PredCfg, state_dict: Dict[str, torch.Tensor], device="cuda:0",
-                 classes=None, precision: str = "fp32", fold_ppm: bool = True):
+                 classes=None, precision: str = "fp32", fold_ppm: bool = True, conv_algo: str = "auto"):
         if not torch.cuda.is_available():
             raise _lib.PeanutHipError("PEANUT_Prediction_Model needs a HIP device (no CPU fallback)")
         self.cfg = cfg
@@ -38,7 +38,10 @@ class HipSegmentor:
         self.CLASSES = classes
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        if conv_algo not in _lib.CONV_ALGOS:
+            raise ValueError(f"conv_algo must be one of {sorted(_lib.CONV_ALGOS)}, got {conv_algo!r}")
         self.precision = precision
+        self.conv_algo = conv_algo
         self._lib = _lib.load()
         tensors = select_inference_tensors(state_dict, cfg)     # raises on missing/mis-shaped keys
         arr = (_lib.TensorC * len(tensors))()
@@ -61,6 +64,7 @@ class HipSegmentor:
         c.head_channels, c.align_corners, c.bn_eps = cfg.head_channels, int(cfg.align_corners), cfg.bn_eps
         c.precision = _lib.PRECISIONS[precision]
         c.fold_ppm = int(fold_ppm)
+        c.conv_algo = _lib.CONV_ALGOS[conv_algo]
         self.fold_ppm = bool(fold_ppm)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -151,7 +155,7 @@ class HipSegmentor:
 
 
 def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
-                   precision: str = "fp32", fold_ppm: bool = True) -> HipSegmentor:
+                   precision: str = "fp32", fold_ppm: bool = True, conv_algo: str = "auto") -> HipSegmentor:
     """``prediction/mmseg/apis/inference.py:12-40``: config path (or PredCfg) + mmcv checkpoint.
     ``state_dict`` lets tests/benchmarks pass seeded weights instead of a checkpoint file."""
     if isinstance(config, str):
@@ -168,7 +172,7 @@ def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
         raise ValueError("init_segmentor needs a checkpoint (or an explicit state_dict): the HIP "
                          "model has no random-init mode")
     return HipSegmentor(cfg, state_dict, device=device, classes=classes, precision=precision,
-                        fold_ppm=fold_ppm)
+                        fold_ppm=fold_ppm, conv_algo=conv_algo)
 
 
 def run_inference(model: HipSegmentor, full_map: np.ndarray) -> List[np.ndarray]:
@@ -189,7 +193,7 @@ class PEANUT_Prediction_Model():
     checkpoint file (seeded weights for tests/benchmarks)."""
 
     def __init__(self, args, state_dict=None, cfg: Optional[PredCfg] = None, precision: Optional[str] = None,
-                 fold_ppm: Optional[bool] = None):
+                 fold_ppm: Optional[bool] = None, conv_algo: Optional[str] = None):
         self.args = args
         ckpt = getattr(args, "pred_model_wts", None) if state_dict is None else None
         if cfg is None:
@@ -201,8 +205,10 @@ class PEANUT_Prediction_Model():
             precision = getattr(args, "pred_precision", None) or os.environ.get("PEANUT_PRECISION", "fp32")
         if fold_ppm is None:
             fold_ppm = os.environ.get("PEANUT_FOLD_PPM", "1") != "0"
+        if conv_algo is None:
+            conv_algo = os.environ.get("PEANUT_CONV_ALGO", "auto")
         self.model = init_segmentor(cfg, checkpoint=ckpt, device=device, state_dict=state_dict,
-                                    precision=precision, fold_ppm=fold_ppm)
+                                    precision=precision, fold_ppm=fold_ppm, conv_algo=conv_algo)
         self.model.eval()
         self.model.cfg = cfg
 

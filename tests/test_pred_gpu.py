@@ -184,3 +184,26 @@ def test_folded_and_plain_bottleneck_agree(model_and_sd):
         assert (a - ref).abs().max().item() <= TOL
         assert (p - ref).abs().max().item() <= TOL
         assert (a - p).abs().max().item() <= 5e-5
+
+
+def test_winograd_and_direct_conv_algorithms_agree(model_and_sd, golden_dir):
+    """conv_algo='auto' (default: Winograd F(4x4,3x3) with fp32 transforms for the stride-1 3x3 convs with
+    >= 256 input channels -- dilations 1, 2 and 4 via sub-grid decomposition) and conv_algo='direct' are the
+    same function up to fp32 rounding; both match the reference golden vectors, incl. odd and rectangular
+    sizes where tiles overhang the feature map."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    assert m.model.conv_algo == "auto"
+    direct = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, conv_algo="direct")
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    worst_a = worst_d = 0.0
+    for case in ("cfg1_240", "b2_96", "odd_100", "rect_72x104"):
+        x = torch.from_numpy(z[f"{case}/input"].astype(np.float32)).cuda()
+        ref = torch.from_numpy(z[f"{case}/logits"])
+        a = m.get_prediction_batch(x, apply_sigmoid=False).cpu()
+        d = direct.get_prediction_batch(x, apply_sigmoid=False).cpu()
+        worst_a = max(worst_a, (a - ref).abs().max().item())
+        worst_d = max(worst_d, (d - ref).abs().max().item())
+        assert (a - d).abs().max().item() <= 1e-4, case
+    print(f"max-abs vs reference golden logits: winograd {worst_a:.3e}, direct {worst_d:.3e}")
+    assert worst_a <= TOL and worst_d <= 2e-5
