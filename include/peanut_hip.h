@@ -182,6 +182,7 @@ typedef struct peanut_rcnn_cfg {
   float pixel_mean[3], pixel_std[3]; /* BGR (103.53, 116.28, 123.675), (1, 1, 1) */
   float bn_eps;            /* FrozenBatchNorm2d eps 1e-5 */
   int precision;           /* PEANUT_PREC_* */
+  int conv_algo;           /* PEANUT_ALGO_* (Winograd for the stride-1 3x3 convs with >= 256 input channels) */
 } peanut_rcnn_cfg;
 
 typedef struct peanut_rcnn peanut_rcnn_t;
@@ -251,10 +252,11 @@ typedef struct peanut_conv peanut_conv_t;
 /* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
  * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
  * which the packer guarantees).  precision = PEANUT_PREC_* (split modes need cin_pad % 32 == 0,
- * otherwise the layer silently stays fp32). */
+ * otherwise the layer silently stays fp32); conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
+ * >= 256 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */
 int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
                        const float* shift_host, int cout, int cin, int cin_pad, int kh, int kw, int stride,
-                       int pad, int dil, int relu, int precision);
+                       int pad, int dil, int relu, int precision, int conv_algo);
 void peanut_conv_destroy(peanut_conv_t* c);
 /* x_dev [B,H,W,cin_pad] (or split x_dev [..,c1] ++ x2_dev [..,cin_pad-c1] when x2_dev != NULL),
  * res_dev optional [B,Ho,Wo,cout], y_dev [B,Ho,Wo,cout]. */

@@ -48,7 +48,7 @@ class RcnnCfgC(C.Structure):
         ("depth", C.c_int), ("stem_out", C.c_int), ("res2_out", C.c_int), ("stride_in_1x1", C.c_int),
         ("fpn_out", C.c_int), ("num_anchors", C.c_int), ("min_size", C.c_int), ("max_size", C.c_int),
         ("size_divisibility", C.c_int), ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3),
-        ("bn_eps", C.c_float), ("precision", C.c_int),
+        ("bn_eps", C.c_float), ("precision", C.c_int), ("conv_algo", C.c_int),
     ]
 
 
@@ -91,7 +91,7 @@ SIGNATURES = {
     "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_int, _P, _P]),
-    "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 10),
+    "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 11),
     "peanut_conv_destroy": (None, [_P]),
     "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
 }

@@ -108,6 +108,33 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   return 0;
 }
 
+// floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]
+inline void wino_scratch_floats(const ConvLayer& L, int B, int H, int W, size_t* v, size_t* m) {
+  int th, tw;
+  long long n_tiles, m_pad;
+  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad);
+  *v = (size_t)36 * m_pad * L.d.cin;
+  *m = (size_t)36 * m_pad * L.d.cout;
+}
+
+// One conv layer, as Winograd (input transform -> grouped GEMM -> output transform) when the layer carries
+// that form and scratch is supplied, else as the direct kernel.
+inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_v, float* wino_m, hipStream_t s) {
+  if (!(L.has_wino && !a.x2 && wino_v && wino_m)) return launch_conv(L.d, a, s);
+  int th, tw, rc;
+  long long n_tiles, m_pad;
+  wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad);
+  if (36 * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
+  if ((rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s))) return rc;
+  ConvArgs g{};
+  g.x = wino_v; g.y = wino_m;
+  g.B = 1; g.H = 1; g.W = (int)(36 * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
+  g.ws = a.ws; g.ws_floats = a.ws_floats;
+  g.mt_per_group = (int)(m_pad / 128); g.w_group_stride = L.wino_group_floats;
+  if ((rc = launch_conv(L.wino, g, s))) return rc;
+  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s);
+}
+
 // ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----
 struct Arena {
   size_t top = 0;

@@ -58,6 +58,7 @@ using namespace peanut;
 struct peanut_conv {
   ConvLayer L;
   DevBuf ws;   // tail split-K scratch, allocated on first forward
+  DevBuf wino_v, wino_m;   // Winograd scratch, grown on demand
 };
 
 struct peanut_pred {
@@ -587,15 +588,19 @@ int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names,
 
 // ---- operator-level conv ----
 int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, const float* shift, int cout, int cin,
-                       int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision) {
+                       int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision, int conv_algo) {
   if (!out || !w) return fail(PEANUT_EINVAL, "peanut_conv_create: null argument");
   if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
   if (precision < 0 || precision > 2) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
   auto c = std::make_unique<peanut_conv>();
   c->L.name = "conv";
+  if (conv_algo != PEANUT_ALGO_AUTO && conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "peanut_conv_create: bad conv_algo");
   int rc = upload_conv(c->L, w, scale, shift, cout, cin, cin_pad, kh, kw, stride, pad, dil, relu, precision);
   if (rc) return rc;
+  if (conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, kh, kw, stride, pad, dil, precision) &&
+      (rc = upload_wino(c->L, w, cout, cin, cin_pad, precision)))
+    return rc;
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = c.release();
   return 0;
@@ -616,7 +621,15 @@ int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c
   if (a.Ho < 1 || a.Wo < 1) return fail(PEANUT_EINVAL, "peanut_conv_forward: empty output");
   if (int rc = c->ws.ensure(kSplitKScratchFloats * sizeof(float))) return rc;
   a.ws = (float*)c->ws.p; a.ws_floats = kSplitKScratchFloats;
-  return launch_conv(d, a, (hipStream_t)stream);
+  if (c->L.has_wino && !x2) {
+    size_t vf, mf;
+    wino_scratch_floats(c->L, B, H, W, &vf, &mf);
+    // growing a scratch buffer frees the old one: make sure no earlier launch still uses it
+    if (vf * sizeof(float) > c->wino_v.bytes || mf * sizeof(float) > c->wino_m.bytes) PEANUT_HIP_CHECK(hipDeviceSynchronize());
+    if (int rc = c->wino_v.ensure(vf * sizeof(float))) return rc;
+    if (int rc = c->wino_m.ensure(mf * sizeof(float))) return rc;
+  }
+  return launch_conv_layer(c->L, a, (float*)c->wino_v.p, (float*)c->wino_m.p, (hipStream_t)stream);
 }
 
 }  // extern "C"

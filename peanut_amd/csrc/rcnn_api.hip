@@ -111,7 +111,8 @@ struct ROp {
   std::string name, kernel;
   const ConvLayer* conv = nullptr;
   Act in, res, out;
-  bool has_res = false;
+  Act wino_v, wino_m;         // scratch of the Winograd form (R_CONV of a layer that carries one)
+  bool has_res = false, has_wino = false;
   double flops = 0;
   float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
   int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
@@ -164,6 +165,9 @@ int add_rconv(peanut_rcnn* h, const TensorMap& tm, const std::string& name, int 
   if ((rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, 1, relu,
                         h->cfg.precision)))
     return rc;
+  if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, 1, h->cfg.precision) &&
+      (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision)))
+    return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
@@ -184,7 +188,7 @@ void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
   *nw = (int)(neww + 0.5);
 }
 
-void push_rconv(RPlan& pl, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
+void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
   ROp op;
   op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
   op.kernel = std::string(L->d.mode == 0 ? "conv_igemm_128x" : (L->d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
@@ -192,6 +196,15 @@ void push_rconv(RPlan& pl, const ConvLayer* L, const Act& in, const Act* res, co
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
   op.ext_slot = ext_slot;
+  if (L->has_wino) {
+    size_t vf, mf;
+    wino_scratch_floats(*L, in.B, in.H, in.W, &vf, &mf);
+    op.wino_v.bytes = vf * sizeof(float); op.wino_v.off = ar.alloc(op.wino_v.bytes);
+    op.wino_m.bytes = mf * sizeof(float); op.wino_m.off = ar.alloc(op.wino_m.bytes);
+    op.has_wino = true;
+    ar.release(op.wino_v.off, op.wino_v.bytes);
+    ar.release(op.wino_m.off, op.wino_m.bytes);
+  }
   pl.ops.push_back(op);
 }
 
@@ -216,7 +229,7 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   { ROp op; op.kind = R_PREPROCESS; op.name = "preprocess"; op.kernel = "rcnn_preprocess"; op.out = x; pl->ops.push_back(op); }
   // BasicStem
   Act s = conv_out_act(ar, h->stem, x);
-  push_rconv(*pl, h->stem, x, nullptr, s);
+  push_rconv(*pl, ar, h->stem, x, nullptr, s);
   rel(x);
   Act cur = make_act(ar, B, conv_out_dim(s.H, 3, 2, 1, 1), conv_out_dim(s.W, 3, 2, 1, 1), s.C);
   { ROp op; op.kind = R_MAXPOOL; op.name = "stem.maxpool"; op.kernel = "maxpool"; op.in = s; op.out = cur; pl->ops.push_back(op); }
@@ -229,16 +242,16 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
       bool own = false;
       if (blk.shortcut) {
         idn = conv_out_act(ar, blk.shortcut, cur);
-        push_rconv(*pl, blk.shortcut, cur, nullptr, idn);
+        push_rconv(*pl, ar, blk.shortcut, cur, nullptr, idn);
         own = true;
       }
       Act t1 = conv_out_act(ar, blk.c1, cur);
-      push_rconv(*pl, blk.c1, cur, nullptr, t1);
+      push_rconv(*pl, ar, blk.c1, cur, nullptr, t1);
       Act t2 = conv_out_act(ar, blk.c2, t1);
-      push_rconv(*pl, blk.c2, t1, nullptr, t2);
+      push_rconv(*pl, ar, blk.c2, t1, nullptr, t2);
       rel(t1);
       Act y = conv_out_act(ar, blk.c3, t2);
-      push_rconv(*pl, blk.c3, t2, &idn, y);        // + shortcut, ReLU fused
+      push_rconv(*pl, ar, blk.c3, t2, &idn, y);        // + shortcut, ReLU fused
       rel(t2);
       if (own) rel(idn);
       // the block input dies here unless it is a stage output that the FPN laterals still need
@@ -254,7 +267,7 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   Act p[5];
   for (int lvl = 3; lvl >= 0; --lvl) {
     Act lat = conv_out_act(ar, h->lateral[lvl], feats[lvl]);
-    push_rconv(*pl, h->lateral[lvl], feats[lvl], nullptr, lat);
+    push_rconv(*pl, ar, h->lateral[lvl], feats[lvl], nullptr, lat);
     rel(feats[lvl]);
     if (lvl < 3) {
       ROp op; op.kind = R_ADD_UP; op.name = "fpn_topdown" + std::to_string(lvl + 2); op.kernel = "add_upsampled2x";
@@ -263,7 +276,7 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
     }
     prev = lat;
     p[lvl] = conv_out_act(ar, h->output[lvl], prev);
-    push_rconv(*pl, h->output[lvl], prev, nullptr, p[lvl], lvl);
+    push_rconv(*pl, ar, h->output[lvl], prev, nullptr, p[lvl], lvl);
   }
   rel(prev);
   p[4] = make_act(ar, B, (p[3].H - 1) / 2 + 1, (p[3].W - 1) / 2 + 1, p[3].C);
@@ -272,16 +285,16 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   for (int lvl = 0; lvl < 5; ++lvl) {
     pl->lvl_h[lvl] = p[lvl].H; pl->lvl_w[lvl] = p[lvl].W;
     Act t = conv_out_act(ar, h->rpn_conv, p[lvl]);
-    push_rconv(*pl, h->rpn_conv, p[lvl], nullptr, t);
+    push_rconv(*pl, ar, h->rpn_conv, p[lvl], nullptr, t);
     Act o = conv_out_act(ar, h->rpn_obj, t);
-    push_rconv(*pl, h->rpn_obj, t, nullptr, o, 5 + lvl);
+    push_rconv(*pl, ar, h->rpn_obj, t, nullptr, o, 5 + lvl);
     Act dl = conv_out_act(ar, h->rpn_delta, t);
-    push_rconv(*pl, h->rpn_delta, t, nullptr, dl, 10 + lvl);
+    push_rconv(*pl, ar, h->rpn_delta, t, nullptr, dl, 10 + lvl);
     rel(t); rel(o); rel(dl);
   }
   size_t hw = pl->splitk.off + Arena::round_up(pl->splitk.bytes);
   for (const auto& op : pl->ops)
-    for (const Act* a : {&op.in, &op.res, &op.out})
+    for (const Act* a : {&op.in, &op.res, &op.out, &op.wino_v, &op.wino_m})
       if (a->bytes && a->off + Arena::round_up(a->bytes) > hw) hw = a->off + Arena::round_up(a->bytes);
   pl->bytes = hw;
   return pl;
@@ -305,6 +318,7 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
   if (cfg->fpn_out % 32 || cfg->num_anchors < 1 || cfg->min_size < 32 || cfg->size_divisibility != 32)
     return fail(PEANUT_EINVAL, "rcnn: unsupported configuration");
   if (cfg->precision < 0 || cfg->precision > 2) return fail(PEANUT_EINVAL, "rcnn: bad precision");
+  if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "rcnn: bad conv_algo");
   auto h = std::make_unique<peanut_rcnn>();
   h->cfg = *cfg;
   TensorMap tm;
@@ -400,7 +414,7 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
         a.y = P(op.out);
         a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = op.out.H; a.Wo = op.out.W;
         a.ws = P(pl->splitk); a.ws_floats = kSplitKScratchFloats;
-        if ((rc = launch_conv(op.conv->d, a, s))) return rc;
+        if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, s))) return rc;
         break;
       }
       case R_MAXPOOL:

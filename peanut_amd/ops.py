@@ -21,12 +21,14 @@ class FusedConv:
 
     weight: [cout, cin, kh, kw] (OIHW, host or device tensor); the NHWC input must carry
     ``cin_pad`` channels (multiple of 16; default round_up(cin, 16)), padded channels are ignored.
+    ``conv_algo='auto'`` runs stride-1 3x3 layers with >= 256 input channels as Winograd F(4x4,3x3)
+    (fp32 transforms, csrc/winograd.hip); ``'direct'`` always uses the direct implicit GEMM.
     """
 
     def __init__(self, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0,
                  dilation: int = 1, relu: bool = False, cin_pad: Optional[int] = None,
-                 precision: str = "fp32"):
+                 precision: str = "fp32", conv_algo: str = "auto"):
         self._lib = _lib.load()
         w = np.ascontiguousarray(weight.detach().cpu().numpy(), dtype=np.float32)
         cout, cin, kh, kw = w.shape
@@ -39,7 +41,7 @@ class FusedConv:
         _lib.check(self._lib.peanut_conv_create(
             C.byref(self._h), w.ctypes.data, None if sc is None else sc.ctypes.data,
             None if sh is None else sh.ctypes.data, cout, cin, self.cin_pad, kh, kw, stride, padding,
-            dilation, int(relu), _lib.PRECISIONS[precision]), "peanut_conv_create")
+            dilation, int(relu), _lib.PRECISIONS[precision], _lib.CONV_ALGOS[conv_algo]), "peanut_conv_create")
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -15,7 +15,8 @@ from .rcnn_weights import RcnnCfg, front_keys
 
 
 class MaskRCNNFront:
-    def __init__(self, cfg: RcnnCfg, state_dict: Dict[str, torch.Tensor], device="cuda:0", precision: str = "fp32"):
+    def __init__(self, cfg: RcnnCfg, state_dict: Dict[str, torch.Tensor], device="cuda:0", precision: str = "fp32",
+                 conv_algo: str = "auto"):
         if not torch.cuda.is_available():
             raise _lib.PeanutHipError("MaskRCNNFront needs a HIP device (no CPU fallback)")
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
@@ -37,6 +38,8 @@ class MaskRCNNFront:
         c.depth, c.stem_out, c.res2_out, c.stride_in_1x1 = cfg.depth, cfg.stem_out, cfg.res2_out, int(cfg.stride_in_1x1)
         c.fpn_out, c.num_anchors, c.min_size, c.max_size = cfg.fpn_out, cfg.num_anchors, cfg.min_size, cfg.max_size
         c.size_divisibility, c.bn_eps, c.precision = cfg.size_divisibility, cfg.bn_eps, _lib.PRECISIONS[precision]
+        c.conv_algo = _lib.CONV_ALGOS[conv_algo]
+        self.conv_algo = conv_algo
         for i in range(3):
             c.pixel_mean[i], c.pixel_std[i] = cfg.pixel_mean[i], cfg.pixel_std[i]
         self._h = C.c_void_p()
@@ -203,8 +206,8 @@ class MaskRCNN(MaskRCNNFront):
     """``GeneralizedRCNN.inference`` + ``detector_postprocess`` as configured by mask_rcnn_R_101_cat9.yaml:
     what ``DefaultPredictor(img)["instances"]`` yields (segmentation.py:45), batched."""
 
-    def __init__(self, cfg: RcnnCfg, state_dict, device="cuda:0", precision: str = "fp32"):
-        super().__init__(cfg, state_dict, device=device, precision=precision)
+    def __init__(self, cfg: RcnnCfg, state_dict, device="cuda:0", precision: str = "fp32", conv_algo: str = "auto"):
+        super().__init__(cfg, state_dict, device=device, precision=precision, conv_algo=conv_algo)
         from .rcnn_weights import roi_head_keys
         for key, shape in roi_head_keys(cfg):
             if key not in state_dict or tuple(state_dict[key].shape) != tuple(shape):
@@ -219,7 +222,8 @@ class MaskRCNN(MaskRCNNFront):
         self.cls_score = lin(sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"], False)
         self.bbox_pred = lin(sd["roi_heads.box_predictor.bbox_pred.weight"], sd["roi_heads.box_predictor.bbox_pred.bias"], False)
         self.mask_fcn = [FusedConv(sd[f"roi_heads.mask_head.mask_fcn{i + 1}.weight"], None,
-                                   sd[f"roi_heads.mask_head.mask_fcn{i + 1}.bias"], padding=1, relu=True, precision=precision)
+                                   sd[f"roi_heads.mask_head.mask_fcn{i + 1}.bias"], padding=1, relu=True, precision=precision,
+                                   conv_algo=conv_algo)
                          for i in range(cfg.num_mask_convs)]
         # ConvTranspose2d(k=2, s=2) = four 1x1 convs, one per output sub-pixel (dy,dx): rows (dy*2+dx)*C + n
         wd, bd = sd["roi_heads.mask_head.deconv.weight"], sd["roi_heads.mask_head.deconv.bias"]

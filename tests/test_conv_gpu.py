@@ -44,7 +44,7 @@ def test_conv_matches_torch(case):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu)
+    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, conv_algo="direct")
     xd = to_nhwc_padded(x.cuda(), round_up(cin, 16))
     rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
     y = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
@@ -105,10 +105,58 @@ def test_split_precision_conv(case, precision):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, precision=precision)
+    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, precision=precision, conv_algo="direct")
     xd = to_nhwc_padded(x.cuda(), round_up(cin, 16))
     rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
     y = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
     err = (y - ref).abs()
     tol = SPLIT_TOL[precision] * (1 + ref.abs())
     assert bool((err <= tol).all()), f"max err {err.max().item():.3e}"
+
+
+WINO_CASES = [
+    # (B, H, W, cin, cout, dil, relu, residual)
+    (2, 16, 16, 256, 256, 1, True, False),     # whole 4x4 tiles
+    (1, 15, 13, 256, 320, 1, True, True),      # tiles overhang the map on both axes; cout not a tile multiple
+    (2, 15, 15, 256, 256, 2, True, False),     # layer3 conv2: sub-grids of 8 and 7 rows
+    (1, 15, 15, 512, 512, 4, False, True),     # layer4 conv2: sub-grids of 4/4/4/3 rows, one tile each
+    (1, 9, 21, 512, 64, 4, True, False),       # some sub-grids narrower than the uniform tile grid
+    (3, 14, 14, 256, 256, 1, True, False),     # mask head shape (mask_fcn*, 14x14 per ROI)
+    (1, 6, 6, 2048, 512, 1, True, True),       # PSP bottleneck over x with the folded term as residual
+]
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-4), ("bf16x3", 1.5e-3)])
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_winograd_conv_matches_torch(case, precision, tol):
+    """conv_algo='auto' on a stride-1 3x3 layer with >= 256 input channels = Winograd F(4x4,3x3) (winograd.hip):
+    input transform -> 36 grouped GEMMs -> output transform with scale/shift/residual/ReLU.  Same operator as
+    F.conv2d up to fp32 rounding of the transforms.  F(4x4,3x3) amplifies rounding ~25x relative to the direct
+    sum on N(0,1) data (measured here vs an fp64 convolution: direct 1.3e-6, Winograd 3-5e-5; with bf16x3
+    products in the GEMM 2.4e-5 -> 6-8e-4), asserted |err| <= 1.5e-4 / 1.5e-3 * (1 + |ref|).  What the contract
+    bounds is the network output: 1.6e-5 / 1.7e-4 max-abs on the logits (tests/test_pred_gpu.py), bound 1e-3."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout, d, relu, residual = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.conv2d(x, w, None, padding=d, dilation=d) * scale[None, :, None, None] + shift[None, :, None, None]
+    res = None
+    if residual:
+        res = _rand(tuple(ref.shape), g)
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+    auto = FusedConv(w, scale, shift, padding=d, dilation=d, relu=relu, precision=precision)
+    y = auto(xd, residual=rd)
+    y2 = auto(xd, residual=rd)
+    assert torch.equal(y, y2)                                  # deterministic
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= tol * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+    if precision == "fp32":
+        direct = FusedConv(w, scale, shift, padding=d, dilation=d, relu=relu, conv_algo="direct")
+        assert not torch.equal(direct(xd, residual=rd), y)     # the two algorithms really are different code paths
