@@ -218,6 +218,11 @@ int peanut_roi_align(const float* const* feats, const int* feat_hw, const float*
 size_t peanut_nms_workspace_bytes(int n);
 int peanut_nms(const float* boxes_sorted, const int* categories, int n, float iou_threshold, void* workspace,
                unsigned char* keep, void* stream);
+/* The same for n_segments independent box lists stored back to back (one per image): segment k is
+ * boxes_sorted[seg_offsets_host[k] .. seg_offsets_host[k+1]), sorted by descending score inside the segment.
+ * workspace >= sum_k peanut_nms_workspace_bytes(n_k) bytes.  One pair of launches per 64 segments. */
+int peanut_nms_segments(const float* boxes_sorted, const int* categories, const int* seg_offsets_host, int n_segments,
+                        float iou_threshold, void* workspace, unsigned char* keep, void* stream);
 /* paste_masks_in_image + threshold: masks device [n,M,M] probabilities, boxes device [n,4] in output-image
  * pixels -> out device uint8 [n,H,W] (1 where the bilinearly resampled mask >= threshold). */
 int peanut_paste_masks(const float* masks, const float* boxes, int n, int M, int H, int W, float threshold,

@@ -87,6 +87,7 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
     "peanut_nms": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
+    "peanut_nms_segments": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, C.c_float, _P, _P, _P]),
     "peanut_paste_masks": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,

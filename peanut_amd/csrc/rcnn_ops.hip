@@ -78,13 +78,30 @@ __global__ __launch_bounds__(256) void roi_align_kernel(Pyramid pyr, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// NMS of boxes already sorted by descending score, restricted to equal category ids (batched_nms).
-// Pass 1: suppression bit matrix (box i suppresses j > i when IoU > thr); pass 2: one wave scans it in order.
+// NMS of boxes already sorted by descending score, restricted to equal category ids (batched_nms), for up to
+// kMaxSegs independent segments (images) per launch.
+// Pass 1: suppression bit matrix per segment (box i suppresses j > i when IoU > thr).
+// Pass 2: one wave per segment walks the matrix in 64-box blocks: the decisions inside a block only need the
+// block's 64x64 diagonal words (resolved in registers with readlane, no memory traffic), then the rows of the
+// kept boxes are OR-ed into the running "removed" set with all loads independent -- n/64 dependent steps
+// instead of n.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ cat, int n,
-                                                      float thr, unsigned long long* __restrict__ mask, int words) {
+constexpr int kMaxSegs = 64;
+struct NmsSegs {
+  int off[kMaxSegs + 1];            // box offsets of the segments
+  long long ws_off[kMaxSegs];       // word offsets of their bit matrices
+};
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes_all, const int* __restrict__ cat_all,
+                                                      const NmsSegs segs, float thr, unsigned long long* __restrict__ ws) {
+  const int seg = blockIdx.z;
+  const int n = segs.off[seg + 1] - segs.off[seg];
+  const int words = (n + 63) >> 6;
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
-  if (col_blk < row_blk) return;
+  if (row_blk >= words || col_blk >= words || col_blk < row_blk) return;
+  const float* boxes = boxes_all + (size_t)segs.off[seg] * 4;
+  const int* cat = cat_all ? cat_all + segs.off[seg] : nullptr;
+  unsigned long long* mask = ws + segs.ws_off[seg];
   const int i = row_blk * 64 + threadIdx.x;
   __shared__ float sb[64][4];
   __shared__ int sc[64];
@@ -114,17 +131,44 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   mask[(size_t)i * words + col_blk] = bits;
 }
 
-__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int words,
-                                                      unsigned char* __restrict__ keep) {
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ ws, const NmsSegs segs,
+                                                      unsigned char* __restrict__ keep_all) {
   extern __shared__ unsigned long long removed[];   // [words]
-  for (int w = threadIdx.x; w < words; w += 64) removed[w] = 0;
+  const int seg = blockIdx.x;
+  const int n = segs.off[seg + 1] - segs.off[seg];
+  const int words = (n + 63) >> 6;
+  const unsigned long long* mask = ws + segs.ws_off[seg];
+  unsigned char* keep = keep_all + segs.off[seg];
+  const int lane = threadIdx.x;
+  for (int w = lane; w < words; w += 64) removed[w] = 0;
   __syncthreads();
-  for (int i = 0; i < n; ++i) {
-    const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;   // uniform across the wave
-    if (threadIdx.x == 0) keep[i] = dead ? 0 : 1;
-    if (!dead) {
-      // rows only carry bits for columns >= their own 64-block; earlier words were never written
-      for (int w = (i >> 6) + threadIdx.x; w < words; w += 64) removed[w] |= mask[(size_t)i * words + w];
+  for (int b = 0; b < words; ++b) {
+    const int i = b * 64 + lane;
+    // rows only carry words for columns >= their own block (earlier ones were never written: zero-filled)
+    const unsigned long long diag = i < n ? mask[(size_t)i * words + b] : 0ull;
+    unsigned long long alive = ~removed[b];                      // uniform
+    if (b == words - 1 && (n & 63)) alive &= (1ull << (n & 63)) - 1;
+    for (int l = 0; l < 64; ++l) {
+      const unsigned long long d = readlane64(diag, l);          // uniform
+      if ((alive >> l) & 1ull) alive &= ~d;
+    }
+    if (i < n) keep[i] = (alive >> lane) & 1ull;
+    // fold the kept rows of this block into the later words
+    for (int w = b + 1 + lane; w < words; w += 64) {
+      unsigned long long acc = 0;
+      unsigned long long rest = alive;
+      while (rest) {
+        const int r = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        acc |= mask[(size_t)(b * 64 + r) * words + w];
+      }
+      removed[w] |= acc;
     }
     __syncthreads();
   }
@@ -191,20 +235,46 @@ int peanut_roi_align(const float* const* feats, const int* feat_hw, const float*
 
 size_t peanut_nms_workspace_bytes(int n) { return (size_t)n * ((n + 63) / 64) * sizeof(unsigned long long); }
 
+int peanut_nms_segments(const float* boxes_sorted, const int* categories, const int* seg_offsets_host, int n_segments,
+                        float iou_threshold, void* workspace, unsigned char* keep, void* stream) {
+  if (n_segments == 0) return 0;
+  if (!boxes_sorted || !seg_offsets_host || !workspace || !keep || n_segments < 0)
+    return fail(PEANUT_EINVAL, "peanut_nms_segments: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  long long ws_words = 0;
+  for (int s0 = 0; s0 < n_segments; s0 += kMaxSegs) {
+    const int cnt = n_segments - s0 < kMaxSegs ? n_segments - s0 : kMaxSegs;
+    NmsSegs segs{};
+    int max_words = 0;
+    const long long first_word = ws_words;
+    for (int k = 0; k < cnt; ++k) {
+      const int lo = seg_offsets_host[s0 + k], hi = seg_offsets_host[s0 + k + 1];
+      if (hi < lo) return fail(PEANUT_EINVAL, "peanut_nms_segments: offsets must be non-decreasing");
+      const int n = hi - lo, words = (n + 63) / 64;
+      if ((size_t)words * sizeof(unsigned long long) > 60 * 1024) return fail(PEANUT_EINVAL, "peanut_nms: more than 491520 boxes");
+      segs.off[k] = lo; segs.off[k + 1] = hi;
+      segs.ws_off[k] = ws_words;
+      ws_words += (long long)n * words;
+      if (words > max_words) max_words = words;
+    }
+    if (max_words == 0) continue;
+    unsigned long long* ws = (unsigned long long*)workspace;
+    PEANUT_HIP_CHECK(hipMemsetAsync(ws + first_word, 0, (size_t)(ws_words - first_word) * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(max_words, max_words, cnt), dim3(64), 0, s, boxes_sorted, categories, segs,
+                       iou_threshold, ws);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(cnt), dim3(64), (size_t)max_words * sizeof(unsigned long long), s,
+                       (const unsigned long long*)ws, segs, keep);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("nms: ") + hipGetErrorString(e));
+}
+
 int peanut_nms(const float* boxes_sorted, const int* categories, int n, float iou_threshold, void* workspace,
                unsigned char* keep, void* stream) {
   if (n == 0) return 0;
-  if (!boxes_sorted || !workspace || !keep || n < 0) return fail(PEANUT_EINVAL, "peanut_nms: bad argument");
-  const int words = (n + 63) / 64;
-  if ((size_t)words * sizeof(unsigned long long) > 60 * 1024) return fail(PEANUT_EINVAL, "peanut_nms: more than 491520 boxes");
-  hipStream_t s = (hipStream_t)stream;
-  PEANUT_HIP_CHECK(hipMemsetAsync(workspace, 0, peanut_nms_workspace_bytes(n), s));
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, s, boxes_sorted, categories, n, iou_threshold,
-                     (unsigned long long*)workspace, words);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), (size_t)words * sizeof(unsigned long long), s,
-                     (const unsigned long long*)workspace, n, words, keep);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("nms: ") + hipGetErrorString(e));
+  if (n < 0) return fail(PEANUT_EINVAL, "peanut_nms: bad argument");
+  const int off[2] = {0, n};
+  return peanut_nms_segments(boxes_sorted, categories, off, 1, iou_threshold, workspace, keep, stream);
 }
 
 int peanut_paste_masks(const float* masks, const float* boxes, int n, int M, int H, int W, float threshold,

@@ -139,27 +139,54 @@ def clip_boxes(b, hw):
     return torch.stack((b[:, 0].clamp(0, w), b[:, 1].clamp(0, h), b[:, 2].clamp(0, w), b[:, 3].clamp(0, h)), dim=1)
 
 
-def nms_keep(boxes_sorted: torch.Tensor, cats: Optional["torch.Tensor"], thr: float) -> torch.Tensor:
-    """peanut_nms: keep mask (bool) for boxes already sorted by descending score."""
+def nms_keep_segments(boxes_sorted: torch.Tensor, cats: Optional["torch.Tensor"], counts: List[int], thr: float) -> torch.Tensor:
+    """peanut_nms_segments: keep mask (bool) for ``len(counts)`` independent box lists stored back to back, each
+    already sorted by descending score (one list per image: a single pair of launches for the whole batch)."""
     lib = _lib.load()
     n = boxes_sorted.shape[0]
+    assert n == sum(counts)
     keep = torch.empty((n,), dtype=torch.uint8, device=boxes_sorted.device)
     if n == 0:
         return keep.bool()
     b = boxes_sorted.contiguous().float()
     c = None if cats is None else cats.to(torch.int32).contiguous()
-    ws = torch.empty((lib.peanut_nms_workspace_bytes(n),), dtype=torch.uint8, device=b.device)
+    offs = (C.c_int * (len(counts) + 1))()
+    for i, k in enumerate(counts):
+        offs[i + 1] = offs[i] + int(k)
+    ws_bytes = sum(lib.peanut_nms_workspace_bytes(int(k)) for k in counts)
+    ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=b.device)
     with torch.cuda.device(b.device):
-        rc = lib.peanut_nms(b.data_ptr(), None if c is None else c.data_ptr(), n, float(thr), ws.data_ptr(),
-                            keep.data_ptr(), _lib.current_stream_ptr(b.device))
-    _lib.check(rc, "peanut_nms")
+        rc = lib.peanut_nms_segments(b.data_ptr(), None if c is None else c.data_ptr(), offs, len(counts), float(thr),
+                                     ws.data_ptr(), keep.data_ptr(), _lib.current_stream_ptr(b.device))
+    _lib.check(rc, "peanut_nms_segments")
     return keep.bool()
+
+
+def nms_keep(boxes_sorted: torch.Tensor, cats: Optional["torch.Tensor"], thr: float) -> torch.Tensor:
+    """peanut_nms: keep mask (bool) for boxes already sorted by descending score."""
+    return nms_keep_segments(boxes_sorted, cats, [boxes_sorted.shape[0]], thr)
+
+
+def batched_nms_segments(items, thr):
+    """``items``: per image (boxes [n,4], scores [n], categories [n]).  torchvision.ops.batched_nms semantics per
+    image, evaluated for all images at once; returns per image the kept indices in decreasing-score order."""
+    orders = [torch.argsort(s, descending=True, stable=True) for _, s, _ in items]
+    if not items:
+        return []
+    boxes = torch.cat([b[o] for (b, _, _), o in zip(items, orders)], 0)
+    cats = torch.cat([c[o] for (_, _, c), o in zip(items, orders)], 0)
+    counts = [len(o) for o in orders]
+    keep = nms_keep_segments(boxes, cats, counts, thr)
+    out, start = [], 0
+    for o, k in zip(orders, counts):
+        out.append(o[keep[start:start + k]])
+        start += k
+    return out
 
 
 def batched_nms(boxes, scores, cats, thr):
     """torchvision.ops.batched_nms semantics: kept indices in decreasing-score order."""
-    order = torch.argsort(scores, descending=True, stable=True)
-    return order[nms_keep(boxes[order], cats[order], thr)]
+    return batched_nms_segments([(boxes, scores, cats)], thr)[0]
 
 
 def roi_align_pyramid(pyr: List[torch.Tensor], rois: torch.Tensor, levels: torch.Tensor, pooled: int) -> torch.Tensor:
@@ -252,17 +279,15 @@ class MaskRCNN(MaskRCNNFront):
             sc.append(s)
             lv.append(torch.full((k,), l, dtype=torch.int64, device=o.device))
         sc, pr, lv = torch.cat(sc, 1), torch.cat(pr, 1), torch.cat(lv, 0)
-        out = []
+        items = []
         for n in range(B):
             boxes, scores, lvl = pr[n], sc[n], lv
             valid = torch.isfinite(boxes).all(1) & torch.isfinite(scores)
-            boxes, scores, lvl = boxes[valid], scores[valid], lvl[valid]
             boxes = clip_boxes(boxes, image_hw)
-            ne = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-            boxes, scores, lvl = boxes[ne], scores[ne], lvl[ne]
-            keep = batched_nms(boxes, scores, lvl, cfg.rpn_nms_thresh)[:cfg.rpn_post_nms_topk]
-            out.append((boxes[keep], scores[keep]))
-        return out
+            ok = valid & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
+            items.append((boxes[ok], scores[ok], lvl[ok]))
+        keeps = batched_nms_segments(items, cfg.rpn_nms_thresh)          # all images in one pair of launches
+        return [(b[k[:cfg.rpn_post_nms_topk]], s[k[:cfg.rpn_post_nms_topk]]) for (b, s, _), k in zip(items, keeps)]
 
     # ---- StandardROIHeads._forward_box (inference) ----
     def box_branch(self, pyr: List[torch.Tensor], rois: torch.Tensor):
@@ -272,19 +297,27 @@ class MaskRCNN(MaskRCNNFront):
         x = self.fc2(self.fc1(x))
         return self.cls_score(x).reshape(x.shape[0], -1), self.bbox_pred(x).reshape(x.shape[0], -1)
 
+    def detections_batch(self, per_image, image_hw):
+        """fast_rcnn_inference: ``per_image`` = list of (boxes [R,4K] decoded, scores [R,K+1] softmax) ->
+        list of (boxes [n,4], scores [n], classes [n])."""
+        cfg = self.cfg
+        items, cls = [], []
+        for boxes, scores in per_image:
+            valid = torch.isfinite(boxes).all(1) & torch.isfinite(scores).all(1)
+            boxes, scores = boxes[valid], scores[valid]
+            scores = scores[:, :-1]
+            K = boxes.shape[1] // 4
+            boxes = clip_boxes(boxes.reshape(-1, 4), image_hw).view(-1, K, 4)
+            mask = scores > cfg.score_thresh_test
+            inds = mask.nonzero()
+            items.append((boxes[mask], scores[mask], inds[:, 1]))
+        keeps = batched_nms_segments(items, cfg.nms_thresh_test)
+        return [(b[k[:cfg.detections_per_image]], s[k[:cfg.detections_per_image]], c[k[:cfg.detections_per_image]])
+                for (b, s, c), k in zip(items, keeps)]
+
     def detections(self, boxes, scores, image_hw):
         """fast_rcnn_inference_single_image: boxes [R,4K] decoded, scores [R,K+1] softmax."""
-        cfg = self.cfg
-        valid = torch.isfinite(boxes).all(1) & torch.isfinite(scores).all(1)
-        boxes, scores = boxes[valid], scores[valid]
-        scores = scores[:, :-1]
-        K = boxes.shape[1] // 4
-        boxes = clip_boxes(boxes.reshape(-1, 4), image_hw).view(-1, K, 4)
-        mask = scores > cfg.score_thresh_test
-        inds = mask.nonzero()
-        boxes, scores = boxes[mask], scores[mask]
-        keep = batched_nms(boxes, scores, inds[:, 1], cfg.nms_thresh_test)[:cfg.detections_per_image]
-        return boxes[keep], scores[keep], inds[keep][:, 1]
+        return self.detections_batch([(boxes, scores)], image_hw)[0]
 
     # ---- MaskRCNNConvUpsampleHead + mask_rcnn_inference ----
     def mask_branch(self, pyr: List[torch.Tensor], rois: torch.Tensor, classes: torch.Tensor) -> torch.Tensor:
@@ -314,10 +347,11 @@ class MaskRCNN(MaskRCNNFront):
         cls_logits, box_deltas = self.box_branch(pyr, rois)
         probs = torch.softmax(cls_logits, dim=-1)
         dec = apply_deltas(box_deltas, rois[:, 1:], cfg.roi_bbox_weights)
-        dets, start = [], 0
-        for n, (b, _) in enumerate(props):
-            dets.append(self.detections(dec[start:start + len(b)], probs[start:start + len(b)], (nh, nw)))
+        per_image, start = [], 0
+        for b, _ in props:
+            per_image.append((dec[start:start + len(b)], probs[start:start + len(b)]))
             start += len(b)
+        dets = self.detections_batch(per_image, (nh, nw))
         mrois = torch.cat([torch.cat([torch.full((len(b), 1), float(n), device=b.device), b], 1) for n, (b, _, _) in enumerate(dets)], 0)
         mprobs = self.mask_branch(pyr, mrois, torch.cat([c for _, _, c in dets], 0))
         out, start = [], 0

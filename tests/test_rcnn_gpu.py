@@ -230,3 +230,21 @@ def test_semantic_pred_maskrcnn_args_constructor(small_net, tmp_path):
     assert len(r["scores"]) > 0 and want.sum() > 0
     assert np.abs(sem - want).mean() <= 2e-3 * max(1.0, want.mean())
     assert (sem != want).mean() < 2e-3
+
+
+def test_nms_segments_bit_exact():
+    """Several independent box lists in one call (one per image), incl. an empty one, exact multiples of the
+    64-box block, and more segments than one launch carries (64)."""
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import nms_keep_segments
+    g = torch.Generator().manual_seed(1)
+    counts = [130, 0, 64, 1, 1000, 63, 128] + [5] * 70
+    boxes, cats = [], []
+    for n in counts:
+        xy = torch.rand((n, 2), generator=g) * 100
+        boxes.append(torch.cat([xy, xy + torch.rand((n, 2), generator=g) * 50 + 1], 1))
+        cats.append(torch.randint(0, 3, (n,), generator=g))
+    ref = torch.cat([rcnn_ref.nms_sorted(b, c, 0.6) for b, c in zip(boxes, cats)])
+    got = nms_keep_segments(torch.cat(boxes).cuda(), torch.cat(cats).cuda(), counts, 0.6).cpu()
+    assert torch.equal(ref, got)
+    assert 0 < int(got.sum()) < len(got)
