@@ -121,6 +121,12 @@ int peanut_pred_debug_read(peanut_pred_t* h, const char* name, float* dst_dev, s
  * is dropped); kernels[i] is the kernel family op i launches (e.g. "conv_igemm_128x128x32");
  * flops[i] = algorithmic FLOPs of one launch of op i.  Returns the op count. */
 int peanut_pred_probe_enable(peanut_pred_t* h, int enable);
+/* hipGraph replay: with enable = 1 the launch sequence of a (B,H,W, in, out, apply_sigmoid, stream) combination is
+ * captured on its second use and replayed as ONE hipGraphLaunch afterwards (small batches are launch-bound:
+ * ~80 kernels per forward).  Up to 16 combinations are cached; growing the workspace drops them.  Results are
+ * identical.  Ignored while the probe or debug taps are on, and on the legacy default stream (NULL), which HIP
+ * cannot capture: pass a created stream. */
+int peanut_pred_use_graph(peanut_pred_t* h, int enable);
 int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names, const char** kernels,
                               double* ms_sum, double* flops, int* n_forwards);
 
@@ -159,6 +165,9 @@ int peanut_map_dims(peanut_map_t* h, int dims[4]);
  * [1,V,V], map_pred [C,M,M] (must not alias maps_last).  Enqueues ~14 launches, no host sync. */
 int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
                        float* poses_inout, float* fp_map_pred, float* map_pred, void* stream);
+/* hipGraph replay of the step's launches, keyed on the seven pointer/stream arguments (an agent ping-pongs two map
+ * buffers: two cached graphs). */
+int peanut_map_use_graph(peanut_map_t* h, int enable);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 1 -- Mask R-CNN front end (preprocessing + ResNet-FPN backbone + RPN head)

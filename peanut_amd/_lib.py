@@ -71,6 +71,8 @@ SIGNATURES = {
     "peanut_pred_debug_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int * 4)]),
     "peanut_pred_debug_read": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int * 4), _P]),
     "peanut_pred_probe_enable": (C.c_int, [_P, C.c_int]),
+    "peanut_pred_use_graph": (C.c_int, [_P, C.c_int]),
+    "peanut_map_use_graph": (C.c_int, [_P, C.c_int]),
     "peanut_pred_probe_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "peanut_map_create": (C.c_int, [C.POINTER(_P), C.POINTER(MapCfgC)]),

@@ -34,6 +34,7 @@
 
 #include "../../include/peanut_hip.h"
 #include "common.h"
+#include "net_common.h"
 
 #pragma clang fp contract(off)
 
@@ -408,7 +409,10 @@ struct peanut_map {
   WarpT* wt = nullptr;
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  bool use_graph = false;    // peanut_map_use_graph: the ten launches of a step replayed as one hipGraph
+  GraphCache graphs;
   ~peanut_map() {
+    graphs.clear();
     for (void* p : {(void*)coords, (void*)pos, (void*)keys, (void*)idx, (void*)skeys, (void*)sidx, (void*)cell_head,
                     (void*)stats, (void*)wts6, (void*)feat_s, (void*)proj, (void*)view, (void*)wt, sort_tmp})
       if (p) (void)hipFree(p);
@@ -498,25 +502,37 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
     return fail(PEANUT_EINVAL, "peanut_map_forward: null argument");
   if (maps_last == map_pred) return fail(PEANUT_EINVAL, "peanut_map_forward: map_pred must not alias maps_last");
   hipStream_t s = (hipStream_t)stream;
-  const MapP& P = h->P;
-  const int nb = (P.N + 255) / 256;
-  hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, P);
-  hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, h->pos, h->keys, h->idx, P);
-  size_t tmp = h->sort_tmp_bytes;
-  PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tmp, h->keys, h->skeys, h->idx, h->sidx, P.N, 0, 21, s));
-  hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 1);
-  const long long vt = (long long)P.N * 8 * P.F;
-  hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(256), 0, s, obs, h->pos, h->skeys, h->sidx, h->wts6, h->feat_s, P);
-  hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, h->wts6, h->feat_s, h->skeys,
-                     h->cell_head, h->proj, P);
-  hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 0);
-  hipLaunchKernelGGL(map_view_kernel, dim3((P.vr * P.vr + 255) / 256), dim3(256), 0, s, h->proj, h->view, fp_map_pred,
-                     h->stats, P);
-  hipLaunchKernelGGL(map_pose_kernel, dim3(1), dim3(64), 0, s, pose_obs, poses_inout, h->wt, P);
-  hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
-                     h->wt, P);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_map_forward: ") + hipGetErrorString(e));
+  auto enqueue = [&]() -> int {
+    const MapP& P = h->P;
+    const int nb = (P.N + 255) / 256;
+    hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, P);
+    hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, h->pos, h->keys, h->idx, P);
+    size_t tmp = h->sort_tmp_bytes;
+    PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tmp, h->keys, h->skeys, h->idx, h->sidx, P.N, 0, 21, s));
+    hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 1);
+    const long long vt = (long long)P.N * 8 * P.F;
+    hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(256), 0, s, obs, h->pos, h->skeys, h->sidx, h->wts6, h->feat_s, P);
+    hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, h->wts6, h->feat_s, h->skeys,
+                       h->cell_head, h->proj, P);
+    hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 0);
+    hipLaunchKernelGGL(map_view_kernel, dim3((P.vr * P.vr + 255) / 256), dim3(256), 0, s, h->proj, h->view, fp_map_pred,
+                       h->stats, P);
+    hipLaunchKernelGGL(map_pose_kernel, dim3(1), dim3(64), 0, s, pose_obs, poses_inout, h->wt, P);
+    hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
+                       h->wt, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_map_forward: ") + hipGetErrorString(e));
+    return 0;
+  };
+  if (!h->use_graph) return enqueue();
+  return h->graphs.run({(uintptr_t)obs, (uintptr_t)pose_obs, (uintptr_t)maps_last, (uintptr_t)poses_inout,
+                        (uintptr_t)fp_map_pred, (uintptr_t)map_pred, (uintptr_t)s}, s, enqueue);
+}
+
+int peanut_map_use_graph(peanut_map_t* h, int enable) {
+  if (!h) return fail(PEANUT_EINVAL, "null handle");
+  h->use_graph = enable != 0;
+  if (!h->use_graph) h->graphs.clear();
   return 0;
 }
 

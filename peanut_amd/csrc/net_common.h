@@ -3,6 +3,8 @@
 #pragma once
 #include <math.h>
 
+#include <stdint.h>
+
 #include <map>
 #include <memory>
 #include <string>
@@ -23,6 +25,56 @@ struct DevBuf {
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
     bytes = n;
+    return 0;
+  }
+};
+
+// Replays a fixed launch sequence as a hipGraph.  Keyed by the caller on everything baked into the captured
+// launches (plan, device pointers, flags).  The first call with a new key runs the sequence directly (so that
+// one-time initialisation -- occupancy queries, the zero page, function attributes -- happens outside a capture),
+// the second captures + instantiates, later ones are a single hipGraphLaunch.
+struct GraphCache {
+  struct Entry { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warmed = false; };
+  std::vector<Entry> entries;
+  static constexpr size_t kMaxEntries = 16;
+  void clear() {
+    for (auto& e : entries) {
+      if (e.exec) (void)hipGraphExecDestroy(e.exec);
+      if (e.graph) (void)hipGraphDestroy(e.graph);
+    }
+    entries.clear();
+  }
+  ~GraphCache() { clear(); }
+  template <class F>
+  int run(const std::vector<uintptr_t>& key, hipStream_t s, F&& enqueue) {
+    if (s == nullptr) return enqueue();   // the legacy default stream cannot be captured: plain launches
+    Entry* hit = nullptr;
+    for (auto& e : entries) if (e.key == key) { hit = &e; break; }
+    if (!hit) {
+      if (entries.size() >= kMaxEntries) {   // drop the oldest
+        if (entries.front().exec) (void)hipGraphExecDestroy(entries.front().exec);
+        if (entries.front().graph) (void)hipGraphDestroy(entries.front().graph);
+        entries.erase(entries.begin());
+      }
+      entries.emplace_back();
+      entries.back().key = key;
+      entries.back().warmed = true;
+      return enqueue();
+    }
+    if (!hit->exec) {
+      PEANUT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue();
+      hipGraph_t g = nullptr;
+      const hipError_t e = hipStreamEndCapture(s, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      hipGraphExec_t x = nullptr;
+      const hipError_t e2 = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+      if (e2 != hipSuccess) { (void)hipGraphDestroy(g); return fail(PEANUT_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+      hit->graph = g;
+      hit->exec = x;
+    }
+    PEANUT_HIP_CHECK(hipGraphLaunch(hit->exec, s));
     return 0;
   }
 };

@@ -80,6 +80,8 @@ struct peanut_pred {
   std::map<std::string, std::unique_ptr<Plan>> plans;
   Plan* last_plan = nullptr;
   DevBuf ws;
+  bool use_graph = false;   // peanut_pred_use_graph: replay each (shape, buffers) launch sequence as a hipGraph
+  GraphCache graphs;
   // event probe (bench.py roofline): per-op HIP events recorded inside forward
   bool probe = false;
   Plan* probe_plan = nullptr;
@@ -528,13 +530,18 @@ int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, i
   Plan* pl = get_plan(h, B, H, W);
   if (!pl) return PEANUT_EINVAL;
   int rc;
+  if (pl->bytes > h->ws.bytes) h->graphs.clear();   // captured launches point into the old workspace
   if ((rc = h->ws.ensure(pl->bytes))) return rc;
   h->last_plan = pl;
   hipStream_t s = (hipStream_t)stream;
   if (!h->probe) {
-    for (const auto& op : pl->ops)
-      if ((rc = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, s))) return rc;
-    return 0;
+    auto enqueue = [&]() -> int {
+      for (const auto& op : pl->ops)
+        if (int r = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, s)) return r;
+      return 0;
+    };
+    if (!h->use_graph || h->keep_all) return enqueue();
+    return h->graphs.run({(uintptr_t)pl, (uintptr_t)in_dev, (uintptr_t)out_dev, (uintptr_t)apply_sigmoid, (uintptr_t)s}, s, enqueue);
   }
   if (h->probe_plan && h->probe_plan != pl) return fail(PEANUT_EINVAL, "probe: shape changed while probing; collect first");
   h->probe_plan = pl;
@@ -549,6 +556,13 @@ int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, i
     PEANUT_HIP_CHECK(hipEventRecord(ev[i + 1], s));
   }
   h->probe_events.push_back(std::move(ev));
+  return 0;
+}
+
+int peanut_pred_use_graph(peanut_pred_t* h, int enable) {
+  if (!h) return fail(PEANUT_EINVAL, "null handle");
+  h->use_graph = enable != 0;
+  if (!h->use_graph) h->graphs.clear();
   return 0;
 }
 

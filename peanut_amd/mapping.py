@@ -61,7 +61,12 @@ class Semantic_Mapping(nn.Module):
             raise ValueError(f"{name} must be a float32 HIP tensor of shape {tuple(shape)}, got "
                              f"{t.dtype} {tuple(t.shape)} on {t.device}")
 
-    def forward(self, obs, pose_obs, maps_last, poses_last, agent_states=None):
+    def use_graph(self, enable: bool = True):
+        """Replay the ten launches of a step as one hipGraph per distinct set of buffers (captured on second use).
+        Only effective when the caller passes persistent ``out=`` buffers (e.g. two map buffers used in turn)."""
+        _lib.check(self._lib.peanut_map_use_graph(self._h, int(enable)), "peanut_map_use_graph")
+
+    def forward(self, obs, pose_obs, maps_last, poses_last, agent_states=None, out=None):
         Cc, M, V = self.channels, self.map_cells, self.vision_range
         h, w = self.args.frame_height, self.args.frame_width
         self._chk(obs, (1, Cc, h, w), "obs")
@@ -71,8 +76,15 @@ class Semantic_Mapping(nn.Module):
         if not poses_last.is_contiguous():
             raise ValueError("poses_last must be contiguous (it is updated in place)")
         obs, pose_obs, maps_last = obs.contiguous(), pose_obs.contiguous(), maps_last.contiguous()
-        fp_map_pred = torch.empty((1, V, V), dtype=torch.float32, device=obs.device)
-        map_pred = torch.empty((Cc, M, M), dtype=torch.float32, device=obs.device)
+        if out is None:
+            fp_map_pred = torch.empty((1, V, V), dtype=torch.float32, device=obs.device)
+            map_pred = torch.empty((Cc, M, M), dtype=torch.float32, device=obs.device)
+        else:                                   # caller-owned (fp_map_pred, map_pred), must not alias maps_last
+            fp_map_pred, map_pred = out
+            self._chk(fp_map_pred, (1, V, V), "out[0]")
+            self._chk(map_pred, (Cc, M, M), "out[1]")
+            if not (fp_map_pred.is_contiguous() and map_pred.is_contiguous()):
+                raise ValueError("out buffers must be contiguous")
         with torch.cuda.device(obs.device):
             rc = self._lib.peanut_map_forward(self._h, obs.data_ptr(), pose_obs.data_ptr(), maps_last.data_ptr(),
                                               poses_last.data_ptr(), fp_map_pred.data_ptr(), map_pred.data_ptr(),

@@ -126,6 +126,14 @@ class HipSegmentor:
                        "peanut_pred_debug_read")
         return out
 
+    def use_graph(self, enable: bool = True):
+        """Replay the launch sequence of each (shape, input buffer, output buffer) combination as one hipGraph
+        (captured on its second use).  Pays off for small batches, where ~80 launches per forward dominate; keep
+        the input/output tensors alive and reuse them (``out=``) so that the cached graphs are hit, and run under a
+        non-default stream (``with torch.cuda.stream(torch.cuda.Stream())``): HIP cannot capture the NULL stream,
+        where the launches simply stay plain."""
+        _lib.check(self._lib.peanut_pred_use_graph(self._h, int(enable)), "peanut_pred_use_graph")
+
     def probe_enable(self, enable: bool = True):
         """Per-op HIP-event probe inside forward (see include/peanut_hip.h)."""
         _lib.check(self._lib.peanut_pred_probe_enable(self._h, int(enable)), "peanut_pred_probe_enable")

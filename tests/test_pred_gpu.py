@@ -207,3 +207,33 @@ def test_winograd_and_direct_conv_algorithms_agree(model_and_sd, golden_dir):
         assert (a - d).abs().max().item() <= 1e-4, case
     print(f"max-abs vs reference golden logits: winograd {worst_a:.3e}, direct {worst_d:.3e}")
     assert worst_a <= TOL and worst_d <= 2e-5
+
+
+def test_graph_replay_is_bit_identical(model_and_sd):
+    """peanut_pred_use_graph: the ~85 launches of a forward replayed as one hipGraph give bit-identical output
+    (first call direct, second captured, later ones replayed; a second shape gets its own graph)."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    g = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    g.model.use_graph(True)
+    side = torch.cuda.Stream()                          # the legacy default stream cannot be captured
+    for (b, h, w) in [(1, 96, 96), (2, 72, 104)]:
+        x = _inputs(b, cfg.in_channels, h, w, seed=5).cuda()
+        want = m.get_prediction_batch(x, apply_sigmoid=True)
+        out = torch.empty_like(want)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for rep in range(4):
+                out.zero_()
+                g.get_prediction_batch(x, apply_sigmoid=True, out=out)
+                side.synchronize()
+                assert torch.equal(out, want), (b, h, w, rep)
+            x2 = _inputs(b, cfg.in_channels, h, w, seed=6).cuda()
+            x.copy_(x2)                                 # same buffer, new contents: the replay must see them
+            g.get_prediction_batch(x, apply_sigmoid=True, out=out)
+            side.synchronize()
+        assert torch.equal(out, m.get_prediction_batch(x2, apply_sigmoid=True))
+    # on the default stream graph mode silently stays with plain launches
+    assert torch.equal(g.get_prediction_batch(x, apply_sigmoid=True), m.get_prediction_batch(x, apply_sigmoid=True))
+    g.model.use_graph(False)
+    assert torch.equal(g.get_prediction_batch(x, apply_sigmoid=True), m.get_prediction_batch(x, apply_sigmoid=True))
