@@ -45,6 +45,9 @@ struct KIter {
 
 const float* zero_page();   // per-device 4 KiB of zeros (allocated on first use)
 int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, float* ws, size_t ws_floats, hipStream_t stream);
+// conv_pw.hip: fp32 pointwise convs / grouped GEMMs with LDS-DMA staging (PEANUT_PW_GLDS=0 disables)
+bool conv_pw_enabled();
+int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream);
 
 // Work decomposition of one launch.
 //  * XCD-aware (guide T1): workgroup b runs on XCD b % 8 (observed, used for speed only); every XCD gets
@@ -81,6 +84,76 @@ __device__ __forceinline__ Work decode_work(const ConvKParams& p) {
   w.mt = tile / p.ntiles;
   w.nt = tile - w.mt * p.ntiles;
   return w;
+}
+
+// ---- shared epilogue: y = relu(acc * scale[n] + shift[n] + res), or the raw partial tile of a split-K part ----
+// The accumulators go through LDS (EP row slabs) so that global traffic is whole rows: each thread then handles
+// 16-byte pieces (4 consecutive channels) -- a wave reads the residual and writes the output as contiguous row
+// segments instead of 64 scalar accesses per lane.  The caller's k-loop must have retired every LDS read (barrier).
+template <int BM, int BN, int WM, int WN, int EP, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& wk, f32x16 (&acc)[MI][NI], float* smem,
+                                              int m0, int n0) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int CS = BN + 4, ER = BM / EP;
+  static_assert(MI == TM / 32 && NI == TN / 32, "accumulator shape");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  constexpr int NV = BN / 4;               // float4 per output row of the tile
+  constexpr int ROWS_PER_PASS = 256 / NV;  // rows covered by the 256 threads per pass
+  const int c4 = (tid % NV) * 4, r0 = tid / NV;
+  const int n = n0 + c4;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);   // scale/shift are padded to cout_pad
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+  const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
+#pragma unroll
+  for (int ep = 0; ep < EP; ++ep) {
+    if (EP == 1 || wm == ep) {
+#pragma unroll
+      for (int t = 0; t < MI; ++t)
+#pragma unroll
+        for (int u = 0; u < NI; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi - ep * ER;
+            smem[row * CS + wn * TN + u * 32 + li] = acc[t][u][r];
+          }
+    }
+    __syncthreads();
+    if (wk.item >= 0) {   // split-K part: raw accumulators, summed + finished by conv_splitk_reduce_kernel
+      float* dst = p.partial + (size_t)wk.item * (BM * BN) + (size_t)ep * ER * BN;
+      for (int row = r0; row < ER; row += ROWS_PER_PASS)
+        *reinterpret_cast<f32x4*>(dst + row * BN + c4) = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+    } else {
+#pragma unroll 4
+      for (int row = r0; row < ER; row += ROWS_PER_PASS) {
+        const int m = m0 + ep * ER + row;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+        v = v * sc + sh;
+        const size_t o = (size_t)m * p.cout + n;
+        if (vec_ok) {
+          if (n < p.cout) {
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(p.y + o) = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < p.cout) {
+              float x = v[e];
+              if (p.res) x += p.res[o + e];
+              if (p.relu) x = fmaxf(x, 0.f);
+              p.y[o + e] = x;
+            }
+          }
+        }
+      }
+    }
+    if (ep + 1 < EP) __syncthreads();
+  }
 }
 
 // host side: pick split_p for T tiles over S slots; returns the number of tail tiles (0 = no split)

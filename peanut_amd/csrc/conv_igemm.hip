@@ -41,10 +41,23 @@ namespace peanut {
 // Branch-free on purpose: out-of-image taps / rows read a 16-byte zero page instead of being predicated
 // (arithmetic select of the address -- a ?: on pointers is lowered to exec-masked code) and the iterator
 // advances with selects, so the steady-state k-loop body is ONE basic block.
-template <int BN, int BK, int A_PER>
+template <int BN, int BK, int A_PER, bool PW>
 __device__ __forceinline__ void prep_addr(const ConvKParams& p, KIter& it, const int (&a_iy0)[A_PER],
                                           const int (&a_ix0)[A_PER], const int (&a_pix)[A_PER], int a_c4,
                                           unsigned long long (&a_addr)[A_PER], const float*& b_tile) {
+  if constexpr (PW) {
+    // pointwise (1x1, pad 0, one source): every row walks its pixel's channels linearly -- one 64-bit add per
+    // pointer per k-tile instead of the tap/bounds arithmetic (a_pix holds the pixel's base float offset / 4,
+    // rows past M were clamped to a valid pixel in the prologue)
+    static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      a_addr[j] = (unsigned long long)(p.x + ((size_t)(unsigned)a_pix[j] << 2)) + ((unsigned long long)(unsigned)it.cbase << 2);
+    });
+    b_tile = it.wtile;
+    it.wtile += BN * BK;
+    it.cbase += BK;
+    return;
+  }
   const bool second = it.cbase >= p.c1;
   const float* src = second ? p.x2 : p.x;
   const int C = second ? p.c2 : p.c1, cb = second ? it.cbase - p.c1 : it.cbase;
@@ -73,7 +86,9 @@ __device__ __forceinline__ void issue_loads(const ConvKParams& p, const unsigned
   constexpr int B_F4 = BN * (BK / 4);
   static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
     constexpr int j = decltype(J)::value;
-    ra[j] = *reinterpret_cast<const f32x4*>(a_addr[j]);
+    // address_space(1): a global_load, not a flat_load (flat loads also count on lgkmcnt and would force the
+    // LDS fragment reads to be waited for in order with them)
+    ra[j] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(a_addr[j]);
   });
   static_for<B_PER>([&](auto J) __attribute__((always_inline)) {
     constexpr int j = decltype(J)::value;
@@ -104,7 +119,7 @@ __device__ __forceinline__ void store_tiles(float* stage, int tid, const f32x4 (
   });
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool PW = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   constexpr int KV = BK / 4;            // f32x4 per tile row
   constexpr int LS = BK + 4;            // LDS row stride (floats)
@@ -137,7 +152,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const int idx = tid + 256 * j;
     const int row = idx / KV;
     const int m = m0 + row;
-    if (row < BM && m < p.M) {
+    if constexpr (PW) {
+      const int mc = (row < BM && m < p.M) ? m : p.M - 1;   // rows past the end compute a valid row and are dropped
+      const int b = mc / p.HoWo;
+      const int rem = mc - b * p.HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      // float offset of (pixel, channel a_c4) divided by 4 (channel counts are multiples of 16): fits 32 bits up to 16 GiB
+      a_pix[j] = (int)((((size_t)(b * p.H * p.W + oy * p.stride * p.W + ox * p.stride)) * p.c1 + a_c4) >> 2);
+      a_iy0[j] = 0;
+      a_ix0[j] = 0;
+    } else if (row < BM && m < p.M) {
       const int b = m / p.HoWo;
       const int rem = m - b * p.HoWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 
   unsigned long long a_addr[A_PER];
   const float* b_tile;
-#define PEANUT_PREP_ADDR() prep_addr<BN, BK, A_PER>(p, it, a_iy0, a_ix0, a_pix, a_c4, a_addr, b_tile)
+#define PEANUT_PREP_ADDR() prep_addr<BN, BK, A_PER, PW>(p, it, a_iy0, a_ix0, a_pix, a_c4, a_addr, b_tile)
 #define PEANUT_ISSUE_LOADS() issue_loads<BN, BK, A_PER, B_PER>(p, a_addr, b_tile, tid, ra, rb)
 #define PEANUT_STORE_TILES(stage) store_tiles<BM, BN, BK, A_PER, B_PER>(stage, tid, ra, rb)
 
@@ -189,102 +213,76 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   PEANUT_PREP_ADDR();                // addresses of k-tile 2
   __syncthreads();
 
-#define PEANUT_COMPUTE(cur)                                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < BK / 8; ++ks) {                                                \
-    f32x4 af[MI], bf[NI];                                                                                \
+  // MFMA fragments of one k-tile are read in two halves (KH groups of 8 k each) into two register sets so that
+  // the ds_reads of one half are in flight while the matrix cores work on the other:
+  //   set A = first half of the current k-tile (read during the previous k-tile's second half),
+  //   set B = second half (read while set A is being consumed).
+  constexpr int KH = BK / 16;   // 8-k groups per half
+  f32x4 afA[KH][MI], bfA[KH][NI], afB[KH][MI], bfB[KH][NI];
+#define PEANUT_LOAD_FRAGS(af, bf, stage, half)                                                           \
+  _Pragma("unroll") for (int j = 0; j < KH; ++j) {                                                       \
     _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                       \
-      af[t] = *reinterpret_cast<const f32x4*>((cur) + a_off + t * 32 * LS + ks * 8);                     \
+      af[j][t] = *reinterpret_cast<const f32x4*>((stage) + a_off + t * 32 * LS + ((half) * KH + j) * 8); \
     _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                       \
-      bf[u] = *reinterpret_cast<const f32x4*>((cur) + b_off + u * 32 * LS + ks * 8);                     \
+      bf[j][u] = *reinterpret_cast<const f32x4*>((stage) + b_off + u * 32 * LS + ((half) * KH + j) * 8); \
+  }
+#define PEANUT_MFMA_HALF(af, bf)                                                                         \
+  _Pragma("unroll") for (int j = 0; j < KH; ++j)                                                         \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
       _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                     \
         _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                   \
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][kk], bf[u][kk], acc[t][u], 0, 0, 0);    \
-  }
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
 
-  // steady state (no conditionals inside): stage k-tile kt+1 from registers to the other LDS buffer, issue
-  // the loads of k-tile kt+2 (addresses ready since the previous iteration), then -- fenced below them --
-  // the 64 MFMAs of k-tile kt with the address arithmetic of k-tile kt+3 in their shadow
+  PEANUT_LOAD_FRAGS(afA, bfA, smem, 0);
+  // steady state (no conditionals inside).  Per k-tile kt:
+  //   registers -> LDS[nxt] (k-tile kt+1), issue the global loads of k-tile kt+2, issue the reads of fragment set B;
+  //   first-half MFMAs on set A with the address arithmetic of k-tile kt+3 in their shadow;
+  //   barrier (LDS[nxt] complete, LDS[cur] no longer needed); issue the reads of set A for k-tile kt+1;
+  //   second-half MFMAs on set B.
   int kt = 0;
   for (; kt + 2 < nk; ++kt) {
     float* const nxt = smem + ((kt + 1) & 1) * STAGE;
     const float* const cur = smem + (kt & 1) * STAGE;
     PEANUT_STORE_TILES(nxt);
     PEANUT_ISSUE_LOADS();
+    PEANUT_LOAD_FRAGS(afB, bfB, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
     PEANUT_PREP_ADDR();
-    PEANUT_COMPUTE(cur);
+    PEANUT_MFMA_HALF(afA, bfA);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    PEANUT_LOAD_FRAGS(afA, bfA, nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afB, bfB);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if (kt + 1 < nk) {   // second-to-last k-tile: nothing left to load
-    PEANUT_STORE_TILES(smem + ((kt + 1) & 1) * STAGE);
-    PEANUT_COMPUTE(smem + (kt & 1) * STAGE);
+  if (kt + 1 < nk) {   // second-to-last k-tile: nothing left to load from global memory
+    float* const nxt = smem + ((kt + 1) & 1) * STAGE;
+    const float* const cur = smem + (kt & 1) * STAGE;
+    PEANUT_STORE_TILES(nxt);
+    PEANUT_LOAD_FRAGS(afB, bfB, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afA, bfA);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    PEANUT_LOAD_FRAGS(afA, bfA, nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afB, bfB);
+    __builtin_amdgcn_sched_barrier(0);
     ++kt;
   }
-  PEANUT_COMPUTE(smem + (kt & 1) * STAGE);   // last k-tile
-  __syncthreads();
-#undef PEANUT_COMPUTE
-
-  // ---- epilogue: y = relu(acc * scale[n] + shift[n] + res) ----
-  // The accumulators go through LDS once so that global traffic is whole rows: each thread then
-  // handles 16-byte pieces (4 consecutive channels) -- a wave reads the residual and writes the
-  // output as 512-byte (BN=128) contiguous row segments instead of 64 scalar accesses per lane.
-  // (The k-loop's last barrier has retired every LDS read, so the pipeline buffers are free.)
-  constexpr int NV = BN / 4;               // float4 per output row of the tile
-  constexpr int ROWS_PER_PASS = 256 / NV;  // rows covered by the 256 threads per pass
-  const int c4 = (tid % NV) * 4, r0 = tid / NV;
-  const int n = n0 + c4;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);   // scale/shift are padded to cout_pad
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-  const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
-#pragma unroll
-  for (int ep = 0; ep < EP; ++ep) {
-    if (EP == 1 || wm == ep) {
-#pragma unroll
-      for (int t = 0; t < MI; ++t)
-#pragma unroll
-        for (int u = 0; u < NI; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi - ep * ER;
-            smem[row * CS + wn * TN + u * 32 + li] = acc[t][u][r];
-          }
-    }
-    __syncthreads();
-    if (wk.item >= 0) {   // split-K part: raw accumulators, summed + finished by conv_splitk_reduce_kernel
-      float* dst = p.partial + (size_t)wk.item * (BM * BN) + (size_t)ep * ER * BN;
-      for (int row = r0; row < ER; row += ROWS_PER_PASS)
-        *reinterpret_cast<f32x4*>(dst + row * BN + c4) = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
-    } else {
-#pragma unroll 4
-      for (int row = r0; row < ER; row += ROWS_PER_PASS) {
-        const int m = m0 + ep * ER + row;
-        if (m >= p.M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
-        v = v * sc + sh;
-        const size_t o = (size_t)m * p.cout + n;
-        if (vec_ok) {
-          if (n < p.cout) {
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<f32x4*>(p.y + o) = v;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e < p.cout) {
-              float x = v[e];
-              if (p.res) x += p.res[o + e];
-              if (p.relu) x = fmaxf(x, 0.f);
-              p.y[o + e] = x;
-            }
-          }
-        }
-      }
-    }
-    if (ep + 1 < EP) __syncthreads();
+  {                    // last k-tile
+    const float* const cur = smem + (kt & 1) * STAGE;
+    PEANUT_LOAD_FRAGS(afB, bfB, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afA, bfA);
+    PEANUT_MFMA_HALF(afB, bfB);
   }
+  __syncthreads();
+#undef PEANUT_LOAD_FRAGS
+#undef PEANUT_MFMA_HALF
+
+  conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, smem, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,9 +333,16 @@ void pack_conv_weights(const float* w, int cout, int cin_real, int cin_pad, int 
 
 template <int BM, int BN, int BK, int WM, int WN>
 static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
+  // pointwise fast path: 1x1, no padding, one source, and every (pixel, channel) float offset / 4 fits 32 bits
+  const bool pw = p.ntaps == 1 && p.pad == 0 && p.c2 == 0 && (size_t)p.M * p.stride * p.stride * p.c1 < ((size_t)1 << 33);
+  if (pw) {
+    static int slots_pw = 0;
+    return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN, true>), BM, BN>(
+        &conv_igemm_kernel<BM, BN, BK, WM, WN, true>, p, ws, ws_floats, stream, &slots_pw);
+  }
   static int slots = 0;
-  return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN>), BM, BN>(
-      &conv_igemm_kernel<BM, BN, BK, WM, WN>, p, ws, ws_floats, stream, &slots);
+  return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN, false>), BM, BN>(
+      &conv_igemm_kernel<BM, BN, BK, WM, WN, false>, p, ws, ws_floats, stream, &slots);
 }
 
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
@@ -363,6 +368,8 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
     if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
     return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);
   }
+  if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c2 == 0 && p.c1 % 32 == 0 && conv_pw_enabled())
+    return launch_conv_pw(p, d.bn_tile, a.ws, a.ws_floats, stream);
   if (d.bk == 32) {
     if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, a.ws, a.ws_floats, stream);
     if (d.bn_tile == 64) return launch_t<128, 64, 32, 2, 2>(p, a.ws, a.ws_floats, stream);

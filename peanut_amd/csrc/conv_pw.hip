@@ -1,0 +1,193 @@
+// Pointwise (1x1, no padding, one source) convolutions and the Winograd position GEMMs: the same 128 x BN x 32 MFMA
+// tiling as conv_igemm_kernel, but the k-tiles travel global memory -> LDS directly (global_load_lds_dwordx4,
+// gfx950 LDS-DMA) instead of through VGPRs.
+//
+// Why a second kernel: measured with tools/micro/mfma_loop.hip on MI355X (2 workgroups/CU, 64 fp32 MFMAs per
+// k-tile and wave): MFMAs + LDS fragment reads + one barrier sustain 150 TF/s; adding the 8 ds_write_b128 of a
+// register-staged pipeline costs 8 %, its 8 global_load_dwordx4 another 4-9 % -- the VGPR traffic of the staging
+// competes with the accumulate traffic of the matrix cores in the unified register file -- while 8
+// global_load_lds cost 6 %.  The 1x1 convs and Winograd GEMMs are > 90 % of the forward's MFMA time, and for
+// them a k-tile row is one contiguous 128-byte run, exactly what the LDS-DMA writes (wave-uniform base + lane * 16).
+//
+// LDS image: rows of 32 floats, unpadded (the DMA destination is lane-linear), 16-byte chunk c of row r stored at
+// chunk position c ^ ((r >> 1) & 7).  The permutation is applied on the SOURCE address of the DMA (which row
+// chunk a lane fetches) and again on the ds_read_b128 address -- the same involution on both sides -- and makes
+// the MFMA fragment reads (16 consecutive rows, one chunk) hit 16 distinct 16-byte bank groups.
+//
+// Ordering (cdna_hip_programming.md, LDS-DMA rules): a stage is read only after `s_waitcnt vmcnt(0)` by the
+// issuing waves followed by a workgroup barrier; it is refilled only after a barrier that follows every wave's
+// last read of it.  One barrier per k-tile, double-buffered LDS, MFMA fragment reads software-pipelined in two
+// halves exactly as in conv_igemm_kernel.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_common.h"
+
+namespace peanut {
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) {
+  constexpr int BM = 128, BK = 32;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
+  constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;   // 1 KiB (8-row) DMA pieces per wave and k-tile
+  constexpr int CS = BN + 4;
+  constexpr int EP = (BM * CS > 2 * STAGE) ? WM : 1;
+  constexpr int ER = BM / EP;
+  constexpr int SMEM_FLOATS = (2 * STAGE > ER * CS) ? 2 * STAGE : ER * CS;
+  static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "4 waves, wave tile a multiple of 32x32");
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const Work wk = decode_work(p);
+  const int mt = wk.mt, nt = wk.nt, nk = wk.kt1 - wk.kt0;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay in SGPRs
+  const int lr = lane >> 3, lp = lane & 7;   // row within an 8-row DMA piece, chunk position within the row
+
+  // ---- per-lane DMA source pointers (advanced by one k-tile per iteration) ----
+  const float* a_src[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int r = (wave * A_INSTR + j) * 8 + lr;
+    const int m = m0 + r;
+    const int mc = m < p.M ? m : p.M - 1;            // rows past the end compute a valid row and are dropped
+    const int b = mc / p.HoWo;
+    const int rem = mc - b * p.HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const size_t pix = (size_t)b * p.H * p.W + (size_t)oy * p.stride * p.W + (size_t)ox * p.stride;
+    const int c = lp ^ ((r >> 1) & 7);
+    a_src[j] = p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4;
+  }
+  const float* b_src[B_INSTR];
+  {
+    const float* wtile = p.w + (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride : 0) +
+                         ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      const int r = (wave * B_INSTR + j) * 8 + lr;
+      const int c = lp ^ ((r >> 1) & 7);
+      b_src[j] = wtile + r * BK + c * 4;
+    }
+  }
+#define PEANUT_DMA_TILE(stage)                                                                                   \
+  {                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                                        \
+      __builtin_amdgcn_global_load_lds((gptr_t)a_src[j], (lptr_t)((stage) + (wave * A_INSTR + j) * 256), 16, 0, 0); \
+      a_src[j] += BK;                                                                                            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j) {                                                        \
+      __builtin_amdgcn_global_load_lds((gptr_t)b_src[j], (lptr_t)((stage) + A_FLOATS + (wave * B_INSTR + j) * 256), 16, 0, 0); \
+      b_src[j] += BN * BK;                                                                                       \
+    }                                                                                                            \
+  }
+#define PEANUT_DMA_LANDED_BARRIER()          \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+  __syncthreads();
+
+  // ---- MFMA fragment coordinates ----
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  const int swz = (li >> 1) & 7;               // (row >> 1) & 7 of every fragment row this lane reads
+  int sw[BK / 8];                              // float offset of k-group ks inside a row, after the permutation
+#pragma unroll
+  for (int ks = 0; ks < BK / 8; ++ks) sw[ks] = ((ks * 2 + hi) ^ swz) * 4;
+  const int a_row = (wm * TM + li) * BK;
+  const int b_row = A_FLOATS + (wn * TN + li) * BK;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int t = 0; t < MI; ++t)
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  constexpr int KH = BK / 16;   // 8-k groups per half
+  f32x4 afA[KH][MI], bfA[KH][NI], afB[KH][MI], bfB[KH][NI];
+#define PEANUT_LOAD_FRAGS(af, bf, stage, half)                                                          \
+  _Pragma("unroll") for (int j = 0; j < KH; ++j) {                                                      \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                      \
+      af[j][t] = *reinterpret_cast<const f32x4*>((stage) + a_row + t * 32 * BK + sw[(half) * KH + j]);  \
+    _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                      \
+      bf[j][u] = *reinterpret_cast<const f32x4*>((stage) + b_row + u * 32 * BK + sw[(half) * KH + j]);  \
+  }
+#define PEANUT_MFMA_HALF(af, bf)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < KH; ++j)                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
+      _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                    \
+        _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                  \
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+
+  // ---- prologue: k-tile 0 into stage 0 ----
+  PEANUT_DMA_TILE(smem);
+  PEANUT_DMA_LANDED_BARRIER();
+  PEANUT_LOAD_FRAGS(afA, bfA, smem, 0);
+
+  // steady state, per k-tile kt: DMA k-tile kt+1 into the other stage; read fragment set B (second half of kt);
+  // MFMAs on set A; wait for the DMA + barrier; read set A of kt+1; MFMAs on set B.
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    float* const nxt = smem + ((kt + 1) & 1) * STAGE;
+    const float* const cur = smem + (kt & 1) * STAGE;
+    PEANUT_DMA_TILE(nxt);
+    PEANUT_LOAD_FRAGS(afB, bfB, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afA, bfA);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_DMA_LANDED_BARRIER();
+    PEANUT_LOAD_FRAGS(afA, bfA, nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afB, bfB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {   // last k-tile
+    const float* const cur = smem + (kt & 1) * STAGE;
+    PEANUT_LOAD_FRAGS(afB, bfB, cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PEANUT_MFMA_HALF(afA, bfA);
+    PEANUT_MFMA_HALF(afB, bfB);
+  }
+  __syncthreads();
+#undef PEANUT_LOAD_FRAGS
+#undef PEANUT_MFMA_HALF
+#undef PEANUT_DMA_TILE
+#undef PEANUT_DMA_LANDED_BARRIER
+
+  conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, smem, m0, n0);
+}
+
+template <int BN, int WM, int WN>
+int launch_pw_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
+  static int slots = 0;
+  return launch_with_tail_split<decltype(&conv_pw_glds_kernel<BN, WM, WN>), 128, BN>(&conv_pw_glds_kernel<BN, WM, WN>, p, ws,
+                                                                                      ws_floats, stream, &slots);
+}
+
+}  // namespace
+
+bool conv_pw_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PEANUT_PW_GLDS");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
+// fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
+int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
+  if (bn_tile == 128) return launch_pw_t<128, 2, 2>(p, ws, ws_floats, stream);
+  if (bn_tile == 64) return launch_pw_t<64, 2, 2>(p, ws, ws_floats, stream);
+  if (bn_tile == 32) return launch_pw_t<32, 4, 1>(p, ws, ws_floats, stream);
+  return fail(-2, "launch_conv_pw: unsupported tile configuration");
+}
+
+}  // namespace peanut
