@@ -153,7 +153,25 @@ __global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict
 #pragma unroll
   for (int s = 0; s < PPM_MAX_SLOTS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* row = x + (((size_t)b * H + y) * W) * C + c;
-  for (int xx = 0; xx < W; ++xx) {
+  // six pixels per step: six independent 16-byte loads in flight per lane (the row walk is latency-bound
+  // otherwise); the bin tests are wave-uniform (kernel arguments vs the loop counter)
+  constexpr int U = 6;
+  int xx = 0;
+  for (; xx + U <= W; xx += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(row + (size_t)(xx + u) * C);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int s = 0; s < PPM_MAX_SLOTS; ++s) {
+        if (s < sl.n && xx + u >= sl.x0[s] && xx + u < sl.x1[s]) {
+          acc[s].x += v[u].x; acc[s].y += v[u].y; acc[s].z += v[u].z; acc[s].w += v[u].w;
+        }
+      }
+    }
+  }
+  for (; xx < W; ++xx) {
     const float4 v = *reinterpret_cast<const float4*>(row + (size_t)xx * C);
 #pragma unroll
     for (int s = 0; s < PPM_MAX_SLOTS; ++s) {
