@@ -118,17 +118,18 @@ int peanut_pred_debug_read(peanut_pred_t* h, const char* name, float* dst_dev, s
  * HIP event before/after each launch ON THE STREAM THE KERNELS RUN ON.  collect() synchronises
  * on those events, sums each op's elapsed time over all forwards since the last collect and
  * clears the probe.  names/kernels point to storage owned by the handle (valid until the plan
- * is dropped); kernels[i] is the kernel family op i launches (e.g. "conv_igemm_128x128x32");
- * flops[i] = algorithmic FLOPs of one launch of op i.  Returns the op count. */
+ * is dropped); kernels[i] is the kernel family op i launches (e.g. "conv_pw_glds_128x128");
+ * flops[i] = FLOPs one launch of op i executes; bytes[i] = its algorithmic HBM bytes (every operand read
+ * once, the result written once).  Returns the op count. */
 int peanut_pred_probe_enable(peanut_pred_t* h, int enable);
+int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names, const char** kernels,
+                              double* ms_sum, double* flops, double* bytes, int* n_forwards);
 /* hipGraph replay: with enable = 1 the launch sequence of a (B,H,W, in, out, apply_sigmoid, stream) combination is
- * captured on its second use and replayed as ONE hipGraphLaunch afterwards (small batches are launch-bound:
- * ~80 kernels per forward).  Up to 16 combinations are cached; growing the workspace drops them.  Results are
- * identical.  Ignored while the probe or debug taps are on, and on the legacy default stream (NULL), which HIP
+ * captured on its second use and replayed as ONE hipGraphLaunch afterwards (~85 kernels per forward; measured on
+ * MI355X the small-batch cases are bound by the dependent chain on the device, not by launches: no gain).
+ * Up to 16 combinations are cached; growing the workspace drops them.  Results are identical.  Ignored while the probe or debug taps are on, and on the legacy default stream (NULL), which HIP
  * cannot capture: pass a created stream. */
 int peanut_pred_use_graph(peanut_pred_t* h, int enable);
-int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names, const char** kernels,
-                              double* ms_sum, double* flops, int* n_forwards);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2 -- egocentric -> allocentric semantic-map projection

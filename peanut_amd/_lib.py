@@ -74,7 +74,8 @@ SIGNATURES = {
     "peanut_pred_use_graph": (C.c_int, [_P, C.c_int]),
     "peanut_map_use_graph": (C.c_int, [_P, C.c_int]),
     "peanut_pred_probe_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
-                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_int)]),
     "peanut_map_create": (C.c_int, [C.POINTER(_P), C.POINTER(MapCfgC)]),
     "peanut_map_destroy": (None, [_P]),
     "peanut_map_dims": (C.c_int, [_P, C.POINTER(C.c_int * 4)]),

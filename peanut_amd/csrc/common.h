@@ -62,6 +62,8 @@ void pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin_pad,
 void pack_conv_weights_split(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile,
                              int fp16, void* out);
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
+// true unless PEANUT_PW_GLDS=0: fp32 1x1 convs / grouped GEMMs run on the LDS-DMA kernel of conv_pw.hip
+bool conv_pw_enabled();
 
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
 // tiles per sub-grid (th x tw), tile count and its padding to whole 128-row GEMM tiles

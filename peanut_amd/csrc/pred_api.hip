@@ -38,6 +38,7 @@ struct Op {
   Act in, in2, res, out;
   bool has_in2 = false, has_res = false;
   double flops = 0;
+  double bytes = 0;            // algorithmic HBM bytes: every operand read once, the result written once
   int wino_mt_per_group = 0;   // OP_WINO_GEMM: 128-row tiles per Winograd position
 };
 
@@ -129,7 +130,10 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   return 0;
 }
 
-std::string conv_kernel_name(const ConvDesc& d) {
+// the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
+std::string conv_kernel_name(const ConvDesc& d, bool two_source = false) {
+  if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && !two_source && d.cin % 32 == 0 && conv_pw_enabled())
+    return "conv_pw_glds_128x" + std::to_string(d.bn_tile);
   return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
          std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
 }
@@ -144,13 +148,16 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     Act v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
     Act m = make_act(*ar, 1, 1, (int)(36 * m_pad), L->d.cout);
     Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
+    a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * 4;
     pl.ops.push_back(a);
     Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino); g.conv = L;
     g.in = v; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128);
     g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
+    g.bytes = 36.0 * (double)m_pad * (in.C + L->d.cout) * 4 + 36.0 * (double)L->wino_group_floats * 4;
     pl.ops.push_back(g);
     Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
+    o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (double)out.bytes * (res ? 2 : 1);
     pl.ops.push_back(o);
     ar->release(v.off, v.bytes);
     ar->release(m.off, m.bytes);
@@ -158,10 +165,12 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
   }
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = conv_kernel_name(L->d);
+  op.kernel = conv_kernel_name(L->d, in2 != nullptr);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
+  op.bytes = (double)in.bytes + (in2 ? (double)in2->bytes : 0.0) + (double)out.bytes * (res ? 2 : 1) +
+             (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4;
   pl.ops.push_back(op);
 }
 
@@ -573,7 +582,7 @@ int peanut_pred_probe_enable(peanut_pred_t* h, int enable) {
 }
 
 int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names, const char** kernels, double* ms_sum,
-                              double* flops, int* n_forwards) {
+                              double* flops, double* bytes, int* n_forwards) {
   if (!h) return fail(PEANUT_EINVAL, "null handle");
   Plan* pl = h->probe_plan;
   if (!pl || h->probe_events.empty()) { if (n_forwards) *n_forwards = 0; return 0; }
@@ -596,6 +605,7 @@ int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names,
     if (kernels) kernels[i] = pl->ops[i].kernel.c_str();
     if (ms_sum) ms_sum[i] = sum[i];
     if (flops) flops[i] = pl->ops[i].flops;
+    if (bytes) bytes[i] = pl->ops[i].bytes;
   }
   return n;
 }

@@ -139,19 +139,20 @@ class HipSegmentor:
         _lib.check(self._lib.peanut_pred_probe_enable(self._h, int(enable)), "peanut_pred_probe_enable")
 
     def probe_collect(self):
-        """-> (n_forwards, [(op name, kernel family, total ms over the forwards, flops per launch)])"""
+        """-> (n_forwards, [(op name, kernel family, total ms over the forwards, executed flops per launch,
+        algorithmic HBM bytes per launch)])"""
         n = 256
         names, kernels = (C.c_char_p * n)(), (C.c_char_p * n)()
-        ms, fl = (C.c_double * n)(), (C.c_double * n)()
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
         nf = C.c_int(0)
-        cnt = self._lib.peanut_pred_probe_collect(self._h, n, names, kernels, ms, fl, C.byref(nf))
+        cnt = self._lib.peanut_pred_probe_collect(self._h, n, names, kernels, ms, fl, by, C.byref(nf))
         if cnt < 0:
             _lib.check(cnt, "peanut_pred_probe_collect")
-        return nf.value, [(names[i].decode(), kernels[i].decode(), float(ms[i]), float(fl[i]))
+        return nf.value, [(names[i].decode(), kernels[i].decode(), float(ms[i]), float(fl[i]), float(by[i]))
                           for i in range(min(cnt, n))]
 
     def profile(self, x: torch.Tensor, repeats: int = 1):
-        """[(op name, kernel family, mean ms, flops)] of a forward, via the event probe."""
+        """[(op name, kernel family, mean ms, flops, bytes)] of a forward, via the event probe."""
         self.probe_enable(True)
         try:
             for _ in range(repeats):
@@ -159,7 +160,7 @@ class HipSegmentor:
             nf, rows = self.probe_collect()
         finally:
             self.probe_enable(False)
-        return [(a, k, ms / max(nf, 1), f) for a, k, ms, f in rows]
+        return [(a, k, ms / max(nf, 1), f, by) for a, k, ms, f, by in rows]
 
 
 def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
