@@ -15,7 +15,6 @@ The float32 operation ORDER of the reference is kept on purpose (e.g. ``((gx - x
 from __future__ import annotations
 
 import itertools
-import math
 from dataclasses import dataclass
 from typing import Tuple
 

@@ -5,7 +5,7 @@ truncated to uint8, 20 snapshots at steps 25, 50, ..., 500) and read back by
 PEANUT map datasets drive the benchmark / parity runs."""
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch

@@ -7,7 +7,6 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Iterable, List, Optional
 
-import torch
 
 from . import dist as pdist
 from .agent_helper import preprocess_obs
