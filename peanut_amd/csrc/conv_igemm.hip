@@ -41,23 +41,10 @@ namespace peanut {
 // Branch-free on purpose: out-of-image taps / rows read a 16-byte zero page instead of being predicated
 // (arithmetic select of the address -- a ?: on pointers is lowered to exec-masked code) and the iterator
 // advances with selects, so the steady-state k-loop body is ONE basic block.
-template <int BN, int BK, int A_PER, bool PW>
+template <int BN, int BK, int A_PER>
 __device__ __forceinline__ void prep_addr(const ConvKParams& p, KIter& it, const int (&a_iy0)[A_PER],
                                           const int (&a_ix0)[A_PER], const int (&a_pix)[A_PER], int a_c4,
                                           unsigned long long (&a_addr)[A_PER], const float*& b_tile) {
-  if constexpr (PW) {
-    // pointwise (1x1, pad 0, one source): every row walks its pixel's channels linearly -- one 64-bit add per
-    // pointer per k-tile instead of the tap/bounds arithmetic (a_pix holds the pixel's base float offset / 4,
-    // rows past M were clamped to a valid pixel in the prologue)
-    static_for<A_PER>([&](auto J) __attribute__((always_inline)) {
-      constexpr int j = decltype(J)::value;
-      a_addr[j] = (unsigned long long)(p.x + ((size_t)(unsigned)a_pix[j] << 2)) + ((unsigned long long)(unsigned)it.cbase << 2);
-    });
-    b_tile = it.wtile;
-    it.wtile += BN * BK;
-    it.cbase += BK;
-    return;
-  }
   const bool second = it.cbase >= p.c1;
   const float* src = second ? p.x2 : p.x;
   const int C = second ? p.c2 : p.c1, cb = second ? it.cbase - p.c1 : it.cbase;
@@ -119,7 +106,7 @@ __device__ __forceinline__ void store_tiles(float* stage, int tid, const f32x4 (
   });
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool PW = false>
+template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   constexpr int KV = BK / 4;            // f32x4 per tile row
   constexpr int LS = BK + 4;            // LDS row stride (floats)
@@ -152,16 +139,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const int idx = tid + 256 * j;
     const int row = idx / KV;
     const int m = m0 + row;
-    if constexpr (PW) {
-      const int mc = (row < BM && m < p.M) ? m : p.M - 1;   // rows past the end compute a valid row and are dropped
-      const int b = mc / p.HoWo;
-      const int rem = mc - b * p.HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      // float offset of (pixel, channel a_c4) divided by 4 (channel counts are multiples of 16): fits 32 bits up to 16 GiB
-      a_pix[j] = (int)((((size_t)(b * p.H * p.W + oy * p.stride * p.W + ox * p.stride)) * p.c1 + a_c4) >> 2);
-      a_iy0[j] = 0;
-      a_ix0[j] = 0;
-    } else if (row < BM && m < p.M) {
+    if (row < BM && m < p.M) {
       const int b = m / p.HoWo;
       const int rem = m - b * p.HoWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -185,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 
   unsigned long long a_addr[A_PER];
   const float* b_tile;
-#define PEANUT_PREP_ADDR() prep_addr<BN, BK, A_PER, PW>(p, it, a_iy0, a_ix0, a_pix, a_c4, a_addr, b_tile)
+#define PEANUT_PREP_ADDR() prep_addr<BN, BK, A_PER>(p, it, a_iy0, a_ix0, a_pix, a_c4, a_addr, b_tile)
 #define PEANUT_ISSUE_LOADS() issue_loads<BN, BK, A_PER, B_PER>(p, a_addr, b_tile, tid, ra, rb)
 #define PEANUT_STORE_TILES(stage) store_tiles<BM, BN, BK, A_PER, B_PER>(stage, tid, ra, rb)
 
@@ -333,16 +311,9 @@ void pack_conv_weights(const float* w, int cout, int cin_real, int cin_pad, int 
 
 template <int BM, int BN, int BK, int WM, int WN>
 static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
-  // pointwise fast path: 1x1, no padding, one source, and every (pixel, channel) float offset / 4 fits 32 bits
-  const bool pw = p.ntaps == 1 && p.pad == 0 && p.c2 == 0 && (size_t)p.M * p.stride * p.stride * p.c1 < ((size_t)1 << 33);
-  if (pw) {
-    static int slots_pw = 0;
-    return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN, true>), BM, BN>(
-        &conv_igemm_kernel<BM, BN, BK, WM, WN, true>, p, ws, ws_floats, stream, &slots_pw);
-  }
   static int slots = 0;
-  return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN, false>), BM, BN>(
-      &conv_igemm_kernel<BM, BN, BK, WM, WN, false>, p, ws, ws_floats, stream, &slots);
+  return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN>), BM, BN>(
+      &conv_igemm_kernel<BM, BN, BK, WM, WN>, p, ws, ws_floats, stream, &slots);
 }
 
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {

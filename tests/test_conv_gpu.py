@@ -160,3 +160,42 @@ def test_winograd_conv_matches_torch(case, precision, tol):
     if precision == "fp32":
         direct = FusedConv(w, scale, shift, padding=d, dilation=d, relu=relu, conv_algo="direct")
         assert not torch.equal(direct(xd, residual=rd), y)     # the two algorithms really are different code paths
+
+
+def test_pointwise_kernels_agree_with_and_without_lds_dma():
+    """1x1 convs and the Winograd GEMMs run on conv_pw.hip's LDS-DMA kernel by default; PEANUT_PW_GLDS=0 (read once
+    per process) sends them through the register-staged conv_igemm kernel.  Both are exact fp32 MFMA sums in the
+    same k order, so a fresh process with the switch off must reproduce this process's result bit for bit --
+    including a ragged M, a strided 1x1 and a cout that is not a tile multiple."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from peanut_amd.ops import FusedConv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(1, 31, 29, 256, 128, 1), (2, 17, 17, 256, 320, 2), (3, 13, 13, 512, 6, 1), (1, 12, 12, 64, 256, 1)]
+    outs = []
+    for i, (B, H, W, cin, cout, s) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + i)
+        x = _rand((B, H, W, cin), g)
+        w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+        outs.append(FusedConv(w, None, None, stride=s)(x.cuda()).cpu())
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(outs, os.path.join(td, "want.pt"))
+        code = f"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from peanut_amd.ops import FusedConv
+from test_conv_gpu import _rand
+want = torch.load({os.path.join(td, 'want.pt')!r})
+for i, (B, H, W, cin, cout, s) in enumerate({cases!r}):
+    g = torch.Generator().manual_seed(100 + i)
+    x = _rand((B, H, W, cin), g)
+    w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+    got = FusedConv(w, None, None, stride=s)(x.cuda()).cpu()
+    assert torch.equal(got, want[i]), i
+print("identical")
+"""
+        env = dict(os.environ, PEANUT_PW_GLDS="0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "identical" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
