@@ -15,10 +15,12 @@ from .segmentation import accumulate_instances
 
 
 def run_episode(state: Agent_State, frames: Iterable[Dict], goal_cat: int,
-                on_step: Optional[Callable[[int, Agent_State, bool], None]] = None) -> int:
+                on_step: Optional[Callable[[int, Agent_State, bool], None]] = None, detector=None) -> int:
     """frames: dicts with either a ready ``obs`` [1,C,h,w] HIP tensor or the raw tuple
-    (``rgb`` u8 [H,W,3], ``depth`` [H,W,1], instance ``masks``/``classes``/``scores``), plus
-    ``sensor_pose`` = (dx, dy, do) (peanut_agent.py:70-95).  Returns the number of predictions."""
+    (``rgb`` u8 [H,W,3], ``depth`` [H,W,1], and instance ``masks``/``classes``/``scores`` unless a ``detector``
+    -- e.g. ``peanut_amd.segmentation.HipDetector`` -- is given, which is then run on the BGR-flipped frame as
+    ``SemanticPredMaskRCNN.get_prediction`` does, segmentation.py:44-45), plus ``sensor_pose`` = (dx, dy, do)
+    (peanut_agent.py:70-95).  Returns the number of predictions."""
     args = state.args
     state.reset()
     n_pred = 0
@@ -26,6 +28,11 @@ def run_episode(state: Agent_State, frames: Iterable[Dict], goal_cat: int,
         if "obs" in fr:
             obs = fr["obs"]
         else:
+            if "masks" not in fr:
+                if detector is None:
+                    raise ValueError("frame carries no instance masks and no detector was given")
+                fr = dict(fr)
+                fr["masks"], fr["classes"], fr["scores"] = detector(fr["rgb"].flip(-1))     # RGB -> BGR
             sem = accumulate_instances(fr["masks"], fr["classes"], fr["scores"], args.num_sem_categories - 1,
                                        args.sem_pred_prob_thr, args.goal_thr, goal_cat)
             obs = preprocess_obs(fr["rgb"], fr["depth"], sem, args)

@@ -114,3 +114,37 @@ def test_replay_loop_runs_full_pipeline():
     assert float(st.local_map[1].sum()) > 0                   # something was explored
     assert float(st.local_map[4 + 1].sum()) > 0               # class-1 instance reached the map
     assert float(st.local_map[4 + 7].sum()) == 0              # score 0.5 < 0.95 was gated out
+
+
+def test_replay_loop_with_the_hip_detector():
+    """Same loop with the detector in it: frames carry only rgb + depth, a (small, seeded) MaskRCNN produces the
+    instance masks -- the map state must equal the run where the same detector's outputs were precomputed and fed
+    as canned masks (the loop adds nothing but the BGR flip of segmentation.py:44)."""
+    from oracle.agent_ref import agent_args
+    from peanut_amd.agent_state import Agent_State
+    from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+    from peanut_amd.replay import run_episode
+    from peanut_amd.segmentation import HipDetector
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    rcfg = RcnnCfg(depth=50, min_size=128, max_size=256, rpn_pre_nms_topk=60, rpn_post_nms_topk=40,
+                   detections_per_image=10, score_thresh_test=0.5)
+    det = HipDetector(rcfg, make_seeded_rcnn_state_dict(rcfg, 7))
+    args = agent_args(only_explore=0, prediction_window=240, map_size_cm=2400, sem_pred_prob_thr=0.55, goal_thr=0.6)
+    sd = make_seeded_state_dict(PredCfg(), 0)
+    g = torch.Generator().manual_seed(3)
+    raw = []
+    for i in range(4):
+        depth = torch.full((480, 640, 1), 0.3) + torch.rand((480, 640, 1), generator=g) * 0.01
+        raw.append(dict(rgb=torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).cuda(), depth=depth.cuda(),
+                        sensor_pose=[0.1, 0.0, 0.0]))
+    canned = []
+    for fr in raw:
+        m, c, s = det(fr["rgb"].flip(-1))
+        assert m.shape[1:] == (480, 640) and len(c) == len(s) == m.shape[0] > 0
+        canned.append(dict(fr, masks=m, classes=c, scores=s))
+    a = Agent_State(args, state_dict=sd)
+    b = Agent_State(args, state_dict=sd)
+    assert run_episode(a, raw, goal_cat=5, detector=det) == run_episode(b, canned, goal_cat=5) == 1
+    assert torch.equal(a.local_map, b.local_map) and torch.equal(a.target_pred, b.target_pred)
+    with pytest.raises(ValueError):
+        run_episode(a, raw, goal_cat=5)                       # no masks and no detector

@@ -2,10 +2,11 @@
 """Config 4 of BASELINE.json on synthetic frames: the full per-step perception loop of the agent
 (instance-mask accumulation -> observation formatting -> map projection -> every update_goal_freq steps
 the 720x720 map-prediction forward), one episode per rank, episodes sharded over the GPUs of the node
-like the reference's --start_ep/--end_ep.  The Mask R-CNN network itself (detectron2) is not part of
-this build: frames carry synthetic instance masks/classes/scores in its output format.
+like the reference's --start_ep/--end_ep.  By default frames carry synthetic instance masks/classes/scores in
+the detector's output format; with --detector the Mask R-CNN R-101-FPN itself (peanut_amd.rcnn, seeded random
+weights, score threshold lowered so that it returns detections) runs on every 640x480 frame as well.
 
-    python tools/bench_pipeline.py [--episodes 8] [--frames 100]
+    python tools/bench_pipeline.py [--episodes 8] [--frames 100] [--detector]
     python -m torch.distributed.run --nproc-per-node N tools/bench_pipeline.py ...
 """
 import argparse
@@ -46,6 +47,7 @@ def main():
     ap.add_argument("--episodes", type=int, default=8)
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--detector", action="store_true", help="run Mask R-CNN on every frame instead of canned masks")
     a = ap.parse_args()
     rank, local_rank, world = pdist.init_process_group()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -54,20 +56,30 @@ def main():
     st = Agent_State(args, state_dict=make_seeded_state_dict(PredCfg(), 0))
     mine = episode_shard(a.episodes)
     eps = {e: synth_episode(1000 + e, a.frames, dev) for e in mine}
+    det = None
+    if a.detector:
+        from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+        from peanut_amd.segmentation import HipDetector
+        rcfg = RcnnCfg(score_thresh_test=0.5)
+        det = HipDetector(rcfg, make_seeded_rcnn_state_dict(rcfg, 0), device=dev, precision=a.precision)
+        for fr in (f for e in mine for f in eps[e]):
+            for k in ("masks", "classes", "scores"):
+                fr.pop(k)
     if mine:
-        run_episode(st, eps[mine[0]][:12], goal_cat=3)     # warm-up (plans, workspaces)
+        run_episode(st, eps[mine[0]][:12], goal_cat=3, detector=det)     # warm-up (plans, workspaces)
     torch.cuda.synchronize()
     pdist.barrier()
     t0 = time.perf_counter()
     n_pred = 0
     for e in mine:
-        n_pred += run_episode(st, eps[e], goal_cat=3)
+        n_pred += run_episode(st, eps[e], goal_cat=3, detector=det)
     torch.cuda.synchronize()
     pdist.barrier()
     dt = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
     if rank == 0:
         steps = a.episodes * a.frames
-        print(json.dumps({"workload": f"config 4: {a.episodes} synthetic episodes x {a.frames} frames, seg-accumulate + "
+        seg = "Mask R-CNN R-101-FPN inference + mask accumulation" if a.detector else "seg-accumulate (canned instance masks)"
+        print(json.dumps({"workload": f"config 4: {a.episodes} synthetic episodes x {a.frames} frames, {seg} + "
                                       "obs formatting + map projection per step, 720x720 map prediction every 10 steps",
                           "n_gpus": world, "steps_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
                           "predictions_rank0": n_pred, "precision": a.precision}))
