@@ -248,3 +248,26 @@ def test_nms_segments_bit_exact():
     got = nms_keep_segments(torch.cat(boxes).cuda(), torch.cat(cats).cuda(), counts, 0.6).cpu()
     assert torch.equal(ref, got)
     assert 0 < int(got.sum()) < len(got)
+
+
+def test_inference_at_the_agent_frame_geometry():
+    """The real geometry of the agent's frames (480x640 -> 800x1067, padded to 800x1088, five FPN levels down to
+    13x17; yaml :28-30) with the default anchor/pooler settings, R-50 body and reduced proposal counts so that the
+    loop-form oracle stays fast.  Same detections, boxes within 0.05 px, masks IoU >= 0.98."""
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import MaskRCNN
+    from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+    cfg = RcnnCfg(depth=50, rpn_pre_nms_topk=200, rpn_post_nms_topk=60, detections_per_image=12, score_thresh_test=0.5)
+    sd = make_seeded_rcnn_state_dict(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (1, 480, 640, 3), generator=g, dtype=torch.uint8)
+    ref = rcnn_ref.inference(sd, img, cfg)[0]
+    got = MaskRCNN(cfg, sd).inference(img.cuda())[0]
+    assert len(ref["scores"]) == 12
+    assert got["pred_classes"].cpu().tolist() == ref["pred_classes"].tolist()
+    assert (got["scores"].cpu() - ref["scores"]).abs().max().item() <= 1e-4
+    assert (got["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max().item() <= 5e-2
+    gm, rm = got["pred_masks"].cpu(), ref["pred_masks"]
+    assert gm.shape == rm.shape == (12, 480, 640)
+    inter, union = (gm & rm).sum().item(), (gm | rm).sum().item()
+    assert union > 0 and inter / union >= 0.98
