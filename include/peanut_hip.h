@@ -67,6 +67,13 @@ typedef struct peanut_pred_cfg {
 #define PEANUT_PREC_FP32 0
 #define PEANUT_PREC_BF16X3 1
 #define PEANUT_PREC_FP16X3 2
+/* BF16X6: fp32 emulated on the bf16 matrix cores.  Every fp32 value is held as three bf16 pieces (3 x 8 = 24
+ * mantissa bits: the split is exact) and every product is rebuilt from the six piece products that matter
+ * (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped ones are <= 2^-24 relative, the size of fp32's own
+ * product rounding) with fp32 accumulation -- fp32-class results, measured on a par with the fp32 MFMA path.  The
+ * 1x1 convs and the Winograd GEMMs use it (csrc/gemm_sx.hip, operands pre-split by their producers); the other
+ * layers stay on the fp32 MFMA kernel. */
+#define PEANUT_PREC_BF16X6 3
 
 /* One entry of an mmcv/PyTorch state dict (HOST memory, fp32, contiguous, OIHW for convs). */
 typedef struct peanut_tensor {

@@ -33,6 +33,8 @@ struct ConvDesc {
   const float* w_packed;   // device
   const float* scale;      // device [cout_pad]
   const float* shift;      // device [cout_pad]
+  const void* w_s;         // device: S-packed weights of a pointwise layer (gemm_sx.hip), or null
+  int s_planes;            // bf16 pieces per value in w_s and in S activations: 2 (bf16x3) or 3 (bf16x6)
 };
 
 struct ConvArgs {
@@ -46,7 +48,13 @@ struct ConvArgs {
   float* ws;          // optional scratch for tail split-K partial tiles (see conv_common.h)
   size_t ws_floats;
   int mt_per_group;        // grouped GEMM: 128-row m-tile mt reads weight block mt / mt_per_group (0 = single block)
-  size_t w_group_stride;   // floats between weight blocks
+  size_t w_group_stride;   // floats between weight blocks (bytes for S-packed weights)
+  // S-format operands (see gemm_sx.hip): A read from xs instead of x; optional S copy of the output
+  const unsigned short* xs;
+  int xs_rows;
+  unsigned short* ys;
+  int ys_rows;
+  int skip_f32;
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 partial 128x128 tiles and then some
@@ -70,11 +78,21 @@ bool conv_pw_enabled();
 void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad);
 // host: OIHW 3x3 weights -> U [36][cout][cin]
 void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out);
-// x [B,H,W,C] -> V [36][m_pad][C]
-int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s);
-// Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res)
-int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y, int B, int H,
-                       int W, int C, int dil, int relu, hipStream_t s);
+// x [B,H,W,C] -> V [36][m_pad][C] fp32, or (Vs != null) the same tensor as `planes` bf16 pieces in the S layout
+int launch_wino_input(const float* x, float* V, unsigned short* Vs, int planes, int B, int H, int W, int C, int dil,
+                      hipStream_t s);
+// Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res); optional S copy ys (rows padded to
+// ys_rows); skip_f32 = 1 leaves y untouched
+int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
+                       unsigned short* ys, int ys_rows, int planes, int skip_f32, int B, int H, int W, int C, int dil, int relu,
+                       hipStream_t s);
+
+// ---- emulated-fp32 GEMM on pre-split bf16 operands (gemm_sx.hip) ----
+size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
+void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
+// bytes of an S tensor of `rows` x `channels`
+inline size_t s_tensor_bytes(size_t rows, int channels, int planes) { return (rows + 127) / 128 * 128 * (size_t)channels * 2 * planes; }
+inline int s_rows_pad(size_t rows) { return (int)((rows + 127) / 128 * 128); }
 
 // ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----
 int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s);

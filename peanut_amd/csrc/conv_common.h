@@ -25,7 +25,40 @@ struct ConvKParams {
   // grouped GEMM (Winograd positions): m-tile mt uses the weight block (mt / mt_per_group); 0 = one block
   int mt_per_group;
   long long w_group_stride;   // floats between consecutive weight blocks
+  // split-plane ("S") operands of the emulated-fp32 GEMM (gemm_sx.hip): every fp32 value as s_planes bf16 pieces
+  // (x = hi + mid (+ lo), each piece the bf16 rounding of what is left), laid out
+  // [16-channel chunk][plane][row][16 bf16] with the row count padded to a multiple of 128
+  const unsigned short* xs;   // A operand in S form (null: fp32 A in x)
+  int xs_rows;                // padded row count of xs
+  unsigned short* ys;         // optional S copy of the output for a following GEMM (needs cout % 16 == 0)
+  int ys_rows;
+  int s_planes;               // 2 (bf16x3) or 3 (bf16x6)
+  int skip_f32;               // 1: do not write y (the consumer reads ys only)
 };
+
+// next bf16 piece of v (round to nearest even) and the remainder; v - piece is exact in fp32 (the piece agrees
+// with v in its leading bits), so the pieces of a value sum to it exactly as long as nothing underflows
+__device__ __forceinline__ unsigned short bf16_piece(float& v) {
+  unsigned bits = __float_as_uint(v);
+  bits += 0x7fffu + ((bits >> 16) & 1u);
+  bits &= 0xffff0000u;
+  v -= __uint_as_float(bits);
+  return (unsigned short)(bits >> 16);
+}
+
+// one fp32 quad (channels n..n+3 of row m) -> its bf16 planes in an S tensor (8-byte stores)
+__device__ __forceinline__ void store_s_quad(unsigned short* ys, int rows_pad, int planes, int m, int n, f32x4 v) {
+  const int g = n >> 4, e = n & 15;
+  unsigned short* dst = ys + ((size_t)(g * planes) * rows_pad + m) * 16 + e;
+  const size_t plane_stride = (size_t)rows_pad * 16;
+  for (int q = 0; q < planes; ++q) {
+    unsigned short h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float t = v[i]; h[i] = bf16_piece(t); v[i] = t; }
+    *reinterpret_cast<uint2*>(dst + (size_t)q * plane_stride) =
+        make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+  }
+}
 
 template <int I>
 struct IC { static constexpr int value = I; };
@@ -48,6 +81,8 @@ int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, float* ws, si
 // conv_pw.hip: fp32 pointwise convs / grouped GEMMs with LDS-DMA staging (PEANUT_PW_GLDS=0 disables)
 bool conv_pw_enabled();
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream);
+// gemm_sx.hip: pointwise layer / grouped GEMM on S-format operands (p.xs, p.w = S-packed weights, nkt = cin / 16)
+int launch_gemm_sx(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
 
 // Work decomposition of one launch.
 //  * XCD-aware (guide T1): workgroup b runs on XCD b % 8 (observed, used for speed only); every XCD gets
@@ -137,7 +172,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
           if (n < p.cout) {
             if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<f32x4*>(p.y + o) = v;
+            if (!p.skip_f32) *reinterpret_cast<f32x4*>(p.y + o) = v;
+            if (p.ys) *reinterpret_cast<f32x4*>(smem + row * CS + c4) = v;   // finished values for the S pass below
           }
         } else {
 #pragma unroll
@@ -148,6 +184,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
               if (p.relu) x = fmaxf(x, 0.f);
               p.y[o + e] = x;
             }
+          }
+        }
+      }
+      if (p.ys) {
+        // S copy of the slab: thread -> (row, 8-channel half of a 16-channel chunk), half fastest, so that a wave's
+        // 16-byte piece stores cover 32 consecutive rows of one (chunk, plane): 1 KiB runs of the S layout
+        __syncthreads();
+        constexpr int HALVES = BN / 8;
+        for (int it = tid; it < ER * HALVES; it += 256) {
+          const int half = it & 1, row = (it >> 1) % ER, hc = (it >> 1) / ER;
+          const int col = hc * 16 + half * 8;
+          const int m = m0 + ep * ER + row, nn = n0 + col;
+          if (m >= p.M || nn >= p.cout) continue;
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * CS + col);
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * CS + col + 4);
+          unsigned short* dst = p.ys + ((size_t)((nn >> 4) * p.s_planes) * p.ys_rows + m) * 16 + half * 8;
+          const size_t plane_stride = (size_t)p.ys_rows * 16;
+          for (int q = 0; q < p.s_planes; ++q) {
+            unsigned short h[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float a = v0[i], b = v1[i];
+              h[i] = bf16_piece(a); h[4 + i] = bf16_piece(b);
+              v0[i] = a; v1[i] = b;
+            }
+            *reinterpret_cast<uint4*>(dst + (size_t)q * plane_stride) =
+                make_uint4((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                           (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16));
           }
         }
       }
@@ -201,7 +265,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
       if (n < p.cout) {
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(p.y + o) = v;
+        if (!p.skip_f32) *reinterpret_cast<f32x4*>(p.y + o) = v;
+        if (p.ys) store_s_quad(p.ys, p.ys_rows, p.s_planes, m, n, v);
       }
     } else {
       for (int e = 0; e < 4; ++e) {

@@ -319,7 +319,7 @@ static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   if (a.c1 + a.c2 != d.cin) return fail(-2, "launch_conv: c1 + c2 != cin");
   if (a.c1 % d.bk != 0 || (a.c2 % d.bk) != 0) return fail(-2, "launch_conv: channel split not a multiple of BK");
-  ConvKParams p;
+  ConvKParams p{};
   p.x = a.x; p.x2 = a.x2 ? a.x2 : a.x; p.w = d.w_packed; p.scale = d.scale; p.shift = d.shift;
   p.res = a.res; p.y = a.y;
   p.zeros = zero_page();
@@ -335,6 +335,14 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride;
+  p.ys = a.ys; p.ys_rows = a.ys_rows; p.s_planes = d.s_planes; p.skip_f32 = a.skip_f32;
+  if (p.ys && (d.cout % 16 || (d.s_planes != 2 && d.s_planes != 3))) return fail(-2, "launch_conv: S output needs cout % 16 == 0 and 2 or 3 planes");
+  if (a.xs) {   // emulated-fp32 GEMM on pre-split operands
+    if (!d.w_s) return fail(-2, "launch_conv: layer has no S-packed weights");
+    p.xs = a.xs; p.xs_rows = a.xs_rows; p.w = static_cast<const float*>(d.w_s);
+    p.nkt = d.cin / 16;
+    return launch_gemm_sx(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
+  }
   if (d.mode != 0) {
     if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
     return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);

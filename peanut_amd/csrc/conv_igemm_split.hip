@@ -260,56 +260,8 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvKParams
 #undef SPLIT_ISSUE_LOADS
 #undef SPLIT_STORE_TILES
 
-  // ---- epilogue (identical to conv_igemm.hip): accumulators -> LDS -> 16-byte row pieces ----
-  float* smem = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-  for (int t = 0; t < MI; ++t)
-#pragma unroll
-    for (int u = 0; u < NI; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * TM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        smem[row * CS + wn * TN + u * 32 + li] = acc[t][u][r];
-      }
-  __syncthreads();
-  constexpr int NV = BN / 4;
-  constexpr int ROWS_PER_PASS = 256 / NV;
-  const int c4 = (tid % NV) * 4, r0 = tid / NV;
-  const int n = n0 + c4;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-  const bool vec_ok = (p.cout & 3) == 0;
-  if (wk.item >= 0) {   // split-K part: raw accumulators (conv_splitk_reduce_kernel finishes the tile)
-    float* dst = p.partial + (size_t)wk.item * (BM * BN);
-    for (int row = r0; row < BM; row += ROWS_PER_PASS)
-      *reinterpret_cast<f32x4*>(dst + row * BN + c4) = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
-    return;
-  }
-#pragma unroll 4
-  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
-    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
-    v = v * sc + sh;
-    const size_t o = (size_t)m * p.cout + n;
-    if (vec_ok) {
-      if (n < p.cout) {
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(p.y + o) = v;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e < p.cout) {
-          float x = v[e];
-          if (p.res) x += p.res[o + e];
-          if (p.relu) x = fmaxf(x, 0.f);
-          p.y[o + e] = x;
-        }
-      }
-    }
-  }
+  // ---- epilogue shared with conv_igemm.hip (whole tile staged at once: the 64 KiB of pipeline buffers hold it) ----
+  conv_epilogue<BM, BN, WM, WN, 1>(p, wk, acc, reinterpret_cast<float*>(smem_raw), m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------

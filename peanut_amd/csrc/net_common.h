@@ -91,7 +91,14 @@ struct ConvLayer {
   ConvDesc wino{};
   size_t wino_group_floats = 0;
   DevBuf wino_w, wino_ss;
+  // S-packed bf16 pieces of the weights (gemm_sx.hip) for the emulated-fp32 modes: of the layer itself when it is
+  // pointwise (d.w_s), of the 36 Winograd position matrices (wino.w_s, wino_group_bytes apart)
+  DevBuf w_s, wino_w_s;
+  size_t wino_group_bytes = 0;
 };
+
+// bf16 pieces per value of the S-format operands in a precision mode (0: the mode has none)
+inline int s_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : 0); }
 
 inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
                 int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision) {
@@ -100,8 +107,10 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
   conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
-  if (precision != 0 && cin_pad % 32 == 0) d.bk = 32;        // split kernels are BK = 32 only
-  d.mode = (precision != 0 && d.bk == 32) ? precision : 0;   // 16-channel (stem.0) layers stay fp32
+  const bool split_mode = precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3;
+  if (split_mode && cin_pad % 32 == 0) d.bk = 32;            // split kernels are BK = 32 only
+  d.mode = (split_mode && d.bk == 32) ? precision : 0;       // 16-channel (stem.0) layers stay fp32; so does every
+                                                             // non-pointwise layer of the bf16x6 mode
   L.cin_real = cin;
   const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);   // same byte count in every mode
   std::vector<float> packed(nw);
@@ -120,13 +129,22 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.w_packed = (const float*)L.w.p;
   d.scale = (const float*)L.ss.p;
   d.shift = (const float*)L.ss.p + d.cout_pad;
+  d.s_planes = s_planes_of(precision);
+  d.w_s = nullptr;
+  if (d.s_planes && kh == 1 && kw == 1 && pad == 0 && cin_pad % 16 == 0) {   // pointwise: may run on gemm_sx.hip
+    std::vector<unsigned char> ps(sx_packed_bytes(cin_pad, cout, d.bn_tile, d.s_planes));
+    pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, ps.data());
+    if ((rc = L.w_s.ensure(ps.size()))) return rc;
+    PEANUT_HIP_CHECK(hipMemcpy(L.w_s.p, ps.data(), ps.size(), hipMemcpyHostToDevice));
+    d.w_s = L.w_s.p;
+  }
   return 0;
 }
 
 // Adds the Winograd form to an uploaded stride-1 3x3 layer (keeps the direct form for the two-source path).
 inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int pad, int dil, int precision) {
   return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= 256 && cin_pad % 32 == 0 && cout % 4 == 0 &&
-         cout >= 64 && precision != 2;   // fp16x3: the 1/24-scaled weight tails would underflow
+         cout >= 64 && precision != PEANUT_PREC_FP16X3;   // fp16x3: the 1/24-scaled weight tails would underflow
 }
 
 inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int cin_pad, int precision) {
@@ -135,7 +153,9 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
   g.bk = 32;
   g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
-  g.mode = precision;
+  g.mode = (precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3) ? precision : 0;
+  g.s_planes = s_planes_of(precision);
+  g.w_s = nullptr;
   const size_t gf = conv_packed_floats(cin_pad, cout, 1, 1, g.bn_tile);
   std::vector<float> U((size_t)36 * cout * cin);
   wino_transform_weights(w_oihw, cout, cin, U.data());
@@ -156,6 +176,16 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   g.scale = (const float*)L.wino_ss.p;
   g.shift = (const float*)L.wino_ss.p + g.cout_pad;
   L.wino_group_floats = gf;
+  if (g.s_planes && cin_pad % 16 == 0) {
+    const size_t gb = sx_packed_bytes(cin_pad, cout, g.bn_tile, g.s_planes);
+    std::vector<unsigned char> ps(36 * gb);
+    for (int pos = 0; pos < 36; ++pos)
+      pack_weights_sx(U.data() + (size_t)pos * cout * cin, cout, cin, cin_pad, g.bn_tile, g.s_planes, ps.data() + pos * gb);
+    if ((rc = L.wino_w_s.ensure(ps.size()))) return rc;
+    PEANUT_HIP_CHECK(hipMemcpy(L.wino_w_s.p, ps.data(), ps.size(), hipMemcpyHostToDevice));
+    g.w_s = L.wino_w_s.p;
+    L.wino_group_bytes = gb;
+  }
   L.has_wino = true;
   return 0;
 }
@@ -177,14 +207,14 @@ inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_
   long long n_tiles, m_pad;
   wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad);
   if (36 * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
-  if ((rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s))) return rc;
+  if ((rc = launch_wino_input(a.x, wino_v, nullptr, 0, a.B, a.H, a.W, L.d.cin, L.d.dil, s))) return rc;
   ConvArgs g{};
   g.x = wino_v; g.y = wino_m;
   g.B = 1; g.H = 1; g.W = (int)(36 * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
   g.ws = a.ws; g.ws_floats = a.ws_floats;
   g.mt_per_group = (int)(m_pad / 128); g.w_group_stride = L.wino_group_floats;
   if ((rc = launch_conv(L.wino, g, s))) return rc;
-  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s);
+  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, nullptr, 0, 0, 0, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s);
 }
 
 // ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----

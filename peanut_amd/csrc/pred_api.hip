@@ -28,6 +28,13 @@ int fail(int code, const std::string& msg) {
 
 namespace {
 
+// an activation in the S layout of gemm_sx.hip
+struct SAct {
+  size_t off = 0, bytes = 0;
+  int rows_pad = 0;
+  bool valid = false;
+};
+
 enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE, OP_WINO_IN, OP_WINO_GEMM, OP_WINO_OUT };
 
 struct Op {
@@ -40,6 +47,8 @@ struct Op {
   double flops = 0;
   double bytes = 0;            // algorithmic HBM bytes: every operand read once, the result written once
   int wino_mt_per_group = 0;   // OP_WINO_GEMM: 128-row tiles per Winograd position
+  SAct in_s, out_s;            // S-format (pre-split bf16 pieces, gemm_sx.hip) copies of the input / output, if any
+  bool skip_f32 = false;       // the fp32 output is not written (only out_s is consumed)
 };
 
 struct Plan {
@@ -131,46 +140,76 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
 }
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
-std::string conv_kernel_name(const ConvDesc& d, bool two_source = false) {
+std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_input = false) {
+  if (s_input) return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
   if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && !two_source && d.cin % 32 == 0 && conv_pw_enabled())
     return "conv_pw_glds_128x" + std::to_string(d.bn_tile);
   return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
          std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
 }
 
+SAct make_sact(Arena& ar, size_t rows, int channels, int planes) {
+  SAct t;
+  t.rows_pad = s_rows_pad(rows);
+  t.bytes = s_tensor_bytes(rows, channels, planes);
+  t.off = ar.alloc(t.bytes);
+  t.valid = true;
+  return t;
+}
+
+// One conv layer into the plan.
+//   in_s   S copy of the input: a pointwise layer with S-packed weights then runs on gemm_sx.hip
+//   out_s  where the epilogue (or the Winograd output transform) shall also write the S form of the result
+//   skip_f32  the fp32 result has no consumer (out.off is then never written)
 // `ar` is only needed for layers that carry a Winograd form (scratch for the transformed tensors).
-void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr) {
+void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr,
+               const SAct* in_s = nullptr, const SAct* out_s = nullptr, bool skip_f32 = false) {
   if (L->has_wino && !in2 && ar) {
     // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
     int th, tw;
     long long n_tiles, m_pad;
     wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad);
-    Act v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
+    const bool s_gemm = L->wino.w_s != nullptr;
+    Act v;   // fp32 V (unused in the S form)
+    SAct vs;
+    if (s_gemm) vs = make_sact(*ar, (size_t)(36 * m_pad), in.C, L->wino.s_planes);
+    else v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
     Act m = make_act(*ar, 1, 1, (int)(36 * m_pad), L->d.cout);
     Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
-    a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * 4;
+    a.out_s = vs;
+    a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0);
     pl.ops.push_back(a);
-    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino); g.conv = L;
-    g.in = v; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128);
+    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, s_gemm); g.conv = L;
+    g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.in_s = vs; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128);
     g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
-    g.bytes = 36.0 * (double)m_pad * (in.C + L->d.cout) * 4 + 36.0 * (double)L->wino_group_floats * 4;
+    g.bytes = 36.0 * (double)m_pad * (in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0) + L->d.cout * 4.0) +
+              36.0 * (s_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
     pl.ops.push_back(g);
     Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
-    o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (double)out.bytes * (res ? 2 : 1);
+    if (out_s) o.out_s = *out_s;
+    o.skip_f32 = skip_f32;
+    o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (skip_f32 ? 0.0 : (double)out.bytes) + (res ? (double)out.bytes : 0.0) +
+              (out_s ? (double)out_s->bytes : 0.0);
     pl.ops.push_back(o);
-    ar->release(v.off, v.bytes);
+    if (s_gemm) ar->release(vs.off, vs.bytes); else ar->release(v.off, v.bytes);
     ar->release(m.off, m.bytes);
     return;
   }
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = conv_kernel_name(L->d, in2 != nullptr);
+  const bool s_in = in_s && in_s->valid && L->d.w_s && !in2;
+  op.kernel = conv_kernel_name(L->d, in2 != nullptr, s_in);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
+  if (s_in) op.in_s = *in_s;
+  if (out_s) op.out_s = *out_s;
+  op.skip_f32 = skip_f32;
   op.flops = conv_flops(L, out);
-  op.bytes = (double)in.bytes + (in2 ? (double)in2->bytes : 0.0) + (double)out.bytes * (res ? 2 : 1) +
-             (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4;
+  op.bytes = (s_in ? (double)in_s->bytes : (double)in.bytes) + (in2 ? (double)in2->bytes : 0.0) +
+             (skip_f32 ? 0.0 : (double)out.bytes) + (res ? (double)out.bytes : 0.0) + (out_s ? (double)out_s->bytes : 0.0) +
+             (s_in ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
+                   : (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4);
   pl.ops.push_back(op);
 }
 
@@ -206,32 +245,48 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     rel(x);
     x = y;
   }
-  // residual stages
+  // residual stages.  In the emulated-fp32 modes (S-format operands, gemm_sx.hip) the pointwise convs read the bf16
+  // pieces their producers wrote: block outputs carry both forms (fp32 for the identity / pooling, S for the next
+  // block's conv1 and downsample), conv2's output only the S form (its single consumer is conv3).
+  const int planes = s_planes_of(h->cfg.precision);
+  SAct xs;   // S copy of the running activation x (invalid until a conv epilogue has produced one)
   for (size_t li = 0; li < h->layers.size(); ++li) {
-    for (const auto& blk : h->layers[li]) {
+    for (size_t bi = 0; bi < h->layers[li].size(); ++bi) {
+      const auto& blk = h->layers[li][bi];
       const ConvDesc& d2 = blk.c2->d;
+      const bool last_block = li + 1 == h->layers.size() && bi + 1 == h->layers[li].size();
       Act t1 = make_act(ar, B, x.H, x.W, blk.c1->d.cout);
-      push_conv(*pl, blk.c1, x, nullptr, nullptr, t1);
-      Act t2 = make_act(ar, B, conv_out_dim(x.H, 3, d2.stride, d2.pad, d2.dil),
-                        conv_out_dim(x.W, 3, d2.stride, d2.pad, d2.dil), d2.cout);
-      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2, &ar);
+      push_conv(*pl, blk.c1, x, nullptr, nullptr, t1, nullptr, &xs);
+      const int h2 = conv_out_dim(x.H, 3, d2.stride, d2.pad, d2.dil), w2 = conv_out_dim(x.W, 3, d2.stride, d2.pad, d2.dil);
+      const bool t2_s = planes && blk.c3->d.w_s && d2.cout % 16 == 0;   // conv3 can take its input as S
+      Act t2;
+      SAct t2s;
+      if (t2_s) { t2s = make_sact(ar, (size_t)B * h2 * w2, d2.cout, planes); t2.B = B; t2.H = h2; t2.W = w2; t2.C = d2.cout; }
+      else t2 = make_act(ar, B, h2, w2, d2.cout);
+      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2, &ar, nullptr, t2_s ? &t2s : nullptr, t2_s);
       rel(t1);
       Act idn = x;
       bool own_idn = false;
       if (blk.down) {
-        idn = make_act(ar, B, t2.H, t2.W, blk.down->d.cout);
-        push_conv(*pl, blk.down, x, nullptr, nullptr, idn);
+        idn = make_act(ar, B, h2, w2, blk.down->d.cout);
+        push_conv(*pl, blk.down, x, nullptr, nullptr, idn, nullptr, &xs);
         own_idn = true;
       }
-      Act y = make_act(ar, B, t2.H, t2.W, blk.c3->d.cout);
-      push_conv(*pl, blk.c3, t2, nullptr, &idn, y);  // BN3 + identity + ReLU fused (resnet.py:289-305)
-      rel(t2);
+      Act y = make_act(ar, B, h2, w2, blk.c3->d.cout);
+      SAct ys;
+      const bool y_s = planes && !last_block && blk.c3->d.cout % 16 == 0;   // next block's conv1 (+ downsample) read it
+      if (y_s) ys = make_sact(ar, (size_t)B * h2 * w2, blk.c3->d.cout, planes);
+      push_conv(*pl, blk.c3, t2, nullptr, &idn, y, nullptr, &t2s, y_s ? &ys : nullptr);  // BN3 + identity + ReLU fused (resnet.py:289-305)
+      if (t2_s) ar.release(t2s.off, t2s.bytes); else rel(t2);
       if (own_idn) rel(idn);
       rel(x);
+      if (xs.valid) ar.release(xs.off, xs.bytes);
       x = y;
+      xs = ys;
     }
     pl->named["layer" + std::to_string(li + 1)] = x;
   }
+  if (xs.valid) { ar.release(xs.off, xs.bytes); xs = SAct(); }
   // PSP head
   int nbins = 0;
   for (int i = 0; i < h->cfg.n_pool_scales; ++i) nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
@@ -316,7 +371,12 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
 static size_t plan_high_water(const Plan& pl) {
   size_t hw = 0;
   auto upd = [&](const Act& a) { if (a.bytes && a.off + Arena::round_up(a.bytes) > hw) hw = a.off + Arena::round_up(a.bytes); };
-  for (const auto& op : pl.ops) { upd(op.in); upd(op.in2); upd(op.res); upd(op.out); }
+  auto upd_s = [&](const SAct& a) { if (a.valid && a.off + Arena::round_up(a.bytes) > hw) hw = a.off + Arena::round_up(a.bytes); };
+  for (const auto& op : pl.ops) {
+    upd(op.in); upd(op.in2); upd(op.res);
+    if (!op.skip_f32) upd(op.out);
+    upd_s(op.in_s); upd_s(op.out_s);
+  }
   for (const auto& kv : pl.named) upd(kv.second);
   upd(pl.splitk);
   return hw;
@@ -351,21 +411,34 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       a.c1 = op.in.C; a.c2 = op.has_in2 ? op.in2.C : 0;
       a.Ho = op.out.H; a.Wo = op.out.W;
       a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
+      if (op.in_s.valid) { a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad; }
+      if (op.out_s.valid) { a.ys = (unsigned short*)(base + op.out_s.off); a.ys_rows = op.out_s.rows_pad; }
+      a.skip_f32 = op.skip_f32;
       return launch_conv(op.conv->d, a, s);
     }
     case OP_WINO_IN:
-      return launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s);
+      return launch_wino_input(P(op.in), op.out_s.valid ? nullptr : P(op.out),
+                               op.out_s.valid ? (unsigned short*)(base + op.out_s.off) : nullptr, op.conv->wino.s_planes, op.in.B,
+                               op.in.H, op.in.W, op.in.C, op.conv->d.dil, s);
     case OP_WINO_GEMM: {
       ConvArgs a{};
       a.x = P(op.in); a.y = P(op.out);
       a.B = 1; a.H = 1; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = 1; a.Wo = op.in.W;
       a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
-      a.mt_per_group = op.wino_mt_per_group; a.w_group_stride = op.conv->wino_group_floats;
+      a.mt_per_group = op.wino_mt_per_group;
+      if (op.in_s.valid) {
+        a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad;
+        a.w_group_stride = op.conv->wino_group_bytes;
+      } else {
+        a.w_group_stride = op.conv->wino_group_floats;
+      }
       return launch_conv(op.conv->wino, a, s);
     }
     case OP_WINO_OUT:
       return launch_wino_output(P(op.in), op.conv->d.scale, op.conv->d.shift, op.has_res ? P(op.res) : nullptr, P(op.out),
-                                op.out.B, op.out.H, op.out.W, op.out.C, op.conv->d.dil, op.conv->d.relu, s);
+                                op.out_s.valid ? (unsigned short*)(base + op.out_s.off) : nullptr, op.out_s.rows_pad,
+                                op.conv->d.s_planes, op.skip_f32 ? 1 : 0, op.out.B, op.out.H, op.out.W, op.out.C,
+                                op.conv->d.dil, op.conv->d.relu, s);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:
@@ -396,7 +469,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
   if (cfg->in_channels < 1 || cfg->num_classes < 1 || cfg->num_classes > 32)
     return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
   if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
-  if (cfg->precision < 0 || cfg->precision > 2) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3}");
+  if (cfg->precision < 0 || cfg->precision > 3) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT)
     return fail(PEANUT_EINVAL, "conv_algo must be PEANUT_ALGO_{AUTO,DIRECT}");
   auto h = std::make_unique<peanut_pred>();

@@ -145,10 +145,11 @@ def test_golden_vectors(model_and_sd, golden_dir):
         assert err <= TOL, f"{case}: max err {err:.3e}"
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("fp16x3", 1e-4)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("fp16x3", 1e-4), ("bf16x6", 5e-5)])
 def test_split_precision_forward_within_contract(precision, tol, golden_dir):
     """Split-product modes (3 x 16-bit MFMA per fp32 product, fp32 accumulate) must stay inside the
-    north_star bound (1e-3) with margin, on config 1 (240x240 golden vector from the reference)."""
+    north_star bound (1e-3) with margin, on config 1 (240x240 golden vector from the reference).  bf16x6 (three bf16
+    pieces per value, six products per fp32 product) is an fp32 emulation: it is held to the fp32 path's own level."""
     from peanut_amd.prediction import PEANUT_Prediction_Model
     from peanut_amd.weights import PredCfg, make_seeded_state_dict
     z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
@@ -237,3 +238,30 @@ def test_graph_replay_is_bit_identical(model_and_sd):
     assert torch.equal(g.get_prediction_batch(x, apply_sigmoid=True), m.get_prediction_batch(x, apply_sigmoid=True))
     g.model.use_graph(False)
     assert torch.equal(g.get_prediction_batch(x, apply_sigmoid=True), m.get_prediction_batch(x, apply_sigmoid=True))
+
+
+def test_bf16x6_emulation_is_fp32_class(model_and_sd, golden_dir):
+    """precision='bf16x6' (csrc/gemm_sx.hip): three bf16 pieces per fp32 value written by the producers (conv
+    epilogues, Winograd transforms) in the S layout, six MFMA products per fp32 product, fp32 accumulation.  It must
+    sit at the fp32 path's own distance from the reference golden logits (both ~1e-5), be deterministic, and cover
+    strided / odd-sized / 25-channel inputs, where S tensors have ragged last row tiles."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    m, sd, cfg = model_and_sd
+    x6 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="bf16x6")
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    worst6 = worst32 = 0.0
+    for case in ("cfg1_240", "b2_96", "odd_100", "rect_72x104"):
+        x = torch.from_numpy(z[f"{case}/input"].astype(np.float32)).cuda()
+        ref = torch.from_numpy(z[f"{case}/logits"])
+        a = x6.get_prediction_batch(x, apply_sigmoid=False)
+        assert torch.equal(a, x6.get_prediction_batch(x, apply_sigmoid=False)), case
+        worst6 = max(worst6, (a.cpu() - ref).abs().max().item())
+        worst32 = max(worst32, (m.get_prediction_batch(x, apply_sigmoid=False).cpu() - ref).abs().max().item())
+    cfg25 = PredCfg(in_channels=25)
+    m25 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg25, 1), cfg=cfg25,
+                                  precision="bf16x6")
+    x = torch.from_numpy(z["cin25_64/input"].astype(np.float32)).cuda()
+    worst6 = max(worst6, (m25.get_prediction_batch(x, apply_sigmoid=False).cpu() - torch.from_numpy(z["cin25_64/logits"])).abs().max().item())
+    print(f"max-abs vs reference golden logits: bf16x6 {worst6:.3e}, fp32 MFMA path {worst32:.3e}")
+    assert worst6 <= 5e-5 and worst6 <= 3 * worst32
