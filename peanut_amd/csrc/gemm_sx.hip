@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
   constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;                       // 1 KiB = 32 rows of a plane
   constexpr int PIECES = A_PIECES + B_PIECES;
   constexpr int PER_WAVE = (PIECES + 3) / 4;
+  constexpr bool EVEN = PIECES % 4 == 0;   // every wave moves PER_WAVE pieces: no per-piece tests, a constant vmcnt
   constexpr int CS = BN + 4;
   constexpr int EP = (BM * CS * 4 > STAGES * STAGE) ? WM : 1;
   constexpr int ER = BM / EP;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
   {                                                                                                               \
     _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j) {                                                        \
       const int piece = wave * PER_WAVE + j;                                                                      \
-      if (piece < PIECES)                                                                                         \
+      if (EVEN || piece < PIECES)                                                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)src[j], (lptr_t)((stage) + piece * 1024), 16, 0, 0);            \
       src[j] += step[j];                                                                                          \
     }                                                                                                             \
@@ -102,15 +103,21 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
   // issued last), then the workgroup barrier that publishes them.  Raw s_barrier: a __syncthreads would make the
   // compiler drain the DMA queue (vmcnt(0)) and with it the prefetch distance.
   const int my_pieces = (wave + 1) * PER_WAVE <= PIECES ? PER_WAVE : (PIECES - wave * PER_WAVE > 0 ? PIECES - wave * PER_WAVE : 0);
-#define SX_WAIT_ALL_BUT_LAST_TILE()                                              \
-  switch (my_pieces) {                                                           \
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;              \
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;              \
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;              \
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;              \
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;              \
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;              \
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;             \
+#define SX_WAIT_ALL_BUT_LAST_TILE()                                                \
+  if constexpr (EVEN && PER_WAVE == 6) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }      \
+  else if constexpr (EVEN && PER_WAVE == 5) { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); } \
+  else if constexpr (EVEN && PER_WAVE == 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+  else if constexpr (EVEN && PER_WAVE == 3) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
+  else {                                                                           \
+    switch (my_pieces) {                                                           \
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;              \
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;              \
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;              \
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;              \
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;              \
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;              \
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;             \
+    }                                                                              \
   }
 #define SX_BARRIER()                                      \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
@@ -146,10 +153,12 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
     SX_DMA_LANDED_BARRIER();
   }
 
+  // byte offsets of the stage being read and of the one(s) being filled, rotated every k-tile
+  int o_cur = 0, o_fill = (STAGES - 1) * STAGE, o_mid = STAGE;   // o_mid only used with three stages
   for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* const cur = smem + (kt % STAGES) * STAGE;
+    const unsigned char* const cur = smem + o_cur;
     const bool more = kt + STAGES - 1 < nk;
-    if (more) SX_DMA_TILE(smem + ((kt + STAGES - 1) % STAGES) * STAGE);
+    if (more) SX_DMA_TILE(smem + o_fill);
     bf16x8 af[NP][MI], bf[NP][NI];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -175,6 +184,8 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
     // the next k-tile must have landed; the one just issued may stay in flight across the barrier
     if (STAGES == 3 && more) { SX_WAIT_ALL_BUT_LAST_TILE(); SX_BARRIER(); }
     else { SX_DMA_LANDED_BARRIER(); }
+    if (STAGES == 3) { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+    else { const int t = o_cur; o_cur = o_fill; o_fill = t; }
   }
 #undef SX_DMA_TILE
 #undef SX_DMA_LANDED_BARRIER
