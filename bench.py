@@ -64,7 +64,7 @@ def synth_maps(b: int, c: int, s: int, device, seed0: int = 0) -> torch.Tensor:
     return out
 
 
-def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 20.0, max_maps: int = 8):
+def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 12.0, max_maps: int = 64):
     """Oracle (= bit-exact restatement of the reference's CPU PyTorch path) on the host cores."""
     from oracle import pspnet_ref
     # tools/cpu_baseline_sweep.py on the MI355X box's 2x EPYC 9575F (profiles/cpu_baseline_sweep_r1.json):
