@@ -15,12 +15,13 @@ from peanut_amd.weights import PredCfg, conv_flops_per_map, make_seeded_state_di
 
 CONFIGS = [("config1 240x240 B=1", 14, 1, 240), ("deployed 720x720 B=1", 14, 1, 720),
            ("480x480 B=1", 14, 1, 480), ("headline 480x480 B=32", 14, 32, 480),
+           ("480x480 C=13 (4+9) B=32", 13, 32, 480),
            ("config5 share 960x960 C=25 B=8", 25, 8, 960)]
 
 
 def main():
     out = []
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x6", "bf16x3"):
         models = {}
         for name, c, b, s in CONFIGS:
             cfg = PredCfg(in_channels=c)
