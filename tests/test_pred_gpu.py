@@ -265,3 +265,36 @@ def test_bf16x6_emulation_is_fp32_class(model_and_sd, golden_dir):
     worst6 = max(worst6, (m25.get_prediction_batch(x, apply_sigmoid=False).cpu() - torch.from_numpy(z["cin25_64/logits"])).abs().max().item())
     print(f"max-abs vs reference golden logits: bf16x6 {worst6:.3e}, fp32 MFMA path {worst32:.3e}")
     assert worst6 <= 5e-5 and worst6 <= 3 * worst32
+
+
+def test_full_size_batch_properties(model_and_sd):
+    """BASELINE.json config 2 at full size (B = 32, 480x480x14), where the oracle is too slow to run: properties that
+    do not need it.  (a) a map's output depends only on that map: changing every other map of the batch leaves it
+    bit-identical, moving it to another batch position changes at most the last bits (which 128-row tiles get their
+    K range split for the tail round depends on the position); (b) two independent algorithm stacks -- Winograd +
+    LDS-DMA kernels vs direct convs -- agree to fp32 rounding; (c) so does the emulated-fp32 mode, whose GEMMs share
+    no kernel with either; (d) outputs are probabilities."""
+    from bench import synth_maps
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    x = synth_maps(32, cfg.in_channels, 480, torch.device("cuda"), seed0=123)
+    y = m.get_prediction_batch(x, apply_sigmoid=False)
+    x2 = synth_maps(32, cfg.in_channels, 480, torch.device("cuda"), seed0=999)
+    x2[7], x2[31] = x[7], x[31]
+    y2 = m.get_prediction_batch(x2, apply_sigmoid=False)
+    assert torch.equal(y2[7], y[7]) and torch.equal(y2[31], y[31]) and not torch.equal(y2[8], y[8])
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(0)).cuda()
+    yp = m.get_prediction_batch(x[perm].contiguous(), apply_sigmoid=False)
+    assert (yp - y[perm]).abs().max().item() <= 2e-5
+    direct = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, conv_algo="direct")
+    yd = direct.get_prediction_batch(x, apply_sigmoid=False)
+    del direct
+    x6 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="bf16x6")
+    y6 = x6.get_prediction_batch(x, apply_sigmoid=False)
+    del x6
+    e_dir, e_x6 = (y - yd).abs().max().item(), (y6 - yd).abs().max().item()
+    print(f"B=32 480x480: winograd vs direct {e_dir:.3e}, bf16x6 vs direct {e_x6:.3e}, |logit| max {yd.abs().max().item():.2f}")
+    assert e_dir <= 1e-4 and e_x6 <= 1e-4
+    p = m.get_prediction_batch(x, apply_sigmoid=True)
+    assert bool(((p > 0) & (p < 1)).all())
+    assert (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
