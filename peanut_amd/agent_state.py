@@ -21,6 +21,20 @@ from .mapping import Semantic_Mapping
 from .prediction import PEANUT_Prediction_Model
 
 
+def default_args(**over):
+    """The flags of nav/arguments.py the hot-path callers read, at their defaults (``argparse.Namespace``), for
+    drivers that run without the reference's argument parser (tools/bench_pipeline.py)."""
+    from argparse import Namespace
+    a = dict(seed=1, cuda=False, sem_gpu_id=0, num_sem_categories=10, map_size_cm=4800, map_resolution=5,
+             global_downscaling=2, only_explore=1, col_rad=4, grid_resolution=24, num_local_steps=20,
+             switch_step=0, update_goal_freq=10, goal_reached_dist=75, prediction_window=720, visualize=0,
+             frame_height=120, frame_width=160, env_frame_height=480, env_frame_width=640, vision_range=100,
+             hfov=79.0, du_scale=1, cat_pred_threshold=5.0, exp_pred_threshold=1.0, map_pred_threshold=0.1,
+             camera_height=0.88, min_depth=0.5, max_depth=5.0, sem_pred_prob_thr=0.95, goal_thr=0.985)
+    a.update(over)
+    return Namespace(**a)
+
+
 def disk(radius, dtype=np.uint8):
     """``skimage.morphology.disk`` (all pixels with x^2 + y^2 <= r^2); scikit-image is only needed
     for this footprint (agent_state.py:85-86)."""

@@ -51,8 +51,8 @@ def main():
     a = ap.parse_args()
     rank, local_rank, world = pdist.init_process_group()
     dev = torch.device("cuda", torch.cuda.current_device())
-    from oracle.agent_ref import agent_args   # argument defaults only (nav/arguments.py values)
-    args = agent_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=a.precision)
+    from peanut_amd.agent_state import default_args   # nav/arguments.py defaults
+    args = default_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=a.precision)
     st = Agent_State(args, state_dict=make_seeded_state_dict(PredCfg(), 0))
     mine = episode_shard(a.episodes)
     eps = {e: synth_episode(1000 + e, a.frames, dev) for e in mine}

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sweep torch CPU thread counts / batch sizes for the oracle forward (480x480) on this host, to give
-the CPU baseline its best configuration."""
+the CPU baseline its best configuration (the oracle is the thing timed: this is the cpu_baseline leg of bench.py,
+swept over thread counts)."""
 import os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Measure the HIP map-projection step on the GPU box: error vs the CPU oracle on seeded sequences
-and steps/s (HIP events over a chained sequence), next to the oracle's CPU time."""
+and steps/s (HIP events over a chained sequence), next to the oracle's CPU time.
+The oracle is used here exactly as in bench.py's cpu_baseline leg and the tests: as the checker and the timed CPU
+baseline, never as part of what is measured on the GPU."""
 import json
 import os
 import sys
