@@ -69,3 +69,36 @@ def test_product_refuses_to_run_without_gpu():
     from types import SimpleNamespace
     with pytest.raises(_lib.PeanutHipError):
         PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(PredCfg(), 0))
+
+
+def test_product_package_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under peanut_amd/ (nor bench.py outside its cpu_baseline leg, nor
+    __graft_entry__ outside smoke()) may import it, and nothing that runs on the GPU box may read /root/reference."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import):
+                hits += [(node.lineno, a.name) for a in node.names if a.name.split(".")[0] == "oracle"]
+            elif isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append((node.lineno, node.module))
+        return hits
+
+    for path in glob.glob(os.path.join(root, "peanut_amd", "**", "*.py"), recursive=True):
+        assert not oracle_imports(path), f"{path} imports the oracle"
+        assert "/root/reference" not in open(path).read(), f"{path} mentions /root/reference"
+    # bench.py: exactly one import, inside cpu_baseline(); __graft_entry__: inside smoke()
+    for fname, func in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        path = os.path.join(root, fname)
+        tree = ast.parse(open(path).read())
+        inside = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef) and node.name == func:
+                inside = {n.lineno for n in ast.walk(node) if isinstance(n, (ast.Import, ast.ImportFrom))}
+        hits = oracle_imports(path)
+        assert hits and all(line in inside for line, _ in hits), f"{fname}: oracle imported outside {func}()"
+        assert "/root/reference" not in open(path).read()
