@@ -72,12 +72,33 @@ def gen_pspnet(report):
     np.savez_compressed(os.path.join(GOLDEN, "pspnet_golden.npz"), **out)
 
 
+def gen_pspnet_fp64(report):
+    """The reference model run in float64 (same files, ``model.double()``): the yardstick for 'fp32-class' --
+    how far is an implementation from the exact result, compared with the reference's own fp32 CPU path?"""
+    out = {}
+    cfg = PredCfg(in_channels=14)
+    m = ref_import.build_reference_model(in_channels=14)
+    m.load_state_dict(make_seeded_state_dict(cfg, 0, with_aux=True), strict=True)
+    m = m.double()
+    z = np.load(os.path.join(GOLDEN, "pspnet_golden.npz"))
+    for name in ("b2_96", "odd_100"):
+        x = torch.from_numpy(z[f"{name}/input"]).double()
+        ref64 = np.stack(ref_import.reference_forward(m, x)).astype(np.float64)
+        err32 = float(np.abs(ref64 - z[f"{name}/logits"].astype(np.float64)).max())
+        out[f"{name}/logits64"] = ref64
+        out[f"{name}/fp32_cpu_reference_max_abs"] = np.float64(err32)
+        report["pspnet_fp64"][name] = dict(fp32_cpu_reference_vs_fp64_max_abs=err32)
+        print(f"[pspnet fp64] {name}: the reference's fp32 CPU path is {err32:.2e} from its fp64 self")
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_fp64_golden.npz"), **out)
+
+
 def main():
     assert ref_import.reference_available(), "needs /root/reference"
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
-    report = {"pspnet": {}, "mapping": {}, "torch": torch.__version__}
+    report = {"pspnet": {}, "pspnet_fp64": {}, "mapping": {}, "torch": torch.__version__}
     gen_pspnet(report)
+    gen_pspnet_fp64(report)
     from oracle import gen_golden_agent, gen_golden_mapping
     gen_golden_mapping.generate(report)
     gen_golden_agent.generate(report)

@@ -298,3 +298,33 @@ def test_full_size_batch_properties(model_and_sd):
     p = m.get_prediction_batch(x, apply_sigmoid=True)
     assert bool(((p > 0) & (p < 1)).all())
     assert (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
+
+
+def test_distance_to_the_fp64_reference(golden_dir):
+    """How far is each arithmetic mode from the EXACT result?  tests/golden/pspnet_fp64_golden.npz holds the logits of
+    the reference's own model files run in float64 (oracle/gen_golden.py: gen_pspnet_fp64); the reference's fp32 CPU
+    path is 5.4-5.7e-6 away from them.  'fp32-class' = the same order of magnitude: asserted for the fp32 MFMA modes
+    and for the bf16x6 emulation; the split modes are reported."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    z64 = np.load(os.path.join(golden_dir, "pspnet_fp64_golden.npz"))
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    dist = {}
+    for label, kw in (("fp32 direct", dict(conv_algo="direct")), ("fp32 winograd (default)", {}), ("bf16x6", dict(precision="bf16x6")),
+                      ("fp16x3", dict(precision="fp16x3")), ("bf16x3", dict(precision="bf16x3"))):
+        m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
+        worst = 0.0
+        for case in ("b2_96", "odd_100"):
+            x = torch.from_numpy(z[f"{case}/input"].astype(np.float32)).cuda()
+            got = m.get_prediction_batch(x, apply_sigmoid=False).cpu().numpy().astype(np.float64)
+            worst = max(worst, float(np.abs(got - z64[f"{case}/logits64"]).max()))
+        dist[label] = worst
+        del m
+    ref32 = max(float(z64["b2_96/fp32_cpu_reference_max_abs"]), float(z64["odd_100/fp32_cpu_reference_max_abs"]))
+    print("max-abs distance to the fp64 reference logits: reference fp32 CPU path %.2e | " % ref32 +
+          " | ".join(f"{k} {v:.2e}" for k, v in dist.items()))
+    assert dist["fp32 direct"] <= 2e-5 and dist["fp32 winograd (default)"] <= 4e-5 and dist["bf16x6"] <= 3e-5
+    assert dist["bf16x6"] <= 1.5 * dist["fp32 winograd (default)"]     # the emulation is not the less accurate of the two
+    assert dist["bf16x3"] <= 5e-4 and dist["fp16x3"] <= 1e-4
