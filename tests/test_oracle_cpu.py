@@ -86,3 +86,20 @@ def test_oracle_reproduces_golden(golden_dir):
         got = pspnet_ref.forward_batch(sd, x, cfg).numpy()
         # same code, same machine class: bit-exact here; 1e-5 leaves room for other CPUs' kernels
         assert np.abs(got - z[f"{case}/logits"]).max() <= 1e-5, case
+
+
+def test_oracle_distance_to_fp64_reference(golden_dir):
+    """The fp64 golden logits (the reference's model files run in float64, oracle/gen_golden.py) put a number on
+    'fp32-class': the oracle -- bit-identical to the reference's fp32 CPU path -- is within 1e-5 of them."""
+    import numpy as np
+    import torch
+    from oracle import pspnet_ref
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    z64 = np.load(os.path.join(golden_dir, "pspnet_fp64_golden.npz"))
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    x = torch.from_numpy(z["odd_100/input"].astype(np.float32))
+    got = pspnet_ref.forward_batch(sd, x, cfg).numpy().astype(np.float64)
+    err = float(np.abs(got - z64["odd_100/logits64"]).max())
+    assert err <= 1e-5 and abs(err - float(z64["odd_100/fp32_cpu_reference_max_abs"])) <= 1e-9
