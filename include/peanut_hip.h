@@ -258,8 +258,9 @@ int peanut_preprocess_obs(const uint8_t* rgb, const float* depth, const float* s
  * (nav/agent/utils/segmentation.py:47-60): for every detected instance j whose class is in
  * range(n_cats) and whose score passes sem_pred_prob_thr (and goal_thr when class == goal_cat),
  * out[:, :, class] += mask_j.  masks [n,H,W] uint8/bool, classes [n] int32, scores [n] fp32,
- * out [H,W,n_cats+1] fp32 (zeroed by the call; channel n_cats stays zero).  The Mask R-CNN
- * network itself (detectron2, not vendored) is not part of this library.
+ * out [H,W,n_cats+1] fp32 (zeroed by the call; channel n_cats stays zero).  The detector that
+ * produces masks/classes/scores is peanut_rcnn_* + peanut_roi_align / peanut_nms / peanut_paste_masks above
+ * (or detectron2 itself: the accumulation only needs the three tensors).
  * ---------------------------------------------------------------------------------------- */
 int peanut_seg_accumulate(const uint8_t* masks, const int32_t* classes, const float* scores, int n, int H, int W,
                           int n_cats, float sem_pred_prob_thr, float goal_thr, int goal_cat, float* out,
