@@ -1,6 +1,6 @@
 // Winograd F(4x4, 3x3) for the stride-1 3x3 convolutions (fp32 transforms around the MFMA GEMM kernel).
 //
-//   Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A        (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf)
+//   Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A        (Lavin & Gray 2016; interpolation points 0, +-3/4, +-3/2, inf)
 //
 // 36 multiplies per 4x4 output tile and channel pair instead of 144: the contraction over input channels
 // becomes 36 independent GEMMs [tiles x Cin] x [Cin x Cout], which run on conv_igemm's MFMA kernel as one
@@ -15,8 +15,8 @@
 //
 // Replaces (reference): the 3x3 conv2 of every stride-1 Bottleneck (prediction/mmseg/models/backbones/
 // resnet.py:267-307, dilations 1/2/4) and the PSP bottleneck conv (models/decode_heads/psp_head.py:86-93).
-// Numerics: fp32 throughout; measured 1e-5 max-abs on the seeded PSPNet logits (|logit| <= 6.4) against the
-// reference golden vectors, contract 1e-3.
+// Numerics: fp32 throughout; on the seeded PSPNet the logits are as far from the fp64 reference as with direct
+// convolutions (5e-6, |logit| <= 6.4); contract 1e-3.
 #include "common.h"
 #include "conv_common.h"
 
@@ -24,16 +24,25 @@ namespace peanut {
 
 namespace {
 
+// Interpolation points 0, +-3/4, +-3/2, inf instead of Lavin & Gray's 0, +-1, +-2, inf: the transform constants stay
+// exact in fp32 (dyadic rationals) and keep the even/odd structure, but the three matrices are better conditioned --
+// on the seeded PSPNet the logits' distance to the fp64 reference drops from 1.5e-5 to the direct convolution's own
+// 5e-6 (tests/test_pred_gpu.py::test_distance_to_the_fp64_reference).
+//   B^T = [81/64 0 -45/16 0 1 0; 0 -27/16 -9/4 3/4 1 0; 0 27/16 -9/4 -3/4 1 0; 0 -27/32 -9/16 3/2 1 0;
+//          0 27/32 -9/16 -3/2 1 0; 0 81/64 0 -45/16 0 1]
+//   A^T = [1 1 1 1 1 0; 0 3/4 -3/4 3/2 -3/2 0; 0 9/16 9/16 9/4 9/4 0; 0 27/64 -27/64 27/8 -27/8 1]
+//   G   = [64/81 0 0; -128/243 -32/81 -8/27; -128/243 32/81 -8/27; 32/243 16/81 8/27; 32/243 -16/81 8/27; 0 0 1]
 // t = B^T d for one 6-vector
 __device__ __forceinline__ void bt6(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4,
                                     const f32x4 d5, f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3, f32x4& t4, f32x4& t5) {
-  const f32x4 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
-  t0 = 4.f * d0 - 5.f * d2 + d4;
+  const f32x4 a = d4 - 2.25f * d2, b = 0.75f * d3 - 1.6875f * d1;
+  const f32x4 c = d4 - 0.5625f * d2, e = 1.5f * d3 - 0.84375f * d1;
+  t0 = 1.265625f * d0 - 2.8125f * d2 + d4;
   t1 = a + b;
   t2 = a - b;
   t3 = c + e;
   t4 = c - e;
-  t5 = 4.f * d1 - 5.f * d3 + d5;
+  t5 = 1.265625f * d1 - 2.8125f * d3 + d5;
 }
 
 // y = A^T m for one 6-vector
@@ -41,9 +50,9 @@ __device__ __forceinline__ void at6(const f32x4 m0, const f32x4 m1, const f32x4 
                                     const f32x4 m5, f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
   const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
   y0 = m0 + s12 + s34;
-  y1 = d12 + 2.f * d34;
-  y2 = s12 + 4.f * s34;
-  y3 = d12 + 8.f * d34 + m5;
+  y1 = 0.75f * d12 + 1.5f * d34;
+  y2 = 0.5625f * s12 + 2.25f * s34;
+  y3 = 0.421875f * d12 + 3.375f * d34 + m5;
 }
 
 struct WinoGeom {
@@ -210,8 +219,12 @@ void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_
 
 // U[(i*6+l)][n][c] = (G g G^T)[i][l], accumulated in double and rounded once
 void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out) {
-  static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  static const double G[6][3] = {{64.0 / 81, 0, 0},
+                                 {-128.0 / 243, -32.0 / 81, -8.0 / 27},
+                                 {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                                 {32.0 / 243, 16.0 / 81, 8.0 / 27},
+                                 {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                                 {0, 0, 1}};
   const size_t plane = (size_t)cout * cin;
   for (int n = 0; n < cout; ++n)
     for (int c = 0; c < cin; ++c) {

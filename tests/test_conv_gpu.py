@@ -134,7 +134,7 @@ def test_winograd_conv_matches_torch(case, precision, tol):
     F.conv2d up to fp32 rounding of the transforms.  F(4x4,3x3) amplifies rounding ~25x relative to the direct
     sum on N(0,1) data (measured here vs an fp64 convolution: direct 1.3e-6, Winograd 3-5e-5; with bf16x3
     products in the GEMM 2.4e-5 -> 6-8e-4), asserted |err| <= 1.5e-4 / 1.5e-3 * (1 + |ref|).  What the contract
-    bounds is the network output: 1.6e-5 / 1.7e-4 max-abs on the logits (tests/test_pred_gpu.py), bound 1e-3."""
+    bounds is the network output: 8e-6 / 1.0e-4 max-abs on the logits (tests/test_pred_gpu.py), bound 1e-3."""
     from peanut_amd.ops import FusedConv
     B, H, W, cin, cout, d, relu, residual = case
     g = torch.Generator().manual_seed(hash(case) & 0xffff)

@@ -3,7 +3,7 @@ the CPU oracle (oracle/pspnet_ref.py) on the same seeded weights and inputs, plu
 golden vectors generated from the reference's own model files (tests/golden/, oracle/gen_golden.py).
 
 Tolerance (BASELINE.json north_star): max-abs <= 1e-3 on logits and on sigmoid outputs, fp32.
-The fp32 path sits at ~1e-5 (direct form 8e-6, default Winograd form 1.6e-5 on |logit| <= 6.4); the tests
+The fp32 path sits at 8e-6 (direct and default Winograd form alike, |logit| <= 6.4); the tests
 assert 2e-4 so that a precision regression is caught long before the contractual bound."""
 import os
 from types import SimpleNamespace
