@@ -19,11 +19,12 @@ from peanut_amd.segmentation import accumulate_instances  # noqa: E402
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    algo = sys.argv[2] if len(sys.argv) > 2 else "auto"
     cfg = RcnnCfg(score_thresh_test=0.5)
     sd = make_seeded_rcnn_state_dict(cfg, 0)
     img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device="cuda")
     for prec in ("fp32", "bf16x3"):
-        m = MaskRCNN(cfg, sd, precision=prec)
+        m = MaskRCNN(cfg, sd, precision=prec, conv_algo=algo)
 
         def step():
             res = m.inference(img)
@@ -45,7 +46,7 @@ def main():
         torch.cuda.synchronize()
         front_ms = (time.perf_counter() - t0) / reps * 1e3
         print(json.dumps({"workload": f"config 3: Mask R-CNN R-101-FPN full inference + mask accumulation, {B} x 640x480 RGB",
-                          "precision": prec, "ms_per_batch": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1),
+                          "precision": prec, "conv_algo": algo, "ms_per_batch": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1),
                           "front_end_ms": round(front_ms, 2), "proposal_roi_paste_ms": round(ms - front_ms, 2),
                           "proposals_per_image": round(sum(len(r["proposals"]) for r in res) / B, 1),
                           "detections_per_image": round(sum(len(r["scores"]) for r in res) / B, 1)}), flush=True)
