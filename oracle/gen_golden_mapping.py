@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 SEQS = [("seq0", 0, 8), ("seq1", 1, 6)]
+# 22 semantic categories (> 16): the other set of full-height categories (mapping.py:107-113), 26-channel maps
+SEQS_C22 = [("c22_seq0", 2, 5)]
 
 
 def reference_module(cfg: mapping_ref.MapCfg):
@@ -30,12 +32,16 @@ def reference_module(cfg: mapping_ref.MapCfg):
 
 
 def generate(report):
-    cfg = mapping_ref.MapCfg()
+    _generate(report, mapping_ref.MapCfg(), SEQS, "mapping_golden.npz")
+    _generate(report, mapping_ref.MapCfg(num_sem_categories=22), SEQS_C22, "mapping_golden_c22.npz")
+
+
+def _generate(report, cfg, seqs, fname):
     sm = reference_module(cfg)
     out = {}
     torch.set_grad_enabled(False)
-    for name, seed, n in SEQS:
-        frames = mapping_scenes.make_sequence(seed, n)
+    for name, seed, n in seqs:
+        frames = mapping_scenes.make_sequence(seed, n, ncat=cfg.num_sem_categories)
         M, C = cfg.map_cells, 4 + cfg.num_sem_categories
         maps_ref = torch.zeros(C, M, M)
         maps_mine = torch.zeros(C, M, M)
@@ -45,7 +51,7 @@ def generate(report):
         sums, nnz, poses, fps, stairs = [], [], [], [], []
         worst = 0.0
         for fr in frames:
-            obs = torch.from_numpy(mapping_scenes.frame_to_obs(fr))[None]
+            obs = torch.from_numpy(mapping_scenes.frame_to_obs(fr, ncat=cfg.num_sem_categories))[None]
             rel = torch.from_numpy(fr["pose"])
             fp_r, maps_ref, _, pose_ref = sm(obs, rel, maps_ref, pose_ref, None)
             fp_m, maps_mine, _, pose_mine = mapping_ref.forward(obs, rel, maps_mine, pose_mine, cfg)
@@ -77,4 +83,4 @@ def generate(report):
                                        stairs_frames=[i for i, s in enumerate(stairs) if s])
         print(f"[mapping] {name}: {n} frames, restatement bit-identical, final nnz {idx.size}, "
               f"stairs branch taken in frames {[i for i, s in enumerate(stairs) if s]}")
-    np.savez_compressed(os.path.join(GOLDEN, "mapping_golden.npz"), **out)
+    np.savez_compressed(os.path.join(GOLDEN, fname), **out)

@@ -3,7 +3,10 @@ FRONT END of the Mask R-CNN the reference runs through detectron2's ``DefaultPre
 (nav/agent/utils/segmentation.py:31-38,45): test-time preprocessing, ResNet-101-FPN backbone and the
 RPN head, as configured by nav/agent/utils/COCO-InstSeg/mask_rcnn_R_101_cat9.yaml.
 
-**PARITY UNPINNED.**  The arithmetic lives in detectron2 (third party; peanut.Dockerfile:15 installs the
+**PARITY UNPINNED against the reference** (partially pinned against detectron2's own published unit tests: ROIAlign
+and anchor generation reproduce the known-answer vectors of tests/layers/test_roi_align.py::test_forward_output and
+tests/modeling/test_anchor_generator.py::test_default_anchor_generator, see tests/test_oracles_cpu.py).
+The arithmetic lives in detectron2 (third party; peanut.Dockerfile:15 installs the
 cu111/torch1.10 wheel => v0.6), which is not vendored, not installed, has no network route here, and whose
 fine-tuned weights are a Drive link.  The reference has no test or golden vector at this boundary.  This
 file therefore restates detectron2 v0.6's PUBLISHED module definitions (``DefaultPredictor.__call__``,
