@@ -271,3 +271,28 @@ def test_inference_at_the_agent_frame_geometry():
     assert gm.shape == rm.shape == (12, 480, 640)
     inter, union = (gm & rm).sum().item(), (gm | rm).sum().item()
     assert union > 0 and inter / union >= 0.98
+
+
+def test_roi_align_kernel_reproduces_detectron2_known_answers():
+    """detectron2 tests/layers/test_roi_align.py::test_forward_output (5x5 arange map, box (1,1,3,3), 4x4 output, legacy and
+    aligned) straight through peanut_roi_align -- the one published numeric fixture this stage has."""
+    import ctypes as C
+    from peanut_amd import _lib
+    lib = _lib.load()
+    feat = torch.zeros((1, 5, 5, 4), device="cuda")
+    feat[0, :, :, 0] = torch.arange(25, dtype=torch.float32, device="cuda").reshape(5, 5)
+    feat[0, :, :, 1] = 1.0
+    rois = torch.tensor([[0.0, 1.0, 1.0, 3.0, 3.0]], device="cuda")
+    lv = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    old = torch.tensor([[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]])
+    new = torch.tensor([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
+    for aligned, want in ((0, old), (1, new)):
+        out = torch.empty((1, 4, 4, 4), device="cuda")
+        feats = (C.c_void_p * 1)(feat.data_ptr())
+        hw = (C.c_int * 2)(5, 5)
+        scales = (C.c_float * 1)(1.0)
+        rc = lib.peanut_roi_align(feats, hw, scales, 1, 4, rois.data_ptr(), lv.data_ptr(), 1, 4, 0, aligned, out.data_ptr(),
+                                  _lib.current_stream_ptr(feat.device))
+        _lib.check(rc, "peanut_roi_align")
+        assert torch.allclose(out[0, :, :, 0].cpu(), want, atol=1e-6), aligned
+        assert torch.allclose(out[0, :, :, 1].cpu(), torch.ones(4, 4), atol=1e-6)
