@@ -1,7 +1,7 @@
 """Mask R-CNN front end on the HIP library: preprocessing + ResNet-101-FPN + RPN head of the detector
 ``SemanticPredMaskRCNN`` builds via detectron2 (nav/agent/utils/segmentation.py:30-38).  detectron2 is
-third party and absent; see oracle/rcnn_ref.py for what parity is (and is not) pinned against.  The
-proposal / ROI stages are not built yet, so this class exposes the dense front end only."""
+third party and absent; see oracle/rcnn_ref.py for what parity is (and is not) pinned against.
+``MaskRCNNFront`` exposes the dense front end, ``MaskRCNN`` (below) the whole inference path."""
 from __future__ import annotations
 
 import ctypes as C
@@ -235,6 +235,7 @@ class MaskRCNN(MaskRCNNFront):
 
     def __init__(self, cfg: RcnnCfg, state_dict, device="cuda:0", precision: str = "fp32", conv_algo: str = "auto"):
         super().__init__(cfg, state_dict, device=device, precision=precision, conv_algo=conv_algo)
+        self._anchor_cache = {}
         from .rcnn_weights import roi_head_keys
         for key, shape in roi_head_keys(cfg):
             if key not in state_dict or tuple(state_dict[key].shape) != tuple(shape):
@@ -265,27 +266,29 @@ class MaskRCNN(MaskRCNNFront):
         per image (boxes [n,4], objectness logits [n])."""
         cfg = self.cfg
         B = obj[0].shape[0]
-        sc, pr, lv = [], [], []
+        sc, dls, ans, lv = [], [], [], []
         for l, (o, d) in enumerate(zip(obj, deltas)):
             _, h, w, A = o.shape
-            anchors = grid_anchors((h, w), 4 * 2 ** l, cfg.anchor_sizes[l], cfg.aspect_ratios, o.device)
+            key = (l, h, w, str(o.device))
+            if key not in self._anchor_cache:                         # anchors depend on the level geometry only
+                self._anchor_cache[key] = grid_anchors((h, w), 4 * 2 ** l, cfg.anchor_sizes[l], cfg.aspect_ratios, o.device)
             logits = o.reshape(B, -1)
             k = min(logits.shape[1], cfg.rpn_pre_nms_topk)
             s, idx = logits.sort(descending=True, dim=1)
             s, idx = s[:, :k], idx[:, :k]
-            dl = d.reshape(B, -1, 4).gather(1, idx[:, :, None].expand(-1, -1, 4))            # decode only the top-k
-            an = anchors[idx.reshape(-1)]
-            pr.append(apply_deltas(dl.reshape(-1, 4), an, cfg.rpn_bbox_weights).view(B, k, 4))
+            dls.append(d.reshape(B, -1, 4).gather(1, idx[:, :, None].expand(-1, -1, 4)))     # decode only the top-k
+            ans.append(self._anchor_cache[key][idx.reshape(-1)].view(B, k, 4))
             sc.append(s)
             lv.append(torch.full((k,), l, dtype=torch.int64, device=o.device))
-        sc, pr, lv = torch.cat(sc, 1), torch.cat(pr, 1), torch.cat(lv, 0)
-        items = []
-        for n in range(B):
-            boxes, scores, lvl = pr[n], sc[n], lv
-            valid = torch.isfinite(boxes).all(1) & torch.isfinite(scores)
-            boxes = clip_boxes(boxes, image_hw)
-            ok = valid & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-            items.append((boxes[ok], scores[ok], lvl[ok]))
+        sc, lv = torch.cat(sc, 1), torch.cat(lv, 0)
+        n_all = sc.shape[1]
+        # one decode + clip + validity pass for all levels and images
+        pr = apply_deltas(torch.cat(dls, 1).reshape(-1, 4), torch.cat(ans, 1).reshape(-1, 4), cfg.rpn_bbox_weights)
+        valid = torch.isfinite(pr).all(1) & torch.isfinite(sc.reshape(-1))
+        pr = clip_boxes(pr, image_hw)
+        ok = (valid & ((pr[:, 2] - pr[:, 0]) > 0) & ((pr[:, 3] - pr[:, 1]) > 0)).view(B, n_all)
+        pr = pr.view(B, n_all, 4)
+        items = [(pr[n][ok[n]], sc[n][ok[n]], lv[ok[n]]) for n in range(B)]
         keeps = batched_nms_segments(items, cfg.rpn_nms_thresh)          # all images in one pair of launches
         return [(b[k[:cfg.rpn_post_nms_topk]], s[k[:cfg.rpn_post_nms_topk]]) for (b, s, _), k in zip(items, keeps)]
 
