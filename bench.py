@@ -8,15 +8,28 @@ batch 32 per GPU, data-parallel over N GPUs of one node (weak scaling, no data-p
 A "step" is one pass of the hot path (NCHW map batch resident in HBM -> NCHW probabilities in HBM)
 over one batch of synthetic maps.  Rank 0 prints ONE JSON line.
 `roofline` is measured live with HIP events recorded inside the timed region on the launch stream
-(peanut_pred_probe_*); `cpu_baseline` times the oracle restatement of the reference's fp32 PyTorch
-path on this box's host cores (rank 0, N=1 only, bounded sample).
+(peanut_pred_probe_*); `roofline.traffic` comes from a rocprofv3 PMC pass over this very command that
+bench.py runs on itself as a child (separate FETCH_SIZE / WRITE_SIZE passes, --kernel-trace only);
+`cpu_baseline` times the oracle restatement of the reference's fp32 PyTorch path on this box's host
+cores (rank 0, N=1 only, bounded sample: BASELINE.md sec. 4 -- 2 warm-ups, best of 5, B=1 and B=4).
+
+Without a launcher (`WORLD_SIZE` unset) `--gpus N` with N > 1 spawns the N ranks itself through
+torch.distributed.run; it exits non-zero when fewer than N GPUs are visible -- it never prints an
+`n_gpus: 1` line for `--gpus 8`.  `--config 5` selects SURVEY.md sec. 8d config 5 (960x960, 25 channels,
+8 maps per GPU, all-gather of the predicted maps timed); `--maps file.npz` feeds a map sequence in the
+reference's on-disk format (nav/collect_maps.py:80-87) instead of synthetic maps.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from types import SimpleNamespace
 
@@ -47,56 +60,186 @@ METRIC = "maps/sec for 480x480x(4+N_cat) prediction fwd, batch 32"
 
 
 def synth_maps(b: int, c: int, s: int, device, seed0: int = 0) -> torch.Tensor:
-    """Synthetic partial maps in the spirit of SURVEY.md sec. 8d config 2 (values in {0,1} like the
-    reference's thresholded maps): ch 0/1 (obstacle / explored) = Bernoulli(0.015) seeds dilated by
-    a 5x5 max-pool (~31 % coverage), ch 2-3 = one 5x5 square (agent location), ch 4.. = category
-    blobs from Bernoulli(0.001) seeds dilated 5x5 (~2.5 % coverage); seed = global map index."""
+    """SURVEY.md sec. 8d config 2, literally (values in {0,1} like the reference's thresholded maps):
+    ch 0/1 (obstacle / explored) = Bernoulli(0.3) seeds dilated by a 5x5 max-pool, ch 2-3 = one 5x5 square
+    (agent location), ch 4.. = category blobs from Bernoulli(0.02) seeds dilated 5x5; seed = global map index."""
     out = torch.zeros((b, c, s, s), dtype=torch.float32, device=device)
     for i in range(b):
         g = torch.Generator(device="cpu").manual_seed(seed0 + i)
-        occ = (torch.rand((1, 2, s, s), generator=g) < 0.3 * 0.05).float()
+        occ = (torch.rand((1, 2, s, s), generator=g) < 0.3).float()
         out[i, 0:2] = torch.nn.functional.max_pool2d(occ, 5, 1, 2)[0].to(device)
         cy, cx = (int(v) for v in torch.randint(8, s - 8, (2,), generator=g))
         out[i, 2:4, cy - 2:cy + 3, cx - 2:cx + 3] = 1.0
         if c > 4:
-            cat = (torch.rand((1, c - 4, s, s), generator=g) < 0.02 * 0.05).float()
+            cat = (torch.rand((1, c - 4, s, s), generator=g) < 0.02).float()
             out[i, 4:] = torch.nn.functional.max_pool2d(cat, 5, 1, 2)[0].to(device)
     return out
 
 
-def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 12.0, max_maps: int = 64):
-    """Oracle (= bit-exact restatement of the reference's CPU PyTorch path) on the host cores."""
+def maps_from_file(path: str, b: int, c: int, s: int, device, first: int = 0) -> torch.Tensor:
+    """[b,c,s,s] model inputs from a map sequence in the reference's .npz format (key 'maps', uint8 [T,C,W,H],
+    nav/collect_maps.py:80-87), scaled by /255 as LoadMapFromFile does (train_prediction_model.py:63-68) and
+    centre-cropped to the prediction window like Agent_State.update_prediction (agent_state.py:357-361).
+    Snapshots are taken round-robin starting at `first` when the file holds fewer than b of them."""
+    from peanut_amd import mapio
+    maps = mapio.load_map_sequence(path)
+    if maps.ndim != 4 or maps.shape[1] != c:
+        raise SystemExit(f"--maps: expected uint8 [T,{c},W,H], got {maps.shape}")
+    if maps.shape[2] < s or maps.shape[3] < s:
+        raise SystemExit(f"--maps: maps of {maps.shape[2]}x{maps.shape[3]} are smaller than --size {s}")
+    x1, y1 = maps.shape[2] // 2 - s // 2, maps.shape[3] // 2 - s // 2
+    xs = [mapio.model_input(maps, (first + i) % maps.shape[0])[:, :, x1:x1 + s, y1:y1 + s] for i in range(b)]
+    return torch.cat(xs, 0).contiguous().to(device)
+
+
+def cpu_model_name() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 40.0):
+    """Oracle (= bit-exact restatement of the reference's CPU PyTorch path) on the host cores, timed as
+    BASELINE.md sec. 4 plans: fp32, no_grad, torch.set_num_threads(N) with N and the CPU model reported,
+    2 warm-ups then best of 5, at B=1 and B=4 (a batch of 32 is 8 x 4).  `value` is the best per-map rate of the
+    legs (the most favourable reading for the CPU).  The thread count defaults to 16: the sweep on the MI355X
+    box's 2x EPYC 9575F (profiles/cpu_baseline_sweep_r1.json) found more threads slower for these convs; a
+    second B=4 leg with 64 threads is tried while the time budget lasts."""
     from oracle import pspnet_ref
-    # tools/cpu_baseline_sweep.py on the MI355X box's 2x EPYC 9575F (profiles/cpu_baseline_sweep_r1.json):
-    # 16 threads at batch 1 is this path's best single-process configuration (5.8 maps/s; torch's
-    # default of 128 threads gives 1.0), so that is what the CPU baseline gets.
     threads = int(os.environ.get("PEANUT_CPU_THREADS", min(16, os.cpu_count() or 1)))
-    torch.set_num_threads(threads)
-    x = synth_maps(1, cfg.in_channels, s, "cpu", seed0=10_000)
-    pspnet_ref.forward_batch(sd, x, cfg)                      # warm-up (oneDNN primitive cache)
-    n, t0 = 0, time.perf_counter()
-    while n < max_maps and (time.perf_counter() - t0 < budget_s or n < 2):
-        pspnet_ref.forward_batch(sd, x, cfg)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "maps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} x [1,{cfg.in_channels},{s},{s}] fp32 forwards after 1 warm-up, "
-                      f"torch {torch.__version__} CPU, {threads} threads"}
+    legs, t_start = [], time.perf_counter()
+    plan = [(1, threads), (4, threads)]
+    if (os.cpu_count() or 1) >= 64 and "PEANUT_CPU_THREADS" not in os.environ:
+        plan.append((4, 64))
+    for b, n in plan:
+        if legs and time.perf_counter() - t_start > budget_s:
+            break
+        torch.set_num_threads(n)
+        x = synth_maps(b, cfg.in_channels, s, "cpu", seed0=10_000)
+        for _ in range(2):
+            pspnet_ref.forward_batch(sd, x, cfg)                  # warm-ups (oneDNN primitive cache)
+        best = float("inf")
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pspnet_ref.forward_batch(sd, x, cfg)
+            best = min(best, time.perf_counter() - t0)
+        legs.append({"batch": b, "threads": n, "maps_per_s": round(b / best, 4), "best_s": round(best, 4)})
+    top = max(legs, key=lambda l: l["maps_per_s"])
+    return {"value": top["maps_per_s"], "unit": "maps/s", "cores": int(top["threads"]), "kind": "port",
+            "cpu_model": cpu_model_name(), "host_logical_cpus": os.cpu_count(), "legs": legs,
+            "sample": f"oracle/pspnet_ref.py forward of [B,{cfg.in_channels},{s},{s}] fp32 maps, 2 warm-ups + best of 5 "
+                      f"per leg (BASELINE.md sec. 4), torch {torch.__version__} CPU kernels; value = best leg "
+                      f"(B={top['batch']}, {top['threads']} threads)"}
 
 
-def hbm_traffic(precision, family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (bench.py cannot run the
-    profiler on itself): profiles/hbm_traffic.json holds the per-dispatch means of FETCH_SIZE and WRITE_SIZE
-    (KiB) measured on this very command; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
-    (16-byte-per-lane streaming reads are tallied at half their size).  null when no measurement is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+# bench kernel family -> substring of the rocprofv3 kernel name
+FAMILY_KERNEL = {
+    "conv_pw_glds_128x128": "conv_pw_glds_kernel<128, 2, 2>",
+    "conv_pw_glds_128x64": "conv_pw_glds_kernel<64, 2, 2>",
+    "conv_pw_glds_128x32": "conv_pw_glds_kernel<32, 4, 1>",
+    "gemm_sx6_128x128": "gemm_sx_kernel<128, 2, 2, 3, 3>",
+    "gemm_sx3_128x128": "gemm_sx_kernel<128, 2, 2, 2, 3>",
+}
+
+
+def _pmc_pass(counter: str, child_args, timeout_s: float):
+    """One `rocprofv3 --kernel-trace --pmc <counter>` pass over a short child run of this script; returns
+    {kernel name: (dispatches, sum)} from the rocpd database, or None."""
+    import sqlite3
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="peanut_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "--", sys.executable, os.path.abspath(__file__)] + child_args
+    try:
+        r = subprocess.run(cmd, cwd=out, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        if r.returncode != 0:
+            return None
+        dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        if not dbs:
+            return None
+        agg = {}
+        cur = sqlite3.connect(dbs[0]).cursor()
+        for kname, cname, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+            if cname == counter:
+                a = agg.setdefault(kname, [0, 0.0])
+                a[0] += 1
+                a[1] += val
+        return agg
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_hbm_traffic(family: str, child_args, timeout_s: float = 150.0):
+    """HBM bytes per launch of `family`'s kernel, measured on THIS command as MI355X_MICROARCH.md's HBM section
+    prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (with --kernel-trace only), values in KiB,
+    FETCH_SIZE doubled on gfx950 (16-byte-per-lane streaming reads are tallied at half their size)."""
+    pat = FAMILY_KERNEL.get(family)
+    if pat is None:
+        return {"traffic": None, "traffic_source": f"no rocprofv3 kernel name known for family {family}"}
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        agg = _pmc_pass(counter, child_args, timeout_s)
+        if not agg:
+            return {"traffic": None, "traffic_source": f"rocprofv3 --pmc {counter} pass unavailable or failed"}
+        n = sum(a[0] for k, a in agg.items() if pat in k)
+        s = sum(a[1] for k, a in agg.items() if pat in k)
+        if n == 0:
+            return {"traffic": None, "traffic_source": f"kernel {pat} not found in the --pmc {counter} pass"}
+        res[counter] = (n, s / n)
+    fetch_kib, write_kib = res["FETCH_SIZE"][1], res["WRITE_SIZE"][1]
+    return {"traffic": round((2.0 * fetch_kib + write_kib) * 1024.0),
+            "traffic_fetch_kib_raw": round(fetch_kib, 1), "traffic_write_kib": round(write_kib, 1),
+            "traffic_dispatches": res["FETCH_SIZE"][0],
+            "traffic_source": "measured by this run: child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and "
+                              "`--pmc WRITE_SIZE` over `bench.py " + " ".join(child_args) + "` (per-dispatch mean of "
+                              f"{pat}; FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+
+
+def hbm_traffic_from_file(precision, family):
+    """Fallback: per-dispatch means committed under profiles/hbm_traffic.json by an earlier PMC run."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as fh:
             e = json.load(fh)[precision][family]
         return {"traffic": round((2.0 * e["fetch_size_kib_mean"] + e["write_size_kib_mean"]) * 1024.0),
-                "traffic_source": e["source"]}
+                "traffic_source": "NOT measured by this run -- " + e["source"]}
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} HIP device(s) are visible; refusing to report a smaller job "
+              f"under that flag", file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+PRESETS = {   # SURVEY.md sec. 8d
+    2: dict(size=480, channels=14, batch=32),
+    5: dict(size=960, channels=25, batch=8),
+}
 
 
 def main():
@@ -104,9 +247,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="maps per GPU per step")
-    ap.add_argument("--size", type=int, default=480)
-    ap.add_argument("--channels", type=int, default=14, help="4 + N_cat input channels")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(PRESETS),
+                    help="SURVEY.md sec. 8d configuration: 2 = headline (480x480, 14 ch, 32 maps/GPU), "
+                         "5 = 960x960, 25 ch, 8 maps/GPU + all-gather of the predicted maps")
+    ap.add_argument("--batch", type=int, default=None, help="maps per GPU per step (overrides the preset)")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--channels", type=int, default=None, help="4 + N_cat input channels")
+    ap.add_argument("--maps", default="", help="map sequence (.npz, key 'maps', uint8 [T,C,W,H]: the reference's "
+                                               "collect_maps.py format) used as input instead of synthetic maps")
     ap.add_argument("--precision", default=os.environ.get("PEANUT_PRECISION", "fp32"),
                     choices=sorted(PEAK_TFLOPS), help="conv arithmetic (include/peanut_hip.h PEANUT_PREC_*)")
     ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO", "bf16x6,bf16x3"),
@@ -114,11 +262,21 @@ def main():
                          "'modes' (empty string to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-op HIP-event probe")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
+                    help="roofline.traffic: 'measure' profiles a short child run of this command with rocprofv3 PMC "
+                         "counters; 'auto' = measure at N=1 when rocprofv3 is installed, else the committed file")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) here")
     args = ap.parse_args()
+    preset = PRESETS[args.config]
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     rank, local_rank, world = pdist.init_process_group()
-    if world != max(args.gpus, 1) and world > 1:
+    if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
@@ -129,7 +287,10 @@ def main():
     sd = make_seeded_state_dict(cfg, seed=0)
     B, S = args.batch, args.size
     # this rank's shard of the global batch (weak scaling: B maps per GPU)
-    x = synth_maps(B, cfg.in_channels, S, dev, seed0=rank * B)
+    if args.maps:
+        x = maps_from_file(args.maps, B, cfg.in_channels, S, dev, first=rank * B)
+    else:
+        x = synth_maps(B, cfg.in_channels, S, dev, seed0=rank * B)
     out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=dev)
 
     def run_mode(precision, steps, warmup, op_table=""):
@@ -164,16 +325,19 @@ def main():
             k, f = max(fam.items(), key=lambda kv: kv[1]["ms"])
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             peak = PEAK_TFLOPS[precision]
+            executed = sum(r[3] for r in rows) / B / 1e9
             roof = {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), **hbm_traffic(precision, k),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": round(f["bytes"] / max(f["launches"], 1)),
                     "launches_per_step": f["launches"] // max(nf, 1),
                     "avg_launch_ms": round(f["ms"] / max(f["launches"], 1), 4),
                     "flops_per_launch": f["flops"] / max(f["launches"], 1),
                     "share_of_step_time": round(f["ms"] / max(sum(v["ms"] for v in fam.values()), 1e-9), 4),
                     "note": "achieved = FLOPs this kernel family EXECUTES per launch (Winograd GEMMs at their transformed "
-                            "size, folded pyramid excluded) / its mean launch time from HIP events inside the timed steps",
-                    "gflop_per_map_executed": round(sum(r[3] for r in rows) / B / 1e9, 3)}
+                            "size incl. tile padding, folded pyramid excluded) / its mean launch time from HIP events "
+                            "inside the timed steps",
+                    "gflop_per_map_executed": round(executed, 3),
+                    "whole_forward_tflops_executed": round(executed * 1e9 * B * steps / elapsed / 1e12, 2)}
             if op_table and rank == 0:
                 with open(op_table, "w") as fh:
                     json.dump({"forwards": nf, "B": B, "S": S, "precision": precision,
@@ -190,38 +354,61 @@ def main():
     elapsed, roof = run_mode(args.precision, args.steps, args.warmup, args.op_table)
     modes = {}
     for extra in [m for m in args.also.split(",") if m and m != args.precision]:
-        e_s, e_roof = run_mode(extra, max(3, args.steps // 2), 2)
         st = max(3, args.steps // 2)
+        e_s, e_roof = run_mode(extra, st, 2)
         modes[extra] = {"value": round(world * B * st / e_s, 3), "unit": "maps/s", "ms_per_step": round(e_s / st * 1e3, 3),
                         "dtype": DTYPE[extra], "steps": st, "roofline": e_roof,
                         "note": MODE_NOTES.get(extra, "")}
 
-    # logging-only collective: collate the predicted maps of the last step (untimed)
+    # logging-only collective: collate the predicted maps of the last step (outside the timed steps; timed on its own)
     gather_ms = None
-    if world > 1:
+    if world > 1 or args.config == 5:
+        pdist.allgather_maps(out)                      # warm-up (communicator set-up)
         torch.cuda.synchronize()
+        pdist.barrier()
         tg = time.perf_counter()
         allmaps = pdist.allgather_maps(out)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - tg) * 1e3
+        gather_ms = pdist.max_over_ranks((time.perf_counter() - tg) * 1e3, device=dev)
         assert allmaps.shape[0] == world * B
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, sd, S)
 
+    if rank == 0 and roof is not None and args.traffic != "none":
+        measured = None
+        if world == 1 and args.traffic in ("auto", "measure"):
+            child = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-probe", "--also", "", "--traffic", "none",
+                     "--config", str(args.config), "--batch", str(B), "--size", str(S), "--channels", str(cfg.in_channels),
+                     "--precision", args.precision] + (["--maps", os.path.abspath(args.maps)] if args.maps else [])
+            measured = measure_hbm_traffic(roof["kernel"], child)
+        if measured is not None and measured.get("traffic") is not None:
+            roof.update(measured)
+        else:
+            fb = hbm_traffic_from_file(args.precision, roof["kernel"]) if (args.config == 2 and not args.maps) else {"traffic": None}
+            if measured is not None and fb.get("traffic") is None:
+                fb = measured
+            elif measured is not None:
+                fb["traffic_source"] += " (" + measured.get("traffic_source", "") + ")"
+            roof.update(fb)
+
     if rank == 0:
         total_maps = world * B * args.steps
         value = total_maps / elapsed
         line = {
-            "metric": METRIC, "value": round(value, 3), "unit": "maps/s", "n_gpus": world,
+            "metric": METRIC if args.config == 2 else f"maps/sec for {S}x{S}x(4+N_cat) prediction fwd, batch {B} per GPU "
+                                                        f"(SURVEY.md sec. 8d config {args.config})",
+            "value": round(value, 3), "unit": "maps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.precision],
+            "data": ("map sequence " + os.path.basename(args.maps)) if args.maps else "synthetic",
             "config": {"workload": f"{S}x{S}, {cfg.in_channels}-channel (4+{cfg.in_channels - 4}) partial maps -> "
                                    f"{cfg.num_classes}-class prediction forward (PSPNet R50-V1c-D8), "
                                    f"batch {B} per GPU, seeded random-init weights",
-                       "global_batch": world * B, "parallelism": f"dp{world} (map shards, no data-path collective)"},
+                       "survey_config": args.config, "global_batch": world * B,
+                       "parallelism": f"dp{world} (map shards, no data-path collective)"},
             "gflop_per_map_nominal": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
             "whole_forward_tflops_nominal": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
             "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 256 input channels as Winograd "
@@ -229,10 +416,13 @@ def main():
                           "(nominal GFLOP/map counts the reference's 61 direct convs, so nominal TFLOP/s can exceed the MFMA peak)",
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if cpu is not None:
+            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         if modes:
             line["modes"] = modes
         if gather_ms is not None:
             line["allgather_maps_ms"] = round(gather_ms, 3)
+            line["allgather_maps_bytes_per_rank"] = int(out.numel() * 4)
         print(json.dumps(line), flush=True)
     pdist.barrier()
     if torch.distributed.is_initialized():

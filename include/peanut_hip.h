@@ -185,8 +185,8 @@ int peanut_map_use_graph(peanut_map_t* h, int enable);
  * SemanticPredMaskRCNN.__init__ (nav/agent/utils/segmentation.py:30-38) from
  * COCO-InstSeg/mask_rcnn_R_101_cat9.yaml.  detectron2 is third party and absent from the reference
  * checkout: the module graph follows its published v0.6 definitions, parity is pinned only against
- * the restatement in oracle/rcnn_ref.py.  Proposal selection, NMS, ROIAlign, box/mask heads and mask
- * pasting are not part of this library yet.
+ * the restatement in oracle/rcnn_ref.py.  Proposal selection, NMS, ROIAlign and mask pasting are the operator
+ * exports further down; peanut_rcnn_inference runs the whole detector.
  * ---------------------------------------------------------------------------------------- */
 typedef struct peanut_rcnn_cfg {
   int depth;               /* RESNETS.DEPTH (101) */
@@ -248,11 +248,12 @@ int peanut_paste_masks(const float* masks, const float* boxes, int n, int M, int
 
 /* Observation formatting, Agent_Helper._preprocess_obs/_preprocess_depth
  * (nav/agent/agent_helper.py:175-217): per-column invalid-depth fill, >0.99 -> far, metres -> cm
- * (min_d*100 + d*(max_d-min_d)*100 in fp32), then rows/cols ds//2::ds of RGB (the reference's PIL
+ * (f32(min_d*100.0) + (d*f32(max_d-min_d))*100 -- the two constants are formed in double like the
+ * reference's Python floats, min_d / max_d are therefore doubles), then rows/cols ds//2::ds of RGB (the reference's PIL
  * NEAREST resize picks the same pixels), depth and semantics.  rgb [H,W,3] uint8, depth [H,W] fp32 in
  * [0,1] (0 = invalid), sem [H,W,ncat] fp32 -> obs [3+1+ncat, H/ds, W/ds] fp32. */
 int peanut_preprocess_obs(const uint8_t* rgb, const float* depth, const float* sem, int H, int W, int ncat, int ds,
-                          float min_d, float max_d, float* obs, void* stream);
+                          double min_d, double max_d, float* obs, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 1 -- per-instance mask accumulation of SemanticPredMaskRCNN.get_prediction
@@ -275,17 +276,41 @@ int peanut_seg_accumulate(const uint8_t* masks, const int32_t* classes, const fl
 typedef struct peanut_conv peanut_conv_t;
 /* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
  * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
- * which the packer guarantees).  precision = PEANUT_PREC_* (split modes need cin_pad % 32 == 0,
- * otherwise the layer silently stays fp32); conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
+ * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X3 / FP16X3; the split modes need
+ * cin_pad % 32 == 0 and the call FAILS with PEANUT_EINVAL otherwise (no silent change of arithmetic);
+ * peanut_conv_precision() returns the PEANUT_PREC_* mode the layer actually runs in.  conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
  * >= 256 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */
 int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
                        const float* shift_host, int cout, int cin, int cin_pad, int kh, int kw, int stride,
                        int pad, int dil, int relu, int precision, int conv_algo);
 void peanut_conv_destroy(peanut_conv_t* c);
+int peanut_conv_precision(peanut_conv_t* c);
 /* x_dev [B,H,W,cin_pad] (or split x_dev [..,c1] ++ x2_dev [..,cin_pad-c1] when x2_dev != NULL),
  * res_dev optional [B,Ho,Wo,cout], y_dev [B,Ho,Wo,cout]. */
 int peanut_conv_forward(peanut_conv_t* c, const float* x_dev, const float* x2_dev, int c1, const float* res_dev,
                         float* y_dev, int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: collation of the predicted maps for logging.  One process per GPU, maps /
+ * episodes sharded with no data-path collective -- the reference shards by hand with --start_ep/--end_ep/
+ * --sem_gpu_id (nav/arguments.py:15-20, nav/collect.py:37-50) and never communicates; this all-gather is the one
+ * collective BASELINE.json's north_star adds.  RCCL over xGMI, bound at run time (the librccl.so already loaded
+ * in the process, e.g. torch's, else ROCm's; PEANUT_RCCL_LIB overrides).
+ * ---------------------------------------------------------------------------------------- */
+#define PEANUT_COMM_ID_BYTES 128
+typedef struct peanut_comm peanut_comm_t;
+/* rank 0: create the id (ncclGetUniqueId), then hand the 128 bytes to every rank (host side: file, MPI, TCP store). */
+int peanut_comm_unique_id(unsigned char id[PEANUT_COMM_ID_BYTES]);
+/* every rank, on its own GPU (the current HIP device): ncclCommInitRank -- a collective call.  n_ranks == 1 needs
+ * neither an id nor RCCL. */
+int peanut_comm_create(peanut_comm_t** out, int n_ranks, int rank, const unsigned char id[PEANUT_COMM_ID_BYTES]);
+void peanut_comm_destroy(peanut_comm_t* c);
+int peanut_comm_info(peanut_comm_t* c, int* n_ranks, int* rank);
+/* which RCCL library got bound ("" when none could be) */
+const char* peanut_comm_backend(void);
+/* local: this rank's [B_local,K,S,S] fp32 maps (device, `count` floats); all: [n_ranks * count] floats (device),
+ * rank-major.  One ncclAllGather on `stream`, no staging copy, no synchronisation. */
+int peanut_allgather_maps(peanut_comm_t* c, const float* local, float* all, size_t count, void* stream);
 
 #ifdef __cplusplus
 }

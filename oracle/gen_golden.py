@@ -92,13 +92,58 @@ def gen_pspnet_fp64(report):
     np.savez_compressed(os.path.join(GOLDEN, "pspnet_fp64_golden.npz"), **out)
 
 
+def gen_pspnet_round2(report):
+    """Round-2 additions, written to their own files so that the round-1 fixtures stay byte-identical:
+    * pspnet_golden_c25.npz -- config 5's channel count (C_in = 25) at 240x240 (one map);
+    * pspnet_fp64_480_golden.npz -- the reference model in float64 on ONE 480x480 map of the benchmark's synthetic
+      recipe (bench.synth_maps, seed 4242), logits kept at rows 1::4, cols 2::4 only (the full fp64 tensor is 11 MB),
+      together with the same sub-grid of the reference's fp32 CPU path."""
+    from bench import synth_maps
+    cfg = PredCfg(in_channels=25)
+    m = ref_import.build_reference_model(in_channels=25)
+    sd = make_seeded_state_dict(cfg, 1, with_aux=True)
+    m.load_state_dict(sd, strict=True)
+    x = psp_input(1, 25, 240, 240, 5)
+    ref = np.stack(ref_import.reference_forward(m, x))
+    mine = pspnet_ref.forward_batch(sd, x, cfg).numpy()
+    err = float(np.abs(ref - mine).max())
+    assert err <= 1e-5, f"cin25_240: oracle restatement deviates from the reference by {err}"
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_golden_c25.npz"), **{
+        "cin25_240/input": x.numpy().astype(np.uint8), "cin25_240/logits": ref.astype(np.float32),
+        "cin25_240/c_in": np.int64(25), "cin25_240/weight_seed": np.int64(1)})
+    report["pspnet"]["cin25_240"] = dict(shape=[1, 25, 240, 240], restatement_max_abs=err, logits_absmax=float(np.abs(ref).max()))
+    print(f"[pspnet] cin25_240: ref vs restatement max-abs {err:.2e}")
+
+    cfg = PredCfg(in_channels=14)
+    m = ref_import.build_reference_model(in_channels=14)
+    m.load_state_dict(make_seeded_state_dict(cfg, 0, with_aux=True), strict=True)
+    x = synth_maps(1, 14, 480, "cpu", seed0=4242)
+    ref32 = np.stack(ref_import.reference_forward(m, x)).astype(np.float64)
+    ref64 = np.stack(ref_import.reference_forward(m.double(), x.double())).astype(np.float64)
+    sub = (slice(None), slice(None), slice(1, None, 4), slice(2, None, 4))
+    err32 = float(np.abs(ref64 - ref32).max())
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_fp64_480_golden.npz"), **{
+        "cfg2_480/input_seed": np.int64(4242), "cfg2_480/logits64_sub": ref64[sub],
+        "cfg2_480/logits32_sub": ref32[sub].astype(np.float32), "cfg2_480/input_sum": np.float64(x.double().sum().item()),
+        "cfg2_480/fp32_cpu_reference_max_abs": np.float64(err32)})
+    report["pspnet_fp64"]["cfg2_480"] = dict(fp32_cpu_reference_vs_fp64_max_abs=err32)
+    print(f"[pspnet fp64] cfg2_480: the reference's fp32 CPU path is {err32:.2e} from its fp64 self")
+
+
 def main():
+    if "--round2" in sys.argv:       # only the added fixtures (the round-1 files are left untouched)
+        report = {"pspnet": {}, "pspnet_fp64": {}}
+        gen_pspnet_round2(report)
+        with open(os.path.join(GOLDEN, "golden_report_r2.json"), "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        return
     assert ref_import.reference_available(), "needs /root/reference"
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
     report = {"pspnet": {}, "pspnet_fp64": {}, "mapping": {}, "torch": torch.__version__}
     gen_pspnet(report)
     gen_pspnet_fp64(report)
+    gen_pspnet_round2(report)
     from oracle import gen_golden_agent, gen_golden_mapping
     gen_golden_mapping.generate(report)
     gen_golden_agent.generate(report)

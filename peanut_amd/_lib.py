@@ -17,6 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
+ABI_VERSION = 4     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -92,11 +93,18 @@ SIGNATURES = {
     "peanut_nms": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "peanut_nms_segments": (C.c_int, [_P, _P, C.POINTER(C.c_int), C.c_int, C.c_float, _P, _P, _P]),
     "peanut_paste_masks": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
-    "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
+    "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
     "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_int, _P, _P]),
+    "peanut_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte * 128)]),
+    "peanut_comm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.POINTER(C.c_ubyte * 128)]),
+    "peanut_comm_destroy": (None, [_P]),
+    "peanut_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "peanut_comm_backend": (C.c_char_p, []),
+    "peanut_allgather_maps": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "peanut_conv_create": (C.c_int, [C.POINTER(_P), _P, _P, _P] + [C.c_int] * 11),
     "peanut_conv_destroy": (None, [_P]),
+    "peanut_conv_precision": (C.c_int, [_P]),
     "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
 }
 
@@ -132,6 +140,10 @@ def load() -> C.CDLL:
                 raise PeanutHipError(f"{path} does not export {name}; rebuild the extension") from e
             fn.restype = res
             fn.argtypes = args
+        got = lib.peanut_abi_version()
+        if got != ABI_VERSION:
+            raise PeanutHipError(f"{path} implements ABI version {got}, this package binds version {ABI_VERSION}: "
+                                 "rebuild the extension (python -m peanut_amd.build --force)")
         _LIB = lib
         return lib
 

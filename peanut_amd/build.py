@@ -67,7 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
     tmp = LIB_PATH + ".tmp"
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")

@@ -460,7 +460,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
 extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
-int peanut_abi_version(void) { return 3; }
+int peanut_abi_version(void) { return 4; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
@@ -690,6 +690,9 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
   if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
   if (precision < 0 || precision > 2) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
+  if (precision != PEANUT_PREC_FP32 && cin_pad % 32 != 0)
+    return fail(PEANUT_EINVAL, "peanut_conv_create: the split-precision modes need cin_pad % 32 == 0 (this layer would "
+                               "have to run in fp32); create it with PEANUT_PREC_FP32 explicitly");
   auto c = std::make_unique<peanut_conv>();
   c->L.name = "conv";
   if (conv_algo != PEANUT_ALGO_AUTO && conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "peanut_conv_create: bad conv_algo");
@@ -704,6 +707,8 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
 }
 
 void peanut_conv_destroy(peanut_conv_t* c) { delete c; }
+
+int peanut_conv_precision(peanut_conv_t* c) { return c ? c->L.d.mode : PEANUT_EINVAL; }
 
 int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c1, const float* res, float* y, int B,
                         int H, int W, void* stream) {

@@ -48,12 +48,87 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+class MapComm:
+    """``peanut_comm_t`` of the C ABI (include/peanut_hip.h, csrc/comm.hip) spanning the torch.distributed world:
+    rank 0 creates the RCCL unique id, the 128 bytes travel through the process group that already exists, every
+    rank builds its communicator on its own GPU.  The collective itself is then one ``peanut_allgather_maps`` call
+    on torch's current stream -- the same entry point a torch-free host uses."""
+
+    def __init__(self, device=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(self._lib.peanut_comm_unique_id(C.byref(ident)), "peanut_comm_unique_id")
+        t = torch.tensor(list(ident), dtype=torch.uint8)
+        on_gpu = dist.get_backend() == "nccl"
+        if on_gpu:
+            t = t.to(self.device)
+        dist.broadcast(t, src=0)
+        for i, v in enumerate(t.cpu().tolist()):
+            ident[i] = v
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.peanut_comm_create(C.byref(self._h), self.world, self.rank, C.byref(ident)),
+                       "peanut_comm_create")
+        self.backend = (self._lib.peanut_comm_backend() or b"").decode()
+
+    def allgather_maps(self, local: torch.Tensor) -> torch.Tensor:
+        from . import _lib
+        if not local.is_cuda or local.dtype != torch.float32:
+            raise ValueError("MapComm.allgather_maps needs a float32 tensor on the HIP device")
+        local = local.contiguous()
+        out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=torch.float32, device=local.device)
+        with torch.cuda.device(local.device):
+            rc = self._lib.peanut_allgather_maps(self._h, local.data_ptr(), out.data_ptr(), local.numel(),
+                                                 _lib.current_stream_ptr(local.device))
+        _lib.check(rc, "peanut_allgather_maps")
+        return out
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.peanut_comm_destroy(h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
+
+_MAP_COMM: Optional[MapComm] = None
+
+
+def map_comm() -> MapComm:
+    """The process-wide communicator (created collectively on first use: every rank must reach this call)."""
+    global _MAP_COMM
+    if _MAP_COMM is None:
+        _MAP_COMM = MapComm()
+    return _MAP_COMM
+
+
+def close_map_comm():
+    global _MAP_COMM
+    if _MAP_COMM is not None:
+        _MAP_COMM.close()
+        _MAP_COMM = None
+
+
 def allgather_maps(local: torch.Tensor, world: Optional[int] = None) -> torch.Tensor:
     """Collate equally-shaped predicted-map shards [B_local,K,H,W] from every rank into
     [world*B_local,K,H,W] (rank-major) with ONE all-gather; logging only, off the data path.
-    With one process it is the identity."""
+    With one process it is the identity.  HIP tensors go through the library's own RCCL entry point
+    (``peanut_allgather_maps``); host tensors (the gloo world-size-2 tests of the sharding logic, no GPU) through
+    ``torch.distributed``."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
+    if local.is_cuda and local.dtype == torch.float32:
+        return map_comm().allgather_maps(local)
     world = world or dist.get_world_size()
     local = local.contiguous()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,

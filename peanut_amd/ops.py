@@ -28,8 +28,10 @@ class FusedConv:
     def __init__(self, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0,
                  dilation: int = 1, relu: bool = False, cin_pad: Optional[int] = None,
-                 precision: str = "fp32", conv_algo: str = "auto"):
+                 precision: str = "fp32", conv_algo: str = "auto", device=None):
+        """``device``: HIP device the weights are uploaded to (default: the current one); inputs must live there."""
         self._lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         w = np.ascontiguousarray(weight.detach().cpu().numpy(), dtype=np.float32)
         cout, cin, kh, kw = w.shape
         self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
@@ -38,10 +40,11 @@ class FusedConv:
         sc = None if scale is None else np.ascontiguousarray(scale.detach().cpu().numpy(), dtype=np.float32)
         sh = None if shift is None else np.ascontiguousarray(shift.detach().cpu().numpy(), dtype=np.float32)
         self._h = C.c_void_p()
-        _lib.check(self._lib.peanut_conv_create(
-            C.byref(self._h), w.ctypes.data, None if sc is None else sc.ctypes.data,
-            None if sh is None else sh.ctypes.data, cout, cin, self.cin_pad, kh, kw, stride, padding,
-            dilation, int(relu), _lib.PRECISIONS[precision], _lib.CONV_ALGOS[conv_algo]), "peanut_conv_create")
+        with torch.cuda.device(self.device):      # the library allocates on the current device
+            _lib.check(self._lib.peanut_conv_create(
+                C.byref(self._h), w.ctypes.data, None if sc is None else sc.ctypes.data,
+                None if sh is None else sh.ctypes.data, cout, cin, self.cin_pad, kh, kw, stride, padding,
+                dilation, int(relu), _lib.PRECISIONS[precision], _lib.CONV_ALGOS[conv_algo]), "peanut_conv_create")
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -62,6 +65,8 @@ class FusedConv:
         """x: [B,H,W,c1] NHWC float32 on the HIP device (c1 == cin_pad, or c1 + x2.shape[3] ==
         cin_pad for the two-source concat form); returns [B,Ho,Wo,cout]."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+        if x.device != self.device:
+            raise ValueError(f"input lives on {x.device}, the conv's weights on {self.device}")
         b, h, w, c1 = x.shape
         c2 = 0
         if x2 is not None:

@@ -244,21 +244,22 @@ class MaskRCNN(MaskRCNNFront):
         P, Fo, K = cfg.box_pooler_resolution, cfg.fpn_out, cfg.num_classes
         # fc1 consumes ROIAlign output flattened NHWC ((y*P+x)*C + c); detectron2 flattens NCHW (c*P*P + y*P + x)
         w1 = sd["roi_heads.box_head.fc1.weight"].view(cfg.fc_dim, Fo, P, P).permute(0, 2, 3, 1).reshape(cfg.fc_dim, -1)
-        lin = lambda w, b, relu: FusedConv(w[:, :, None, None], None, b, relu=relu, precision=precision)  # noqa: E731
+        lin = lambda w, b, relu: FusedConv(w[:, :, None, None], None, b, relu=relu, precision=precision,  # noqa: E731
+                                           device=self.device)
         self.fc1 = lin(w1, sd["roi_heads.box_head.fc1.bias"], True)
         self.fc2 = lin(sd["roi_heads.box_head.fc2.weight"], sd["roi_heads.box_head.fc2.bias"], True)
         self.cls_score = lin(sd["roi_heads.box_predictor.cls_score.weight"], sd["roi_heads.box_predictor.cls_score.bias"], False)
         self.bbox_pred = lin(sd["roi_heads.box_predictor.bbox_pred.weight"], sd["roi_heads.box_predictor.bbox_pred.bias"], False)
         self.mask_fcn = [FusedConv(sd[f"roi_heads.mask_head.mask_fcn{i + 1}.weight"], None,
                                    sd[f"roi_heads.mask_head.mask_fcn{i + 1}.bias"], padding=1, relu=True, precision=precision,
-                                   conv_algo=conv_algo)
+                                   conv_algo=conv_algo, device=self.device)
                          for i in range(cfg.num_mask_convs)]
         # ConvTranspose2d(k=2, s=2) = four 1x1 convs, one per output sub-pixel (dy,dx): rows (dy*2+dx)*C + n
         wd, bd = sd["roi_heads.mask_head.deconv.weight"], sd["roi_heads.mask_head.deconv.bias"]
         wd4 = wd.permute(2, 3, 1, 0).reshape(4 * wd.shape[1], wd.shape[0])        # [(dy,dx,n), c]
         self.deconv = lin(wd4, bd.repeat(4), True)
         self.mask_pred = FusedConv(sd["roi_heads.mask_head.predictor.weight"], None, sd["roi_heads.mask_head.predictor.bias"],
-                                   precision=precision)
+                                   precision=precision, device=self.device)
 
     # ---- RPN.predict_proposals + find_top_rpn_proposals ----
     def proposals(self, obj: List[torch.Tensor], deltas: List[torch.Tensor], image_hw):
@@ -296,7 +297,11 @@ class MaskRCNN(MaskRCNNFront):
     def box_branch(self, pyr: List[torch.Tensor], rois: torch.Tensor):
         """rois [N,5] -> (class logits [N,K+1], box deltas [N,4K])."""
         x = roi_align_pyramid(pyr, rois, assign_levels(rois[:, 1:]), self.cfg.box_pooler_resolution)
-        x = x.reshape(x.shape[0], 1, 1, -1)
+        n, P = x.shape[0], self.cfg.box_pooler_resolution
+        if n == 0:          # no valid proposal in the whole batch: empty Instances, like detectron2
+            K = self.cfg.num_classes
+            return x.new_zeros((0, K + 1)), x.new_zeros((0, 4 * K))
+        x = x.reshape(n, 1, 1, P * P * self.cfg.fpn_out)
         x = self.fc2(self.fc1(x))
         return self.cls_score(x).reshape(x.shape[0], -1), self.bbox_pred(x).reshape(x.shape[0], -1)
 

@@ -46,6 +46,42 @@ def run_episode(state: Agent_State, frames: Iterable[Dict], goal_cat: int,
     return n_pred
 
 
+def run_recorded_episode(agent, episode, on_step: Optional[Callable[[int, Dict], None]] = None) -> int:
+    """One pass of the reference's inner loop (nav/collect.py:44-59: ``hab_env.reset(); nav_agent.reset();
+    while not episode_over: action = nav_agent.act(observations)``) over a recorded episode
+    (peanut_amd/episodes.py: the (rgb, depth, gps, compass, objectgoal) tuples Habitat produced).  ``agent`` is a
+    ``peanut_amd.peanut_agent.PEANUT_Agent``; ``episode`` a path or a loaded dict.  Returns the number of
+    predictions."""
+    from . import episodes as E
+    ep = E.load_episode(episode) if isinstance(episode, str) else episode
+    agent.reset()
+    n_pred = 0
+    for i, observations in enumerate(E.iter_observations(ep)):
+        out = agent.act(observations)
+        n_pred += int(out.get('predicted', False))
+        if on_step is not None:
+            on_step(i, out)
+    return n_pred
+
+
+def run_recorded_shard(agent, episode_paths: List[str], start_ep: int = 0, end_ep: int = -1,
+                       on_episode: Optional[Callable[[int, int], None]] = None) -> Dict[int, int]:
+    """The outer loop of nav/collect.py:40-84 with its ``--start_ep/--end_ep`` window (:37-39,50): every episode
+    before ``end_ep`` is iterated (the reference resets the env for skipped ones too), only those in
+    [start_ep, end_ep) are run.  Returns {episode index: predictions}."""
+    num_episodes = len(episode_paths)
+    end = end_ep if end_ep > 0 else num_episodes
+    done = {}
+    ep_i = 0
+    while ep_i < min(num_episodes, end):
+        if start_ep <= ep_i < end:
+            done[ep_i] = run_recorded_episode(agent, episode_paths[ep_i])
+            if on_episode is not None:
+                on_episode(ep_i, done[ep_i])
+        ep_i += 1
+    return done
+
+
 def episode_shard(n_episodes: int) -> List[int]:
     """Episode ids owned by this rank (contiguous ``[start_ep, end_ep)`` like nav/collect.py:50)."""
     rank, _, world = pdist.env_rank_world()

@@ -102,3 +102,15 @@ def test_product_package_never_touches_the_oracle_or_the_reference():
         hits = oracle_imports(path)
         assert hits and all(line in inside for line, _ in hits), f"{fname}: oracle imported outside {func}()"
         assert "/root/reference" not in open(path).read()
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` on a box with fewer devices exits non-zero and prints no result line (here: none)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, text=True)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "n_gpus" not in r.stdout

@@ -148,3 +148,74 @@ def test_replay_loop_with_the_hip_detector():
     assert torch.equal(a.local_map, b.local_map) and torch.equal(a.target_pred, b.target_pred)
     with pytest.raises(ValueError):
         run_episode(a, raw, goal_cat=5)                       # no masks and no detector
+
+
+def test_agent_loop_from_gps_compass_matches_reference(golden_dir):
+    """H-3: ``PEANUT_Agent.act`` driven by recorded (gps, compass, objectgoal) readings over two episodes back to
+    back -- pose change from the sensors, hm3d -> coco goal mapping, per-episode reset, map update every step,
+    prediction at step 0 and every 10th step -- against the reference's own PEANUT_Agent.get_info + Agent_State
+    (tests/golden/pose_golden.npz, oracle/gen_golden_pose.py)."""
+    from oracle import mapping_scenes
+    from oracle.agent_ref import agent_args, fake_pattern
+    from peanut_amd.peanut_agent import PEANUT_Agent
+    z = np.load(os.path.join(golden_dir, "pose_golden.npz"))
+    args = agent_args()
+    agent = PEANUT_Agent(args, prediction_model=FakePredictionGPU(fake_pattern(size=args.prediction_window)))
+    for e in range(int(z["n_episodes"])):
+        frames = mapping_scenes.make_sequence(seed=int(z[f"ep{e}_seed"]), n_frames=int(z[f"ep{e}_n"]))
+        agent.reset()
+        assert agent.total_episodes == e + 1 and agent.last_sim_location is None
+        st = agent.agent_states
+        for i, fr in enumerate(frames):
+            observations = {"gps": z[f"ep{e}_gps"][i], "compass": z[f"ep{e}_compass"][i],
+                            "objectgoal": np.array([int(z[f"ep{e}_goal"])]),
+                            "obs": torch.from_numpy(mapping_scenes.frame_to_obs(fr))[None]}
+            out = agent.act(observations)
+            np.testing.assert_allclose(np.asarray(out["sensor_pose"], np.float64), z[f"ep{e}_sensor_pose"][i], rtol=0,
+                                       atol=3e-7)
+            assert out["predicted"] == bool(z[f"ep{e}_predicted"][i]), f"episode {e} step {i}: prediction schedule"
+            assert list(st.lmb) == list(z[f"ep{e}_lmb"][i]), f"episode {e} step {i}: local map boundaries"
+            assert [st.loc_r, st.loc_c] == list(z[f"ep{e}_loc"][i]), f"episode {e} step {i}: agent cell"
+            np.testing.assert_allclose(st.local_pose.cpu().numpy(), z[f"ep{e}_local_pose"][i], rtol=0, atol=3e-5)
+            sums = st.local_map.double().sum((1, 2)).cpu().numpy()
+            np.testing.assert_allclose(sums, z[f"ep{e}_channel_sums"][i], rtol=1e-6, atol=0.05, err_msg=f"ep {e} step {i}")
+        assert st.goal_cat == {0: 0, 1: 3, 2: 2, 3: 4, 4: 5, 5: 1}[int(z[f"ep{e}_goal"])]
+        full = st.full_map.cpu().numpy().reshape(-1)
+        ref = np.zeros_like(full)
+        ref[z[f"ep{e}_full_idx"]] = z[f"ep{e}_full_val"]
+        assert np.abs(full - ref).max() <= 5e-5, f"episode {e}: full map (a stale map would mean reset() failed)"
+
+
+def test_recorded_episode_files_drive_the_replay(tmp_path):
+    """The on-disk (rgb, depth, gps, compass, objectgoal [+ instances]) episode format feeds replay.run_recorded_shard
+    with collect.py's --start_ep/--end_ep window; timestep_limit stops the agent like peanut_agent.py:41-43."""
+    from oracle.agent_ref import agent_args
+    from peanut_amd import episodes as E
+    from peanut_amd.peanut_agent import PEANUT_Agent
+    from peanut_amd.replay import run_recorded_shard
+    rng = np.random.RandomState(3)
+    paths = []
+    for e in range(3):
+        frames = []
+        x, o = 0.0, 0.0
+        for t in range(12):
+            x += 0.1
+            masks = np.zeros((2, 480, 640), np.uint8)
+            masks[0, 280:400, 100:220] = 1
+            masks[1, 300:420, 300:420] = 1
+            frames.append(dict(rgb=rng.randint(0, 255, (480, 640, 3)).astype(np.uint8),
+                               depth=np.full((480, 640, 1), 0.4, np.float32), gps=np.array([x, 0.0], np.float32),
+                               compass=np.array([o], np.float32), objectgoal=np.array([e]),
+                               instances=(masks, np.array([0, 3], np.int32), np.array([0.99, 0.97], np.float32))))
+        p = str(tmp_path / f"ep{e}.npz")
+        E.save_episode(p, frames)
+        paths.append(p)
+    args = agent_args(only_explore=0, prediction_window=240, map_size_cm=2400, timestep_limit=11)
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    agent = PEANUT_Agent(args, state_dict=make_seeded_state_dict(PredCfg(), seed=0))
+    seen = []
+    done = run_recorded_shard(agent, paths, start_ep=1, end_ep=3, on_episode=lambda i, n: seen.append(i))
+    assert sorted(done) == [1, 2] and seen == [1, 2]
+    assert all(n == 2 for n in done.values())            # steps 0 and 9 of the 11 acted frames (the 12th is past the limit)
+    assert agent.total_episodes == 2 and agent.timestep == 12
+    assert float(agent.agent_states.local_map[4].sum()) > 0 and agent.agent_states.target_pred is not None

@@ -1,31 +1,87 @@
-"""RCCL smoke on the GPU box: the collectives bench.py / peanut_amd.dist use for N > 1 (barrier,
-all_reduce(MAX), all_gather_into_tensor) run on the `nccl` (= RCCL) backend with a single rank.  The
-multi-rank logic itself is covered by the world-size-2 gloo tests (tests/test_dist_cpu.py)."""
+"""RCCL on the GPU box: the collectives bench.py / peanut_amd.dist use for N > 1, with min(2, visible GPUs) ranks
+(one process per GPU, launched like the driver launches bench.py), the C-ABI communicator with one rank, and
+bench.py's own rank spawning."""
+import ctypes as C
+import json
 import os
-import socket
+import subprocess
+import sys
 
 import pytest
 import torch
-import torch.distributed as dist
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def test_rccl_single_rank_collectives():
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _free_port():
+    import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        torch.cuda.set_device(0)
-        dist.barrier()
-        t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert float(t) == 3.5
-        local = torch.rand(2, 6, 16, 16, device="cuda")
-        out = torch.empty_like(local)
-        dist.all_gather_into_tensor(out, local)
-        assert torch.equal(out, local)
-    finally:
-        dist.destroy_process_group()
+        return s.getsockname()[1]
+
+
+def test_rccl_ranks_allgather_through_the_c_abi():
+    n = min(2, torch.cuda.device_count())
+    assert n >= 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_rccl_worker.py")]
+    r = subprocess.run(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert f"RCCL_WORKER_OK world={n}" in r.stdout, r.stdout[-3000:]
+
+
+def test_single_rank_communicator_and_rccl_binding():
+    """peanut_comm_* with one rank (no id needed) copies the shard; the unique id comes from the RCCL copy torch
+    already loaded (no second RCCL in the process)."""
+    from peanut_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.peanut_comm_create(C.byref(h), 1, 0, None), "peanut_comm_create")
+    n, r = C.c_int(), C.c_int()
+    _lib.check(lib.peanut_comm_info(h, C.byref(n), C.byref(r)), "peanut_comm_info")
+    assert (n.value, r.value) == (1, 0)
+    local = torch.rand(2, 6, 16, 16, device="cuda")
+    out = torch.zeros_like(local)
+    _lib.check(lib.peanut_allgather_maps(h, local.data_ptr(), out.data_ptr(), local.numel(), _lib.current_stream_ptr()),
+               "peanut_allgather_maps")
+    torch.cuda.synchronize()
+    assert torch.equal(out, local)
+    lib.peanut_comm_destroy(h)
+    ident = (C.c_ubyte * 128)()
+    _lib.check(lib.peanut_comm_unique_id(C.byref(ident)), "peanut_comm_unique_id")
+    assert any(ident) and b"rccl" in lib.peanut_comm_backend()
+    assert lib.peanut_comm_create(C.byref(h), 2, 5, C.byref(ident)) != 0        # rank out of range
+
+
+def test_bench_spawns_its_own_ranks_or_refuses():
+    """`python bench.py --gpus N` without a launcher must run N ranks (n_gpus == N in the JSON line) or exit
+    non-zero -- never report a smaller job under that flag."""
+    have = torch.cuda.device_count()
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "96",
+            "--no-cpu-baseline", "--also", "", "--traffic", "none"]
+    r = subprocess.run(base + ["--gpus", str(have + 1)], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout
+    n = min(2, have)
+    if n > 1:
+        r = subprocess.run(base + ["--gpus", str(n)], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["config"]["global_batch"] == 2 * n and "allgather_maps_ms" in line
+    # config-5 preset (per-GPU shard shrunk to keep the test short): the all-gather is timed and reported
+    r = subprocess.run(base[:2] + ["--config", "5", "--steps", "1", "--warmup", "1", "--batch", "1", "--size", "192", "--no-cpu-baseline",
+                                   "--also", "", "--traffic", "none"], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["survey_config"] == 5 and "25-channel" in line["config"]["workload"]
+    assert "allgather_maps_ms" in line

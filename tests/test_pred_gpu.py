@@ -4,7 +4,7 @@ golden vectors generated from the reference's own model files (tests/golden/, or
 
 Tolerance (BASELINE.json north_star): max-abs <= 1e-3 on logits and on sigmoid outputs, fp32.
 The fp32 path sits at 8e-6 (direct and default Winograd form alike, |logit| <= 6.4); the tests
-assert 2e-4 so that a precision regression is caught long before the contractual bound."""
+assert 5e-5 so that a precision regression is caught long before the contractual bound."""
 import os
 from types import SimpleNamespace
 
@@ -14,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-4          # asserted
+TOL = 5e-5          # asserted (measured: 8e-6)
 CONTRACT = 1e-3     # north_star bound
 
 
@@ -328,3 +328,158 @@ def test_distance_to_the_fp64_reference(golden_dir):
     assert dist["fp32 direct"] <= 2e-5 and dist["fp32 winograd (default)"] <= 4e-5 and dist["bf16x6"] <= 3e-5
     assert dist["bf16x6"] <= 1.5 * dist["fp32 winograd (default)"]     # the emulation is not the less accurate of the two
     assert dist["bf16x3"] <= 5e-4 and dist["fp16x3"] <= 1e-4
+
+
+def test_golden_c25_240(golden_dir):
+    """Config 5's channel count (C_in = 25) at 240x240 against the reference's own model files
+    (tests/golden/pspnet_golden_c25.npz), fp32 default, direct and bf16x6."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_golden_c25.npz"))
+    cfg = PredCfg(in_channels=int(z["cin25_240/c_in"]))
+    sd = make_seeded_state_dict(cfg, int(z["cin25_240/weight_seed"]))
+    x = torch.from_numpy(z["cin25_240/input"].astype(np.float32)).cuda()
+    ref = torch.from_numpy(z["cin25_240/logits"])
+    for kw, tol in ((dict(), TOL), (dict(conv_algo="direct"), 2e-5), (dict(precision="bf16x6"), TOL)):
+        m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
+        err = (m.get_prediction_batch(x, apply_sigmoid=False).cpu() - ref).abs().max().item()
+        assert err <= tol, f"{kw}: {err:.3e}"
+        del m
+
+
+def test_config5_full_size_properties():
+    """BASELINE.json config 5 at its per-GPU size (C_in = 25, 960x960, 8 maps per GPU), where the oracle is too slow:
+    map independence, agreement of the Winograd / direct / bf16x6 kernel stacks, probabilities, and the batch-shape
+    independence of the workspace planner at this size (a 960x960 batch of 8 has the tile count of config 2)."""
+    from bench import synth_maps
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    cfg = PredCfg(in_channels=25)
+    sd = make_seeded_state_dict(cfg, seed=1)
+    dev = torch.device("cuda")
+    x = synth_maps(8, 25, 960, dev, seed0=50)
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    y = m.get_prediction_batch(x, apply_sigmoid=False)
+    assert tuple(y.shape) == (8, 6, 960, 960) and bool(torch.isfinite(y).all())
+    assert torch.equal(y, m.get_prediction_batch(x, apply_sigmoid=False))
+    x2 = synth_maps(8, 25, 960, dev, seed0=900)
+    x2[3] = x[3]
+    y2 = m.get_prediction_batch(x2, apply_sigmoid=False)
+    assert torch.equal(y2[3], y[3]) and not torch.equal(y2[4], y[4])
+    one = m.get_prediction_batch(x[3:4].contiguous(), apply_sigmoid=False)
+    assert (one[0] - y[3]).abs().max().item() <= 2e-5
+    p = m.get_prediction_batch(x, apply_sigmoid=True)
+    assert bool(((p > 0) & (p < 1)).all()) and (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
+    del p, y2, m
+    direct = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, conv_algo="direct")
+    yd = direct.get_prediction_batch(x, apply_sigmoid=False)
+    del direct
+    x6 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="bf16x6")
+    y6 = x6.get_prediction_batch(x, apply_sigmoid=False)
+    del x6
+    e_dir, e_x6 = (y - yd).abs().max().item(), (y6 - yd).abs().max().item()
+    print(f"config 5 (8 x 25 x 960 x 960): winograd vs direct {e_dir:.3e}, bf16x6 vs direct {e_x6:.3e}, "
+          f"|logit| max {yd.abs().max().item():.2f}")
+    assert e_dir <= 1e-4 and e_x6 <= 1e-4
+
+
+def test_distance_to_the_fp64_reference_at_480(golden_dir):
+    """The benchmark's own input recipe at the headline size: one 480x480 map (bench.synth_maps, seed 4242) against
+    the reference's model files run in float64 (sub-grid rows 1::4, cols 2::4 of the logits,
+    tests/golden/pspnet_fp64_480_golden.npz).  The fp32 MFMA path and the bf16x6 emulation must both be as close to
+    the exact result as the reference's own fp32 CPU path is (same order of magnitude)."""
+    from bench import synth_maps
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_fp64_480_golden.npz"))
+    x = synth_maps(1, 14, 480, "cpu", seed0=int(z["cfg2_480/input_seed"]))
+    assert float(x.double().sum()) == float(z["cfg2_480/input_sum"]), "bench.synth_maps changed: regenerate the fixture"
+    ref64, ref32 = z["cfg2_480/logits64_sub"], z["cfg2_480/logits32_sub"]
+    cpu32 = float(z["cfg2_480/fp32_cpu_reference_max_abs"])
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    dist = {}
+    for label, kw in (("fp32 direct", dict(conv_algo="direct")), ("fp32 winograd (default)", {}), ("bf16x6", dict(precision="bf16x6")),
+                      ("bf16x3", dict(precision="bf16x3"))):
+        m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
+        got = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu().numpy()[:, :, 1::4, 2::4]
+        dist[label] = float(np.abs(got.astype(np.float64) - ref64).max())
+        if label == "fp32 winograd (default)":
+            assert np.abs(got - ref32).max() <= TOL          # and the fp32 reference itself at full size
+        del m
+    print("480x480, max-abs distance to the fp64 reference logits: reference fp32 CPU path %.2e | " % cpu32 +
+          " | ".join(f"{k} {v:.2e}" for k, v in dist.items()))
+    assert dist["fp32 direct"] <= 3e-5 and dist["fp32 winograd (default)"] <= 5e-5 and dist["bf16x6"] <= 4e-5
+    assert dist["bf16x6"] <= 1.5 * dist["fp32 winograd (default)"] + 2e-6
+    assert dist["bf16x3"] <= 5e-4
+
+
+def test_map_sequence_file_drives_the_forward(tmp_path):
+    """the reference's on-disk map format (collect_maps.py:80-87: uint8 [T,C,W,H] under key
+    'maps', x255) -> mapio.load_map_sequence -> model_input (/255, train_prediction_model.py:63-68) -> HIP forward,
+    against the oracle on the same decoded inputs; plus bench.maps_from_file's centre crop."""
+    from bench import maps_from_file
+    from oracle import pspnet_ref
+    from peanut_amd import mapio
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(9)
+    T, S = 4, 160
+    soft = torch.rand((T, cfg.in_channels, S, S), generator=g)
+    full = torch.where(torch.rand((T, cfg.in_channels, S, S), generator=g) > 0.8, soft, torch.zeros(()))   # non-binary values
+    path = str(tmp_path / "seq.npz")
+    mapio.save_map_sequence(path, [full[t] for t in range(T)])
+    maps = mapio.load_map_sequence(path)
+    assert maps.dtype == np.uint8 and maps.shape == (T, cfg.in_channels, S, S)
+    assert np.array_equal(maps, (full.numpy() * 255).astype(np.uint8))
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    for t in (0, 3):
+        x = mapio.model_input(maps, t)
+        assert x.dtype == torch.float32 and float(x.max()) <= 1.0
+        ref = pspnet_ref.forward_batch(sd, x, cfg)
+        got = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu()
+        assert (got - ref).abs().max().item() <= TOL
+    xb = maps_from_file(path, 3, cfg.in_channels, 96, torch.device("cuda"), first=2)     # snapshots 2, 3, 0, centre 96x96
+    lo = S // 2 - 48
+    for i, t in enumerate((2, 3, 0)):
+        assert torch.equal(xb[i].cpu(), mapio.model_input(maps, t)[0, :, lo:lo + 96, lo:lo + 96])
+    ref = pspnet_ref.forward_batch(sd, xb.cpu(), cfg)
+    assert (m.get_prediction_batch(xb, apply_sigmoid=False).cpu() - ref).abs().max().item() <= TOL
+
+
+def test_constructor_from_files_on_disk(tmp_path):
+    """``PEANUT_Prediction_Model(args)`` exactly as the agent builds it (nav/agent/prediction.py:142-152,
+    agent_state.py:83): ``args.pred_model_cfg`` = an mmcv-style python config, ``args.pred_model_wts`` = an mmcv
+    checkpoint ({'meta': {'CLASSES': ...}, 'state_dict': ...} with auxiliary_head.* / num_batches_tracked / 'module.'
+    prefixes), both read from disk; then get_prediction(np) against the oracle."""
+    from oracle import pspnet_ref
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, seed=3, with_aux=True)
+    ck = {"meta": {"CLASSES": ("chair", "sofa", "plant", "bed", "toilet", "tv"), "PALETTE": None},
+          "state_dict": {"module." + k: v for k, v in sd.items()}}
+    wts = str(tmp_path / "pred_model_wts.pth")
+    torch.save(ck, wts)
+    cfg_path = str(tmp_path / "pred_model_cfg.py")
+    with open(cfg_path, "w") as f:        # the fields of nav/pred_model_cfg.py:2-42 in mmcv config syntax
+        f.write("norm_cfg = dict(type='BN', requires_grad=True)\n"
+                "model = dict(type='EncoderDecoder', pretrained=None,\n"
+                "    backbone=dict(type='ResNetV1c', depth=50, in_channels=14, num_stages=4, out_indices=(0, 1, 2, 3),\n"
+                "        dilations=(1, 1, 2, 4), strides=(1, 2, 1, 1), norm_cfg=norm_cfg, norm_eval=False, style='pytorch',\n"
+                "        contract_dilation=True),\n"
+                "    decode_head=dict(type='PSPHead', in_channels=2048, in_index=3, channels=512, pool_scales=(1, 2, 3, 6),\n"
+                "        dropout_ratio=0.1, num_classes=6, norm_cfg=norm_cfg, align_corners=False,\n"
+                "        loss_decode=dict(type='MyLoss', loss_weight=1.0)),\n"
+                "    auxiliary_head=dict(type='FCNHead', in_channels=1024, in_index=2, channels=256, num_convs=1,\n"
+                "        num_classes=6, norm_cfg=norm_cfg, align_corners=False),\n"
+                "    train_cfg=dict(), test_cfg=dict(mode='whole'))\n")
+    args = SimpleNamespace(pred_model_wts=wts, pred_model_cfg=cfg_path, sem_gpu_id=0)
+    m = PEANUT_Prediction_Model(args)
+    assert m.model.CLASSES == ck["meta"]["CLASSES"]
+    full_map = _inputs(1, 14, 104, 88, seed=21)[0].numpy()
+    got = m.get_prediction(full_map)
+    ref = pspnet_ref.get_prediction(sd, full_map, cfg)
+    assert got.shape == (6, 104, 88) and np.abs(got - ref).max() <= TOL
