@@ -1,0 +1,231 @@
+/* ORACLE (test infrastructure, not product code): CPU restatement of scikit-fmm's `skfmm.distance(phi, dx=1)` for
+ * 2-D masked arrays -- the call the reference makes at nav/agent/agent_state.py:391 (update_global_goal) and
+ * nav/agent/utils/fmm_planner.py:65,73 (FMMPlanner.set_goal / set_multi_goal).
+ *
+ * PARITY UNPINNED.  scikit-fmm (pinned `scikit-fmm==2019.1.30`, peanut.Dockerfile:8) is a third-party dependency
+ * that is neither vendored in /root/reference nor installed in this image, and the reference holds no test or
+ * fixture at this boundary.  What follows restates its PUBLISHED algorithm (J. Furlong, scikit-fmm:
+ * skfmm/base_marcher.cpp, distance_marcher.cpp, heap.cpp, pfmm.py): Sethian's fast marching method with a binary
+ * min-heap, second-order upwind finite differences (order = 2, the default) falling back to first order where the
+ * second upwind neighbour is not frozen / not monotone, masked cells excluded from every stencil, cells the front
+ * never reaches returned masked.
+ *
+ *   initialise : every unmasked cell with phi == 0 is Frozen at distance 0 (distanceMarcher::initalizeFrozen; the
+ *                sign-change interpolation branch never fires for the reference's phi in {0, 1});
+ *                every Far neighbour of a Frozen cell becomes Narrow with a tentative distance (initalizeNarrow);
+ *   march      : pop the Narrow cell of smallest |d|, freeze it, recompute its non-frozen neighbours, and -- second
+ *                order only -- the Narrow cell two steps away behind a Frozen neighbour (baseMarcher::solve);
+ *   update     : per axis take the Frozen neighbour of smaller |d| (v1); if the cell behind it is Frozen with
+ *                d2 <= v1 use the second-order term  (9/4) (u - (4 v1 - d2)/3)^2 , else (u - v1)^2 ; solve
+ *                sum = 1 for the larger root (distanceMarcher::updatePointOrderTwo / solveQuadratic).
+ *
+ * Second-order rule.  The second upwind neighbour n2 (two cells from the point, behind the Frozen neighbour n1) is
+ * used when it is Frozen and strictly closer to the contour than n1 on the point's own side (phi > 0: d2 < v1).
+ * Two details of scikit-fmm's test could not be checked without its source and are fixed here by what its
+ * documented outputs imply: (i) the comparison is strict -- the `skfmm.distance` docstring example
+ * (phi = ones((3,3)), phi[1,1] = -1 -> corners 1.20710678 = 0.5 + 1/sqrt(2)) is the FIRST-order value although the
+ * second neighbour is Frozen at an equal 0.5; (ii) the side is taken from the sign of phi at the point, so a cell
+ * next to an exact zero of phi (the reference plants one at the agent / goal cell) gets distance 1, not the 1/3 a
+ * sign test on v1 == 0 would give.  Either way only cells within two steps of a seed are affected.
+ *
+ * Heap tie-breaking follows a textbook binary heap (push at the end + sift up, pop = move last to the root + sift
+ * down, strict comparisons); scikit-fmm's exact order among EQUAL keys cannot be reproduced without its source and
+ * only matters for cells at exactly equal distance.
+ *
+ * Build: gcc -O2 -shared -fPIC -o oracle/_build/libfmm_ref.so oracle/fmm_ref.c -lm   (oracle/fmm_ref.py does it)
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { FAR = 0, NARROW = 1, FROZEN = 2, MASK = 3 };
+
+typedef struct {
+  int n;          /* elements in the heap */
+  int* addr;      /* heap position -> cell */
+  double* key;    /* heap position -> |distance| */
+  int* pos;       /* cell -> heap position (-1: not in the heap) */
+} heap_t;
+
+static void heap_swap(heap_t* h, int a, int b) {
+  int ca = h->addr[a], cb = h->addr[b];
+  double ka = h->key[a];
+  h->addr[a] = cb; h->key[a] = h->key[b]; h->pos[cb] = a;
+  h->addr[b] = ca; h->key[b] = ka; h->pos[ca] = b;
+}
+static void sift_up(heap_t* h, int i) {
+  while (i > 0) {
+    int p = (i - 1) / 2;
+    if (h->key[i] < h->key[p]) { heap_swap(h, i, p); i = p; } else break;
+  }
+}
+static void sift_down(heap_t* h, int i) {
+  for (;;) {
+    int l = 2 * i + 1, r = l + 1, m = i;
+    if (l < h->n && h->key[l] < h->key[m]) m = l;
+    if (r < h->n && h->key[r] < h->key[m]) m = r;
+    if (m == i) break;
+    heap_swap(h, i, m);
+    i = m;
+  }
+}
+static void heap_push(heap_t* h, int cell, double key) {
+  int i = h->n++;
+  h->addr[i] = cell; h->key[i] = key; h->pos[cell] = i;
+  sift_up(h, i);
+}
+static void heap_set(heap_t* h, int cell, double key) {
+  int i = h->pos[cell];
+  double old = h->key[i];
+  h->key[i] = key;
+  if (key < old) sift_up(h, i); else sift_down(h, i);
+}
+static int heap_pop(heap_t* h, double* key) {
+  int cell = h->addr[0];
+  *key = h->key[0];
+  h->pos[cell] = -1;
+  h->n--;
+  if (h->n > 0) {
+    h->addr[0] = h->addr[h->n]; h->key[0] = h->key[h->n]; h->pos[h->addr[0]] = 0;
+    sift_down(h, 0);
+  }
+  return cell;
+}
+
+typedef struct {
+  int H, W, order;
+  const double* phi;
+  unsigned char* flag;
+  double* dist;
+} grid_t;
+
+/* neighbour `dir` steps along `dim` (0 = rows, 1 = cols); -1 when outside the array or masked (_getN(..., Mask)) */
+static int get_n(const grid_t* g, int cell, int dim, int dir) {
+  int r = cell / g->W, c = cell % g->W;
+  if (dim == 0) { r += dir; if (r < 0 || r >= g->H) return -1; }
+  else { c += dir; if (c < 0 || c >= g->W) return -1; }
+  int a = r * g->W + c;
+  return g->flag[a] == MASK ? -1 : a;
+}
+
+static double solve_quadratic(const grid_t* g, int i, double a, double b, double c) {
+  c -= 1.0;
+  double det = b * b - 4.0 * a * c;
+  if (det >= 0.0) {
+    if (g->phi[i] > DBL_EPSILON) return (-b + sqrt(det)) / 2.0 / a;
+    return (-b - sqrt(det)) / 2.0 / a;
+  }
+  return 0.0;   /* no real root: the caller lowers the order */
+}
+
+static double update_point_order_one(const grid_t* g, int i) {
+  double a = 0, b = 0, c = 0;
+  for (int dim = 0; dim < 2; ++dim) {
+    double value = DBL_MAX;
+    for (int j = -1; j < 2; j += 2) {
+      int n = get_n(g, i, dim, j);
+      if (n != -1 && g->flag[n] == FROZEN && fabs(g->dist[n]) < fabs(value)) value = g->dist[n];
+    }
+    if (value < DBL_MAX) { a += 1.0; b -= 2.0 * value; c += value * value; }
+  }
+  return solve_quadratic(g, i, a, b, c);
+}
+
+static double update_point_order_two(const grid_t* g, int i) {
+  const double aa = 9.0 / 4.0, oneThird = 1.0 / 3.0;
+  double a = 0, b = 0, c = 0;
+  for (int dim = 0; dim < 2; ++dim) {
+    double value1 = DBL_MAX, value2 = DBL_MAX;
+    for (int j = -1; j < 2; j += 2) {
+      int n = get_n(g, i, dim, j);
+      if (n != -1 && g->flag[n] == FROZEN && fabs(g->dist[n]) < fabs(value1)) {
+        value1 = g->dist[n];
+        int n2 = get_n(g, i, dim, j * 2);
+        /* monotone second neighbour on the side phi[i] lies on (see "Second-order rule" in the header) */
+        if (n2 != -1 && g->flag[n2] == FROZEN &&
+            ((g->phi[i] > 0 && g->dist[n2] < value1) || (g->phi[i] < 0 && g->dist[n2] > value1)))
+          value2 = g->dist[n2];
+        else
+          value2 = DBL_MAX;
+      }
+    }
+    if (value2 < DBL_MAX) {
+      double tp = oneThird * (4.0 * value1 - value2);
+      a += aa; b -= 2.0 * aa * tp; c += aa * tp * tp;
+    } else if (value1 < DBL_MAX) {
+      a += 1.0; b -= 2.0 * value1; c += value1 * value1;
+    }
+  }
+  double r = solve_quadratic(g, i, a, b, c);
+  if (r == 0.0) r = update_point_order_one(g, i);
+  return r;
+}
+
+static double update_point(const grid_t* g, int i) {
+  return g->order == 2 ? update_point_order_two(g, i) : update_point_order_one(g, i);
+}
+
+/* phi [H*W] (row-major doubles), mask [H*W] (1 = masked), out [H*W]: distance, or DBL_MAX for masked / never
+ * reached cells (what pfmm.post_process_result turns into the masked entries of the returned MaskedArray).
+ * Returns 0, or 2 when no cell is frozen initially (scikit-fmm's "the array phi contains no zero contour"). */
+int fmm_ref_distance(const double* phi, const unsigned char* mask, int H, int W, int order, double* out) {
+  const int size = H * W;
+  grid_t g = {H, W, order, phi, (unsigned char*)malloc(size), out};
+  heap_t h = {0, (int*)malloc(sizeof(int) * size), (double*)malloc(sizeof(double) * size), (int*)malloc(sizeof(int) * size)};
+  int frozen = 0;
+  for (int i = 0; i < size; ++i) {
+    g.flag[i] = mask && mask[i] ? MASK : FAR;
+    g.dist[i] = 0.0;
+    h.pos[i] = -1;
+  }
+  for (int i = 0; i < size; ++i)
+    if (g.flag[i] != MASK && phi[i] == 0.0) { g.flag[i] = FROZEN; g.dist[i] = 0.0; ++frozen; }
+  if (!frozen) { free(g.flag); free(h.addr); free(h.key); free(h.pos); return 2; }
+  /* initalizeNarrow */
+  for (int i = 0; i < size; ++i)
+    if (g.flag[i] == FAR)
+      for (int dim = 0; dim < 2; ++dim)
+        for (int j = -1; j < 2; j += 2) {
+          int n = get_n(&g, i, dim, j);
+          if (n != -1 && g.flag[n] == FROZEN && g.flag[i] == FAR) {
+            g.flag[i] = NARROW;
+            double d = update_point(&g, i);
+            g.dist[i] = d;
+            heap_push(&h, i, fabs(d));
+          }
+        }
+  /* solve */
+  while (h.n > 0) {
+    double value;
+    int addr = heap_pop(&h, &value);
+    g.flag[addr] = FROZEN;
+    for (int dim = 0; dim < 2; ++dim)
+      for (int j = -1; j < 2; j += 2) {
+        int n = get_n(&g, addr, dim, j);
+        if (n != -1 && g.flag[n] != FROZEN) {
+          if (g.flag[n] == NARROW) {
+            double d = update_point(&g, n);
+            if (d) { heap_set(&h, n, fabs(d)); g.dist[n] = d; }
+          } else if (g.flag[n] == FAR) {
+            double d = update_point(&g, n);
+            if (d) { g.dist[n] = d; g.flag[n] = NARROW; heap_push(&h, n, fabs(d)); }
+          }
+        }
+        if (order == 2) {   /* the Narrow cell two steps away behind a Frozen neighbour gains a second-order term */
+          int ln = get_n(&g, addr, dim, j);
+          if (ln != -1 && g.flag[ln] == FROZEN) {
+            int n2 = get_n(&g, addr, dim, j * 2);
+            if (n2 != -1 && g.flag[n2] == NARROW) {
+              double d = update_point(&g, n2);
+              if (d) { heap_set(&h, n2, fabs(d)); g.dist[n2] = d; }
+            }
+          }
+        }
+      }
+  }
+  for (int i = 0; i < size; ++i)
+    if (g.flag[i] == MASK || g.flag[i] == FAR) g.dist[i] = DBL_MAX;
+  free(g.flag); free(h.addr); free(h.key); free(h.pos);
+  return 0;
+}

@@ -367,7 +367,7 @@ def test_config5_full_size_properties():
     y2 = m.get_prediction_batch(x2, apply_sigmoid=False)
     assert torch.equal(y2[3], y[3]) and not torch.equal(y2[4], y[4])
     one = m.get_prediction_batch(x[3:4].contiguous(), apply_sigmoid=False)
-    assert (one[0] - y[3]).abs().max().item() <= 2e-5
+    assert (one[0] - y[3]).abs().max().item() <= 5e-5      # other batch shape -> other tail split-K plan: last bits only
     p = m.get_prediction_batch(x, apply_sigmoid=True)
     assert bool(((p > 0) & (p < 1)).all()) and (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
     del p, y2, m
