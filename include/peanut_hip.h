@@ -291,6 +291,50 @@ int peanut_conv_forward(peanut_conv_t* c, const float* x_dev, const float* x2_de
                         float* y_dev, int B, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Long-term goal selection: Agent_State.update_global_goal
+ * (nav/agent/agent_state.py:376-415) and the geodesic distance transform behind it and behind
+ * FMMPlanner.set_goal / set_multi_goal (nav/agent/utils/fmm_planner.py:55-75).  The reference calls scikit-fmm's
+ * heap-ordered fast marching on the host (`skfmm.distance`, second order); here the same second-order upwind
+ * discretisation is solved as a fixed point by tile-wise relaxation (csrc/goal.hip).  scikit-fmm is an absent
+ * third-party dependency: parity is pinned against the restatement in oracle/fmm_ref.c only (PARITY UNPINNED).
+ * Distances are doubles, in cells.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct peanut_goal peanut_goal_t;
+/* full_h x full_w = the full map (960 x 960); col_rad = args.col_rad, the radius of the dilation disk
+ * (skimage.morphology.disk(col_rad), agent_state.py:85).  Allocates ~35 B per cell.  Synchronous. */
+int peanut_goal_create(peanut_goal_t** out, int full_h, int full_w, int col_rad);
+void peanut_goal_destroy(peanut_goal_t* g);
+/* Agent_State.reset (:94-105): forget the last distance weights (`self.dd_wt = None`). */
+int peanut_goal_reset(peanut_goal_t* g);
+/* relaxation rounds the last solve took (diagnostics) */
+int peanut_goal_rounds(peanut_goal_t* g);
+/* agent_state.py:382-386: trav = ~binary_dilation(rint(full_map[0]), disk(col_rad)); trav[collision_map == 1] = 0;
+ * trav[visited_vis == 1] = 1.  full_obstacle device fp32 [H,W]; collision_map / visited_vis device uint8 [H,W] or
+ * NULL; trav_out device uint8 [H,W] (NULL: kept inside the handle). */
+int peanut_goal_traversible(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map,
+                            const uint8_t* visited_vis, uint8_t* trav_out, void* stream);
+/* FMMPlanner.set_goal (goal_mask NULL, one goal cell) / set_multi_goal (goal_mask device uint8 [H,W], 1 = goal;
+ * pass goal_r = -1): traversible device uint8 [H,W] (0 = masked; goal cells are unmasked like
+ * `traversible_ma[goal] = 0` does).  dist_out device double [H,W]; cells that are masked or never reached get
+ * +inf (fill_mode 0) or max(reached) + 1 (fill_mode 1 = `ma.filled(dd, np.max(dd) + 1)`, fmm_planner.py:66,74).
+ * Synchronises the stream (the solver polls a convergence counter). */
+int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint8_t* goal_mask, int goal_r, int goal_c,
+                        int fill_mode, double* dist_out, void* stream);
+/* The whole of update_global_goal: traversible map, geodesic field from the agent's cell
+ * (clip(loc + lmb[0/2], 0, full - 1)), weights exp(-dd / (dist_weight_temperature / map_resolution)) over the local
+ * window lmb = {gx1, gx2, gy1, gy2} with the "sum < 10: keep the last weights" rule, value = target_pred * weights
+ * (temperature -1: target_pred alone; 0: frontier mode, exp(-dd'/100) with dd' = inf below 60) and its
+ * first-occurrence argmax.  target_pred device fp32 [gx2-gx1, gy2-gy1].  Outputs (host): goal_rc_out = the argmax
+ * cell in local-map coordinates (`np.unravel_index(value.argmax(), value.shape)`); stats_out (optional) =
+ * {value max, sum of the fresh weights, 1 if the last weights were kept, relaxation rounds}; dist_out (optional,
+ * device double [H,W], +inf = masked / unreachable) and value_out (optional, device double [w,h]) for tests.
+ * The "avoid repeating the last goal" bookkeeping (:412-415) is host logic of the caller.  Synchronises. */
+int peanut_goal_select(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map,
+                       const uint8_t* visited_vis, const int lmb[4], int loc_r, int loc_c, const float* target_pred,
+                       double dist_weight_temperature, int map_resolution, int goal_rc_out[2], double stats_out[4],
+                       double* dist_out, double* value_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU: collation of the predicted maps for logging.  One process per GPU, maps /
  * episodes sharded with no data-path collective -- the reference shards by hand with --start_ep/--end_ep/
  * --sem_gpu_id (nav/arguments.py:15-20, nav/collect.py:37-50) and never communicates; this all-gather is the one

@@ -39,7 +39,9 @@ def agent_args(**over):
              switch_step=0, update_goal_freq=10, goal_reached_dist=75, prediction_window=720, visualize=0,
              frame_height=120, frame_width=160, env_frame_height=480, env_frame_width=640, vision_range=100,
              hfov=79.0, du_scale=1, cat_pred_threshold=5.0, exp_pred_threshold=1.0, map_pred_threshold=0.1,
-             camera_height=0.88, min_depth=0.5, max_depth=5.0, sem_pred_prob_thr=0.95, goal_thr=0.985)
+             camera_height=0.88, min_depth=0.5, max_depth=5.0, sem_pred_prob_thr=0.95, goal_thr=0.985,
+             dist_weight_temperature=500, timestep_limit=499,
+             select_goal=False)     # peanut_amd-only switch: the round-1 fixtures drive Agent_State without update_global_goal
     a.update(over)
     return Namespace(**a)
 

@@ -181,6 +181,35 @@ int fmm_ref_distance(const double* phi, const unsigned char* mask, int H, int W,
   }
   for (int i = 0; i < size; ++i)
     if (g.flag[i] != MASK && phi[i] == 0.0) { g.flag[i] = FROZEN; g.dist[i] = 0.0; ++frozen; }
+  /* cells next to a sign change of phi: distance to the interpolated zero crossing (distanceMarcher::initalizeFrozen,
+   * second loop).  Never taken for the reference's phi in {0, 1}; kept so that the restatement can be checked against
+   * scikit-fmm's published docstring example. */
+  {
+    double* init = (double*)malloc(sizeof(double) * size);
+    unsigned char* border = (unsigned char*)calloc(size, 1);
+    for (int i = 0; i < size; ++i) {
+      if (g.flag[i] != FAR) continue;
+      double ld[2] = {0, 0};
+      int borders = 0;
+      for (int dim = 0; dim < 2; ++dim)
+        for (int j = -1; j < 2; j += 2) {
+          int n = get_n(&g, i, dim, j);
+          if (n != -1 && phi[i] * phi[n] < 0) {
+            borders = 1;
+            double d = phi[i] / (phi[i] - phi[n]);      /* dx = 1 */
+            if (ld[dim] == 0 || ld[dim] > d) ld[dim] = d;
+          }
+        }
+      if (borders) {
+        double dsum = 0;
+        for (int dim = 0; dim < 2; ++dim) if (ld[dim] > 0) dsum += 1 / ld[dim] / ld[dim];
+        init[i] = phi[i] < 0 ? -sqrt(1 / dsum) : sqrt(1 / dsum);
+        border[i] = 1;
+      }
+    }
+    for (int i = 0; i < size; ++i) if (border[i]) { g.flag[i] = FROZEN; g.dist[i] = init[i]; ++frozen; }
+    free(init); free(border);
+  }
   if (!frozen) { free(g.flag); free(h.addr); free(h.key); free(h.pos); return 2; }
   /* initalizeNarrow */
   for (int i = 0; i < size; ++i)

@@ -59,7 +59,12 @@ def generate(report):
     probes = [(480, 480), (470, 520), (520, 430), (400, 560), (600, 600), (300, 480)]
     last = {}
 
+    prev = {}
+
     def record(i, s, predicted):
+        cur = (int(s.loc_r + s.lmb[0]), int(s.loc_c + s.lmb[2]))
+        goal_ref.mark_visited(helper.visited_vis, prev.get("rc", cur), cur)      # the planner's trail (every step)
+        prev["rc"] = cur
         if not predicted:
             return
         s.update_global_goal()                                     # the reference's own method

@@ -19,6 +19,19 @@ def binary_dilation(image, footprint=None):
     return ndi.binary_dilation(np.asarray(image) != 0, structure=footprint)
 
 
+def mark_visited(visited_vis, prev_rc, cur_rc, half=2):
+    """Test-harness stand-in for the trail Agent_Helper draws into ``visited_vis`` between consecutive agent cells
+    (agent_helper.py:262-266, vu.draw_line): a (2*half+1)-wide bar of samples along the segment, full-map cells."""
+    (r0, c0), (r1, c1) = prev_rc, cur_rc
+    n = max(abs(r1 - r0), abs(c1 - c0), 1)
+    H, W = visited_vis.shape
+    for k in range(n + 1):
+        r = int(round(r0 + (r1 - r0) * k / n))
+        c = int(round(c0 + (c1 - c0) * k / n))
+        visited_vis[max(r - half, 0):min(r + half + 1, H), max(c - half, 0):min(c + half + 1, W)] = 1
+    return visited_vis
+
+
 def traversible_map(full_obstacle, selem, collision_map, visited_vis):
     """agent_state.py:382-386."""
     trav = binary_dilation(np.rint(full_obstacle), selem) != True  # noqa: E712

@@ -96,6 +96,14 @@ SIGNATURES = {
     "peanut_preprocess_obs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
     "peanut_seg_accumulate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_int, _P, _P]),
+    "peanut_goal_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int]),
+    "peanut_goal_destroy": (None, [_P]),
+    "peanut_goal_reset": (C.c_int, [_P]),
+    "peanut_goal_rounds": (C.c_int, [_P]),
+    "peanut_goal_traversible": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "peanut_fmm_distance": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "peanut_goal_select": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int * 4), C.c_int, C.c_int, _P, C.c_double, C.c_int,
+                                     C.POINTER(C.c_int * 2), C.POINTER(C.c_double * 4), _P, _P, _P]),
     "peanut_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte * 128)]),
     "peanut_comm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.POINTER(C.c_ubyte * 128)]),
     "peanut_comm_destroy": (None, [_P]),

@@ -7,8 +7,12 @@ differences, all on purpose:
   ``update_prediction`` crops, predicts, pads and masks ON the device (the reference copies the
   14x720x720 crop to the host, back to the GPU inside ``run_inference`` and the result back again,
   agent_state.py:361 -> prediction.py:128-131,268);
-* goal selection (``update_global_goal`` :376-415, scikit-fmm) and ``update_goal_map`` (:418-446,
-  scikit-image) are CPU planner glue outside the hot path and are not here.
+* long-term goal selection (``update_global_goal`` :376-415) runs on the device too (csrc/goal.hip: dilation,
+  geodesic field, distance weights and the argmax; scikit-fmm's fast marching replaced by a fixed-point solver of
+  the same discretisation).  ``collision_map`` / ``visited_vis``, which the reference
+  reads from ``self.helper`` (the CPU planner's bookkeeping), are attributes here (uint8 HIP tensors, zero until a
+  planner writes them);
+* ``update_goal_map`` (:418-446, scikit-image erosion of the goal category) is CPU planner glue and is not here.
 
 The 12-byte pose read-back per step (`local_pose.cpu()`, :276) is kept: the integer cell indices it
 yields drive Python-side slicing exactly as in the reference."""
@@ -30,7 +34,8 @@ def default_args(**over):
              switch_step=0, update_goal_freq=10, goal_reached_dist=75, prediction_window=720, visualize=0,
              frame_height=120, frame_width=160, env_frame_height=480, env_frame_width=640, vision_range=100,
              hfov=79.0, du_scale=1, cat_pred_threshold=5.0, exp_pred_threshold=1.0, map_pred_threshold=0.1,
-             camera_height=0.88, min_depth=0.5, max_depth=5.0, sem_pred_prob_thr=0.95, goal_thr=0.985)
+             camera_height=0.88, min_depth=0.5, max_depth=5.0, sem_pred_prob_thr=0.95, goal_thr=0.985,
+             dist_weight_temperature=500, timestep_limit=499)
     a.update(over)
     return Namespace(**a)
 
@@ -77,6 +82,12 @@ class Agent_State:
         self.target_pred = None
         self.global_goals = [[0, 0]]
         self.dist_to_goal = float("inf")
+        # long-term goal selection (agent_state.py:376-415); the planner-side maps live here as HIP tensors
+        self.collision_map = torch.zeros((self.full_w, self.full_h), dtype=torch.uint8, device=self.device)
+        self.visited_vis = torch.zeros((self.full_w, self.full_h), dtype=torch.uint8, device=self.device)
+        self._goal = None
+        self.last_global_goal = None
+        self.value_max = None
 
     # ---- agent_state.py:94-105 ----
     def reset(self):
@@ -86,6 +97,11 @@ class Agent_State:
         self.found_goal = False
         self.init_map_and_pose()
         self.target_pred = None
+        self.last_global_goal = None
+        self.collision_map.zero_()              # Agent_Helper.reset (agent_helper.py:114-115)
+        self.visited_vis.zero_()
+        if self._goal is not None:
+            self._goal.reset()                  # self.dd_wt = None
 
     # ---- agent_state.py:154-178 ----
     def get_local_map_boundaries(self, agent_loc, local_sizes, full_sizes):
@@ -214,6 +230,23 @@ class Agent_State:
         target_pred = target_pred * (self.local_map[1] < 0.5)        # unexplored regions only
         self.target_pred = target_pred
 
+    # ---- agent_state.py:376-415, on the device ----
+    def update_global_goal(self):
+        """Geodesic-distance-weighted argmax of the target prediction (csrc/goal.hip).  Needs ``target_pred`` (from
+        ``update_prediction``) unless ``dist_weight_temperature == 0``."""
+        from .goal import GeodesicSolver
+        args = self.args
+        if self._goal is None:
+            self._goal = GeodesicSolver(self.full_w, self.full_h, int(args.col_rad), device=self.device)
+        res = self._goal.select(self.full_map[0], self.collision_map, self.visited_vis, self.lmb, (self.loc_r, self.loc_c),
+                                self.target_pred, float(getattr(args, "dist_weight_temperature", 500)), int(args.map_resolution))
+        self.value_max = res["value_max"]
+        self.goal_rounds = res["rounds"]
+        new_global_goal = [res["goal"]]
+        if new_global_goal != self.last_global_goal:      # avoid repeating the last goal
+            self.last_global_goal = self.global_goals
+            self.global_goals = new_global_goal
+
     # ---- agent_state.py:449-454 ----
     def inc_step(self):
         args = self.args
@@ -224,8 +257,9 @@ class Agent_State:
     # ---- perception half of update_state (agent_state.py:213-245) ----
     def update_state(self, obs, infos):
         """Map update -> (every num_local_steps) full-map update -> (every update_goal_freq steps,
-        at step 0, or near the goal) prediction.  Returns whether a prediction ran.  Goal selection and
-        planner-input assembly (:244-263) are outside the hot path."""
+        at step 0, or near the goal) prediction + long-term goal selection (:240-245; ``args.select_goal = False``
+        skips the latter).  Returns whether a prediction ran.  ``update_goal_map`` and the planner-input assembly
+        (:246-263) are CPU planner glue outside the hot path."""
         args = self.args
         self.goal_cat = infos['goal_cat_id']
         self.poses = torch.from_numpy(np.asarray(infos['sensor_pose'])).float().to(self.device)
@@ -238,6 +272,8 @@ class Agent_State:
                 self.dist_to_goal < args.goal_reached_dist) and self.step >= args.switch_step \
                 and self.prediction_model is not None:
             self.update_prediction()
+            if getattr(args, "select_goal", True):
+                self.update_global_goal()
             predicted = True
         self.inc_step()
         return predicted

@@ -1,0 +1,410 @@
+// Long-term goal selection on the device: the reference's
+// Agent_State.update_global_goal (nav/agent/agent_state.py:376-415) and the geodesic distance transform of
+// FMMPlanner.set_goal / set_multi_goal (nav/agent/utils/fmm_planner.py:55-75).
+//
+// The reference computes the geodesic field with scikit-fmm (`skfmm.distance`, heap-ordered fast marching, second
+// order) on the host: ~0.2 s per call on a 960x960 map, the largest CPU cost per step once stages 1-3 run on the
+// GPU.  A heap is inherently serial, so the field is solved here as the FIXED POINT of the same discretisation
+// (second-order upwind differences with the first-order fallback, masked cells excluded from every stencil; see
+// oracle/fmm_ref.c for the update rule that is mirrored operation by operation, in double):
+//
+//   * the map is cut into 32x32 tiles; a workgroup stages a tile plus a 2-cell halo in LDS (36x36 doubles) and
+//     relaxes it (Jacobi sweeps, two barriers each, 4 cells per lane) until nothing in the tile changes;
+//   * a tile that changed wakes its four neighbours for the next round (the stencil is axis-aligned: no diagonal
+//     dependency); rounds are plain launches over the tile grid in which sleeping tiles exit at once; the host
+//     reads one counter every few rounds and stops when a round changed nothing;
+//   * an update depends only on the neighbours' values (no min with the own old value): the second-order term is
+//     not monotone in the second neighbour, so "keep the smaller" could freeze a transient; without it the
+//     iteration has no memory and settles -- in causal order, like the marching front -- on the unique fixed point.
+//
+// Equality with the heap-ordered march is up to which cells take the second-order term while exactly tied values
+// meet; tests hold the field to <= 0.5 cell of the oracle and the selected goal cell to equality.
+//
+// The rest of update_global_goal is fused around it: obstacle dilation by the collision disk + collision / visited
+// overrides -> traversible map (:382-386), exp(-d / temperature) weights with the "stuck: keep the last weights"
+// rule (:395-399), value = target_pred * weights and its first-occurrence argmax (:401-413).
+#include <math.h>
+
+#include <vector>
+
+#include "net_common.h"
+
+#pragma clang fp contract(off)
+
+namespace peanut {
+namespace {
+
+constexpr int TILE = 32, HALO = 2, LT = TILE + 2 * HALO;   // 36
+constexpr int MAX_SWEEPS = 96;                             // per round and tile (a front crosses a tile in <= 64)
+constexpr int ROUNDS_PER_CHECK = 8;
+
+enum : unsigned char { ST_MASKED = 0, ST_FREE = 1, ST_SEED = 2 };
+
+// ---- traversible map: ~dilate(rint(obstacle), disk(rad)), collision -> 0, visited -> 1  (agent_state.py:382-386) ----
+__global__ __launch_bounds__(256) void goal_trav_kernel(const float* __restrict__ obst, const unsigned char* __restrict__ collision,
+                                                        const unsigned char* __restrict__ visited, int H, int W, int rad,
+                                                        unsigned char* __restrict__ trav) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (r >= H || c >= W) return;
+  bool blocked = false;
+  for (int dy = -rad; dy <= rad && !blocked; ++dy) {
+    const int rr = r + dy;
+    if (rr < 0 || rr >= H) continue;
+    for (int dx = -rad; dx <= rad; ++dx) {
+      if (dx * dx + dy * dy > rad * rad) continue;
+      const int cc = c + dx;
+      if (cc < 0 || cc >= W) continue;
+      if (rintf(obst[(size_t)rr * W + cc]) != 0.f) { blocked = true; break; }
+    }
+  }
+  unsigned char t = blocked ? 0 : 1;
+  const size_t i = (size_t)r * W + c;
+  if (collision && collision[i] == 1) t = 0;
+  if (visited && visited[i] == 1) t = 1;
+  trav[i] = t;
+}
+
+// state / distance initialisation: masked where not traversible, seeds (one cell and/or a mask) at distance 0
+__global__ __launch_bounds__(256) void fmm_init_kernel(const unsigned char* __restrict__ trav, const unsigned char* __restrict__ seed_mask,
+                                                       int seed_r, int seed_c, int H, int W, unsigned char* __restrict__ state,
+                                                       double* __restrict__ dist, unsigned char* __restrict__ active, int tiles_x) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int r = i / W, c = i - r * W;
+  const bool seed = (r == seed_r && c == seed_c) || (seed_mask && seed_mask[i] == 1);
+  state[i] = seed ? ST_SEED : (trav[i] ? ST_FREE : ST_MASKED);
+  dist[i] = seed ? 0.0 : INFINITY;
+  if (seed) active[(r / TILE) * tiles_x + (c / TILE)] = 1;
+}
+
+// one axis of distanceMarcher::updatePointOrderTwo: m1/m2 = the neighbours one and two steps towards smaller
+// indices, p1/p2 towards larger ones (INFINITY = masked / outside / not reached yet)
+struct AxisTerm { double a, b, c, v1; };
+__device__ __forceinline__ AxisTerm axis_term(double m1, double m2, double p1, double p2) {
+  AxisTerm t{0.0, 0.0, 0.0, INFINITY};
+  double v1 = INFINITY, v2 = INFINITY;
+  if (m1 < v1) { v1 = m1; v2 = (m2 < v1) ? m2 : INFINITY; }      // j = -1 first; j = +1 only when strictly closer
+  if (p1 < v1) { v1 = p1; v2 = (p2 < v1) ? p2 : INFINITY; }
+  t.v1 = v1;
+  if (v2 < INFINITY) {
+    const double aa = 9.0 / 4.0, tp = (1.0 / 3.0) * (4.0 * v1 - v2);
+    t.a = aa; t.b = -2.0 * aa * tp; t.c = aa * tp * tp;
+  } else if (v1 < INFINITY) {
+    t.a = 1.0; t.b = -2.0 * v1; t.c = v1 * v1;
+  }
+  return t;
+}
+__device__ __forceinline__ double solve_root(double a, double b, double c) {
+  c -= 1.0;
+  const double det = b * b - 4.0 * a * c;
+  return det >= 0.0 ? (-b + sqrt(det)) / 2.0 / a : -1.0;
+}
+__device__ __forceinline__ double update_cell(const AxisTerm& y, const AxisTerm& x) {
+  const bool hy = y.v1 < INFINITY, hx = x.v1 < INFINITY;
+  if (!hy && !hx) return INFINITY;
+  if (hy && hx) {
+    const double u = solve_root(y.a + x.a, y.b + x.b, y.c + x.c);
+    if (u >= fmax(y.v1, x.v1)) return u;                 // causal two-axis solution
+    const AxisTerm& s = (y.v1 <= x.v1) ? y : x;          // transient only: the farther axis is not upwind (yet)
+    return solve_root(s.a, s.b, s.c);
+  }
+  const AxisTerm& s = hy ? y : x;
+  return solve_root(s.a, s.b, s.c);
+}
+
+__global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dist, const unsigned char* __restrict__ state, int H, int W,
+                                                        int tiles_x, int tiles_y, const unsigned char* __restrict__ active_in,
+                                                        unsigned char* __restrict__ active_out, unsigned int* __restrict__ changed_tiles) {
+  const int tile = blockIdx.x;
+  if (!active_in[tile]) return;
+  __shared__ double d[LT][LT + 1];
+  __shared__ unsigned char st[LT][LT + 4];
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int r0 = ty * TILE - HALO, c0 = tx * TILE - HALO;
+  for (int i = threadIdx.x; i < LT * LT; i += 256) {
+    const int ly = i / LT, lx = i - ly * LT;
+    const int r = r0 + ly, c = c0 + lx;
+    const bool in = r >= 0 && r < H && c >= 0 && c < W;
+    d[ly][lx] = in ? dist[(size_t)r * W + c] : INFINITY;
+    st[ly][lx] = in ? state[(size_t)r * W + c] : ST_MASKED;
+  }
+  __syncthreads();
+  const int lx = HALO + (threadIdx.x & 31), lyb = HALO + (threadIdx.x >> 5);   // cells (lyb + 8k, lx), k = 0..3
+  bool ever = false;
+  int sweeps = 0;
+  for (; sweeps < MAX_SWEEPS; ++sweeps) {
+    double nv[4];
+    bool ch = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ly = lyb + 8 * k;
+      const double old = d[ly][lx];
+      nv[k] = old;
+      if (st[ly][lx] == ST_FREE) {
+        const AxisTerm y = axis_term(d[ly - 1][lx], d[ly - 2][lx], d[ly + 1][lx], d[ly + 2][lx]);
+        const AxisTerm x = axis_term(d[ly][lx - 1], d[ly][lx - 2], d[ly][lx + 1], d[ly][lx + 2]);
+        const double u = update_cell(y, x);
+        nv[k] = u;
+        ch |= (u != old);
+      }
+    }
+    const int any = __syncthreads_or(ch);
+    if (!any) break;
+    ever = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[lyb + 8 * k][lx] = nv[k];
+    __syncthreads();
+  }
+  if (!ever) return;      // (uniform: `ever` derives from __syncthreads_or)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ly = lyb + 8 * k, r = r0 + ly, c = c0 + lx;
+    if (r < H && c < W) dist[(size_t)r * W + c] = d[ly][lx];
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(changed_tiles, 1u);
+    if (sweeps == MAX_SWEEPS) active_out[tile] = 1;       // not settled inside the budget: go on next round
+    if (ty > 0) active_out[tile - tiles_x] = 1;
+    if (ty + 1 < tiles_y) active_out[tile + tiles_x] = 1;
+    if (tx > 0) active_out[tile - 1] = 1;
+    if (tx + 1 < tiles_x) active_out[tile + 1] = 1;
+  }
+}
+
+// max over the reached cells (for `ma.filled(dd, np.max(dd) + 1)`); bits of a non-negative double order like an integer
+__global__ __launch_bounds__(256) void fmm_max_kernel(const double* __restrict__ dist, int n, unsigned long long* __restrict__ max_bits) {
+  double m = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double v = dist[i];
+    if (v < INFINITY && v > m) m = v;
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(m));
+}
+__global__ __launch_bounds__(256) void fmm_fill_kernel(const double* __restrict__ dist, int n, const unsigned long long* __restrict__ max_bits,
+                                                       double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double v = dist[i];
+  out[i] = v < INFINITY ? v : __longlong_as_double((long long)*max_bits) + 1.0;
+}
+
+// ---- weights over the local window: exp(-dd / temperature) (:395-396), their sum (:398) ----
+__global__ __launch_bounds__(256) void goal_weight_kernel(const double* __restrict__ dist, int W, int gx1, int gy1, int lw, int lh,
+                                                          double temperature, int frontier, double* __restrict__ wt, double* __restrict__ sum) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double w = 0.0;
+  if (i < lw * lh) {
+    const int r = i / lh, c = i - r * lh;
+    double dd = dist[(size_t)(gx1 + r) * W + (gy1 + c)];
+    if (frontier) {            // dist_weight_temperature == 0: frontier-based exploration (:404-406)
+      if (dd < 60.0) dd = INFINITY;
+      w = exp(-dd / 100.0);
+    } else {
+      w = exp(-dd / temperature);
+    }
+    wt[i] = w;
+  }
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sum, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// value = target_pred * dd_wt (or one of them alone) and its first-occurrence argmax (:401-413); two stages
+struct ArgMax { double v; int i; };
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__global__ __launch_bounds__(256) void goal_argmax_kernel(const float* __restrict__ target_pred, const double* __restrict__ wt_new,
+                                                          const double* __restrict__ wt_last, const double* __restrict__ sum, int have_last,
+                                                          int mode, int n, double* __restrict__ value_out, ArgMax* __restrict__ partial) {
+  // mode 0: target_pred * wt, 1: target_pred alone (temperature -1), 2: wt alone (temperature 0)
+  const bool keep_last = mode != 2 && have_last && *sum < 10.0;      // (:398) "stuck inside obstacle, use last dd_wt"
+  const double* wt = keep_last ? wt_last : wt_new;
+  ArgMax best{-INFINITY, 0x7fffffff};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double tp = target_pred ? (double)target_pred[i] : 1.0;
+    const double v = mode == 1 ? tp : (mode == 2 ? wt[i] : tp * wt[i]);
+    if (value_out) value_out[i] = v;
+    if (v > best.v) { best.v = v; best.i = i; }       // ascending i per lane: ties keep the first
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax other{__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
+    best = better(best, other);
+  }
+  __shared__ ArgMax part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = better(better(part[0], part[1]), better(part[2], part[3]));
+}
+__global__ __launch_bounds__(64) void goal_argmax_final_kernel(const ArgMax* __restrict__ partial, int nparts, const double* __restrict__ sum,
+                                                               int have_last, int mode, const double* __restrict__ wt_new,
+                                                               double* __restrict__ wt_last, int n, int* __restrict__ out_idx,
+                                                               double* __restrict__ out_val) {
+  ArgMax best{-INFINITY, 0x7fffffff};
+  for (int i = threadIdx.x; i < nparts; i += 64) best = better(best, partial[i]);
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax other{__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
+    best = better(best, other);
+  }
+  if (threadIdx.x == 0) {
+    out_idx[0] = best.i;
+    out_idx[1] = (mode != 2 && have_last && *sum < 10.0) ? 1 : 0;      // 1: the last weights were kept
+    out_val[0] = best.v;
+    out_val[1] = *sum;
+  }
+}
+
+}  // namespace
+}  // namespace peanut
+
+using namespace peanut;
+
+struct peanut_goal {
+  int H = 0, W = 0, rad = 0, tiles_x = 0, tiles_y = 0;
+  DevBuf trav, state, dist, active, counters, maxbits, wt_new, wt_last, sum, partial, out_idx, out_val, value;
+  bool have_last = false;
+  int last_lw = 0, last_lh = 0;
+  int last_rounds = 0;
+};
+
+namespace {
+
+int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* seed_mask, int seed_r, int seed_c, hipStream_t s) {
+  const int H = g->H, W = g->W, n = H * W, nt = g->tiles_x * g->tiles_y;
+  unsigned char* act = (unsigned char*)g->active.p;     // two flag arrays, ping-pong
+  PEANUT_HIP_CHECK(hipMemsetAsync(act, 0, 2 * (size_t)nt, s));
+  hipLaunchKernelGGL(fmm_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, trav, seed_mask, seed_r, seed_c, H, W,
+                     (unsigned char*)g->state.p, (double*)g->dist.p, act, g->tiles_x);
+  const int max_rounds = 8 * (g->tiles_x + g->tiles_y) * 4 + 64;    // generous bound on the front's path, in tiles
+  unsigned int* counters = (unsigned int*)g->counters.p;
+  std::vector<unsigned int> host(ROUNDS_PER_CHECK);
+  int cur = 0, round = 0;
+  for (; round < max_rounds; round += ROUNDS_PER_CHECK) {
+    PEANUT_HIP_CHECK(hipMemsetAsync(counters, 0, ROUNDS_PER_CHECK * sizeof(unsigned int), s));
+    for (int k = 0; k < ROUNDS_PER_CHECK; ++k) {
+      unsigned char* in = act + (size_t)cur * nt;
+      unsigned char* out = act + (size_t)(cur ^ 1) * nt;
+      PEANUT_HIP_CHECK(hipMemsetAsync(out, 0, nt, s));
+      hipLaunchKernelGGL(fmm_round_kernel, dim3(nt), dim3(256), 0, s, (double*)g->dist.p, (const unsigned char*)g->state.p, H, W,
+                         g->tiles_x, g->tiles_y, in, out, counters + k);
+      cur ^= 1;
+    }
+    PEANUT_HIP_CHECK(hipMemcpyAsync(host.data(), counters, ROUNDS_PER_CHECK * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+    if (host[ROUNDS_PER_CHECK - 1] == 0) { round += ROUNDS_PER_CHECK; break; }
+  }
+  g->last_rounds = round;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("fmm: ") + hipGetErrorString(e));
+  if (round >= max_rounds) return fail(PEANUT_EHIP, "fmm: the field did not settle within the round budget");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int peanut_goal_create(peanut_goal_t** out, int full_h, int full_w, int col_rad) {
+  if (!out || full_h < 1 || full_w < 1 || col_rad < 0) return fail(PEANUT_EINVAL, "peanut_goal_create: bad arguments");
+  auto g = std::make_unique<peanut_goal>();
+  g->H = full_h; g->W = full_w; g->rad = col_rad;
+  g->tiles_x = (full_w + TILE - 1) / TILE;
+  g->tiles_y = (full_h + TILE - 1) / TILE;
+  const size_t n = (size_t)full_h * full_w;
+  int rc;
+  if ((rc = g->trav.ensure(n)) || (rc = g->state.ensure(n)) || (rc = g->dist.ensure(n * sizeof(double))) ||
+      (rc = g->active.ensure(2 * (size_t)g->tiles_x * g->tiles_y)) || (rc = g->counters.ensure(ROUNDS_PER_CHECK * sizeof(unsigned int))) ||
+      (rc = g->maxbits.ensure(sizeof(unsigned long long))) || (rc = g->wt_new.ensure(n * sizeof(double))) ||
+      (rc = g->wt_last.ensure(n * sizeof(double))) || (rc = g->value.ensure(n * sizeof(double))) || (rc = g->sum.ensure(sizeof(double))) ||
+      (rc = g->partial.ensure(1024 * sizeof(ArgMax))) || (rc = g->out_idx.ensure(2 * sizeof(int))) || (rc = g->out_val.ensure(2 * sizeof(double))))
+    return rc;
+  *out = g.release();
+  return 0;
+}
+
+void peanut_goal_destroy(peanut_goal_t* g) { delete g; }
+
+int peanut_goal_reset(peanut_goal_t* g) {
+  if (!g) return fail(PEANUT_EINVAL, "peanut_goal_reset: null handle");
+  g->have_last = false;
+  return 0;
+}
+
+int peanut_goal_rounds(peanut_goal_t* g) { return g ? g->last_rounds : PEANUT_EINVAL; }
+
+int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint8_t* goal_mask, int goal_r, int goal_c, int fill_mode,
+                        double* dist_out, void* stream) {
+  if (!g || !traversible || !dist_out) return fail(PEANUT_EINVAL, "peanut_fmm_distance: null argument");
+  if (!goal_mask && (goal_r < 0 || goal_r >= g->H || goal_c < 0 || goal_c >= g->W))
+    return fail(PEANUT_EINVAL, "peanut_fmm_distance: goal cell outside the map");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = solve_field(g, traversible, goal_mask, goal_mask && goal_r < 0 ? -1 : goal_r, goal_c, s)) return rc;
+  const int n = g->H * g->W;
+  if (fill_mode == 0) {
+    PEANUT_HIP_CHECK(hipMemcpyAsync(dist_out, g->dist.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  } else {
+    PEANUT_HIP_CHECK(hipMemsetAsync(g->maxbits.p, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(fmm_max_kernel, dim3(256), dim3(256), 0, s, (const double*)g->dist.p, n, (unsigned long long*)g->maxbits.p);
+    hipLaunchKernelGGL(fmm_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double*)g->dist.p, n,
+                       (const unsigned long long*)g->maxbits.p, dist_out);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_fmm_distance: ") + hipGetErrorString(e));
+}
+
+int peanut_goal_traversible(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map, const uint8_t* visited_vis,
+                            uint8_t* trav_out, void* stream) {
+  if (!g || !full_obstacle) return fail(PEANUT_EINVAL, "peanut_goal_traversible: null argument");
+  hipLaunchKernelGGL(goal_trav_kernel, dim3((g->W + 31) / 32, (g->H + 7) / 8), dim3(256), 0, (hipStream_t)stream, full_obstacle,
+                     collision_map, visited_vis, g->H, g->W, g->rad, trav_out ? trav_out : (unsigned char*)g->trav.p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_goal_traversible: ") + hipGetErrorString(e));
+}
+
+int peanut_goal_select(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map, const uint8_t* visited_vis,
+                       const int lmb[4], int loc_r, int loc_c, const float* target_pred, double dist_weight_temperature,
+                       int map_resolution, int goal_rc_out[2], double stats_out[4], double* dist_out, double* value_out, void* stream) {
+  if (!g || !full_obstacle || !lmb || !goal_rc_out) return fail(PEANUT_EINVAL, "peanut_goal_select: null argument");
+  const int gx1 = lmb[0], gx2 = lmb[1], gy1 = lmb[2], gy2 = lmb[3];
+  const int lw = gx2 - gx1, lh = gy2 - gy1;
+  if (gx1 < 0 || gy1 < 0 || gx2 > g->H || gy2 > g->W || lw < 1 || lh < 1) return fail(PEANUT_EINVAL, "peanut_goal_select: bad local map boundaries");
+  const int mode = dist_weight_temperature == -1 ? 1 : (dist_weight_temperature == 0 ? 2 : 0);
+  if (mode != 2 && !target_pred) return fail(PEANUT_EINVAL, "peanut_goal_select: target_pred is needed unless dist_weight_temperature == 0");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, stream)) return rc;
+  // np.clip(loc + lmb, 0, full - 1)  (:389-390)
+  int sr = loc_r + gx1, sc = loc_c + gy1;
+  sr = sr < 0 ? 0 : (sr > g->H - 1 ? g->H - 1 : sr);
+  sc = sc < 0 ? 0 : (sc > g->W - 1 ? g->W - 1 : sc);
+  if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, s)) return rc;
+  if (g->have_last && (g->last_lw != lw || g->last_lh != lh)) g->have_last = false;
+  const int n = lw * lh;
+  const double temperature = dist_weight_temperature / (double)map_resolution;      // (:395)
+  PEANUT_HIP_CHECK(hipMemsetAsync(g->sum.p, 0, sizeof(double), s));
+  hipLaunchKernelGGL(goal_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double*)g->dist.p, g->W, gx1, gy1, lw, lh,
+                     temperature, mode == 2 ? 1 : 0, (double*)g->wt_new.p, (double*)g->sum.p);
+  const int nparts = std::min(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(goal_argmax_kernel, dim3(nparts), dim3(256), 0, s, target_pred, (const double*)g->wt_new.p, (const double*)g->wt_last.p,
+                     (const double*)g->sum.p, g->have_last ? 1 : 0, mode, n, value_out ? value_out : (double*)g->value.p, (ArgMax*)g->partial.p);
+  hipLaunchKernelGGL(goal_argmax_final_kernel, dim3(1), dim3(64), 0, s, (const ArgMax*)g->partial.p, nparts, (const double*)g->sum.p,
+                     g->have_last ? 1 : 0, mode, (const double*)g->wt_new.p, (double*)g->wt_last.p, n, (int*)g->out_idx.p, (double*)g->out_val.p);
+  int idx[2];
+  double val[2];
+  PEANUT_HIP_CHECK(hipMemcpyAsync(idx, g->out_idx.p, sizeof(idx), hipMemcpyDeviceToHost, s));
+  PEANUT_HIP_CHECK(hipMemcpyAsync(val, g->out_val.p, sizeof(val), hipMemcpyDeviceToHost, s));
+  if (dist_out) PEANUT_HIP_CHECK(hipMemcpyAsync(dist_out, g->dist.p, (size_t)g->H * g->W * sizeof(double), hipMemcpyDeviceToDevice, s));
+  PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+  if (!idx[1] && mode != 2) {    // self.dd_wt = dd_wt (:410): the fresh weights become the last ones unless the old ones were kept
+    PEANUT_HIP_CHECK(hipMemcpyAsync(g->wt_last.p, g->wt_new.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    g->last_lw = lw; g->last_lh = lh;
+  }
+  g->have_last = true;
+  goal_rc_out[0] = idx[0] / lh;
+  goal_rc_out[1] = idx[0] - goal_rc_out[0] * lh;
+  if (stats_out) { stats_out[0] = val[0]; stats_out[1] = val[1]; stats_out[2] = idx[1]; stats_out[3] = g->last_rounds; }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_goal_select: ") + hipGetErrorString(e));
+}
+
+}  // extern "C"

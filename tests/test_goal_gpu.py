@@ -1,0 +1,213 @@
+"""Long-term goal selection on the device (csrc/goal.hip, peanut_amd/goal.py) against
+oracle/fmm_ref.c (restated scikit-fmm, PARITY UNPINNED), oracle/goal_ref.py and the golden episode produced by the
+reference's own Agent_State.update_global_goal (tests/golden/goal_golden.npz).
+
+Gates: distance field <= 0.5 cell max-abs vs the heap-ordered oracle (measured: ~1e-12 on these maps), identical
+masked / unreachable pattern, chosen goal cell identical."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from numpy import ma
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = 0.5      # cells (the gate); printed maxima show how far below it the solver sits
+
+
+class FakePredictionGPU:
+    """Device twin of oracle.agent_ref.FakePrediction (same formula on HIP tensors)."""
+
+    def __init__(self, pattern):
+        self.pattern = torch.from_numpy(pattern).cuda()
+
+    def get_prediction_batch(self, maps, apply_sigmoid=True, out=None):
+        sel = maps[:, [0, 1, 4, 5, 6, 7]]
+        return torch.tanh(sel + self.pattern[None]) * 0.5 + 0.5
+
+
+def _maze(h, w, seed, density=0.012, wall_len=(10, 60)):
+    rng = np.random.RandomState(seed)
+    trav = np.ones((h, w), np.uint8)
+    for _ in range(int(density * h * w / 20)):
+        r, c = rng.randint(0, h), rng.randint(0, w)
+        n = rng.randint(*wall_len)
+        if rng.rand() < 0.5:
+            trav[r:r + 2, c:c + n] = 0
+        else:
+            trav[r:r + n, c:c + 2] = 0
+    trav[rng.randint(0, h, 40), rng.randint(0, w, 40)] = 0
+    # a closed box: its inside is unreachable
+    trav[h // 4:h // 4 + 30, w // 4] = 0
+    trav[h // 4:h // 4 + 30, w // 4 + 29] = 0
+    trav[h // 4, w // 4:w // 4 + 30] = 0
+    trav[h // 4 + 29, w // 4:w // 4 + 30] = 0
+    return trav
+
+
+def _oracle_field(trav, seeds):
+    from oracle import fmm_ref
+    t = ma.masked_values(trav.astype(np.float64), 0)
+    for r, c in seeds:
+        t[r, c] = 0
+    d = fmm_ref.distance(t, dx=1)
+    return np.where(ma.getmaskarray(d), np.inf, ma.getdata(d))
+
+
+@pytest.mark.parametrize("shape,seed", [((960, 960), 1), ((480, 480), 2), ((250, 333), 3), ((64, 40), 4)],
+                         ids=lambda v: str(v))
+def test_fmm_field_matches_oracle(shape, seed):
+    from peanut_amd.goal import GeodesicSolver
+    h, w = shape
+    trav = _maze(h, w, seed)
+    src = (h // 2 + 3, w // 2 - 5)
+    trav[src[0] - 2:src[0] + 3, src[1] - 2:src[1] + 3] = 1
+    ref = _oracle_field(trav, [src])
+    sol = GeodesicSolver(h, w, 0)
+    got = sol.distance(torch.from_numpy(trav), goal=src).cpu().numpy()
+    assert np.array_equal(np.isinf(got), np.isinf(ref)), "masked / unreachable pattern"
+    fin = np.isfinite(ref)
+    assert fin.sum() > 0.5 * h * w and np.isinf(ref[h // 4 + 10, w // 4 + 10])
+    err = np.abs(got[fin] - ref[fin]).max()
+    print(f"{h}x{w}: max |GPU - oracle| = {err:.3e} cells over {fin.sum()} reached cells, max distance {ref[fin].max():.1f}, "
+          f"{sol.rounds} relaxation rounds")
+    assert err <= FIELD_TOL
+    # fill_max_plus_one = ma.filled(dd, np.max(dd) + 1) (fmm_planner.py:66)
+    filled = sol.distance(torch.from_numpy(trav), goal=src, fill_max_plus_one=True).cpu().numpy()
+    assert np.isfinite(filled).all() and abs(filled[~fin].min() - (ref[fin].max() + 1)) <= FIELD_TOL
+    assert np.unique(filled[~fin]).size == 1
+
+
+def test_fmm_multi_goal_and_seed_inside_obstacle():
+    from oracle import goal_ref
+    from peanut_amd.goal import FMMPlanner, GeodesicSolver
+    trav = _maze(300, 300, 9)
+    gm = np.zeros((300, 300), np.uint8)
+    gm[40:43, 200:203] = 1
+    gm[250, 30] = 1
+    gm[80, 80] = 1
+    trav[80, 80] = 0                                    # a goal on a masked cell gets unmasked (traversible_ma[goal] = 0)
+    ref = goal_ref.fmm_set_multi_goal(trav.astype(np.float64), gm)
+    pl = FMMPlanner(trav.astype(np.float64))
+    pl.set_multi_goal(gm)
+    assert np.abs(pl.fmm_dist - ref).max() <= FIELD_TOL
+    pl.set_goal((150.7, 149.2))
+    ref1 = goal_ref.fmm_set_goal(trav.astype(np.float64), (150, 149))
+    assert np.abs(pl.fmm_dist - ref1).max() <= FIELD_TOL
+    # short-term goal: one step of descent on the field from a cell 30 cells away
+    start = [150.4, 119.6]
+    if trav[150, 119]:
+        sx, sy, dist, stop, replan = pl.get_short_term_goal(start)
+        assert not stop and pl.fmm_dist[int(sx), int(sy)] <= pl.fmm_dist[150, 119]
+    # agent walled in: only the seed is reached
+    box = np.zeros((64, 64), np.uint8)
+    sol = GeodesicSolver(64, 64, 0)
+    got = sol.distance(torch.from_numpy(box), goal=(10, 12)).cpu().numpy()
+    assert got[10, 12] == 0 and np.isinf(got).sum() == 64 * 64 - 1
+
+
+def test_traversible_map_is_bit_exact():
+    from oracle import goal_ref
+    from oracle.agent_ref import disk
+    from peanut_amd.goal import GeodesicSolver
+    rng = np.random.RandomState(0)
+    obst = (rng.rand(200, 260) > 0.97).astype(np.float32) * rng.choice([0.3, 0.5, 0.51, 1.0, 1.5], size=(200, 260)).astype(np.float32)
+    obst[0, 0] = obst[199, 259] = 1.0                    # borders: the footprint is cut off, zero outside
+    col = (rng.rand(200, 260) > 0.995).astype(np.float64)
+    vis = (rng.rand(200, 260) > 0.99).astype(np.float64)
+    for rad in (4, 1, 0):
+        sol = GeodesicSolver(200, 260, rad)
+        got = sol.traversible(torch.from_numpy(obst), col, vis).cpu().numpy()
+        ref = goal_ref.traversible_map(obst, disk(rad), col, vis)
+        assert np.array_equal(got.astype(bool), ref), rad
+
+
+def test_goal_selection_episode_matches_reference(golden_dir):
+    """The golden episode (reference Agent_State.update_global_goal under the restated skfmm): identical goal cell
+    at every prediction step, incl. the 'avoid repeating the last goal' bookkeeping; distance probes and the
+    last field within the gate."""
+    from oracle import goal_ref, mapping_scenes
+    from oracle.agent_ref import agent_args, fake_pattern
+    from oracle.gen_golden_goal import helper_maps
+    from peanut_amd.agent_state import Agent_State
+    z = np.load(os.path.join(golden_dir, "goal_golden.npz"))
+    args = agent_args(dist_weight_temperature=500, select_goal=False)
+    st = Agent_State(args, prediction_model=FakePredictionGPU(fake_pattern(size=args.prediction_window)))
+    frames = mapping_scenes.make_sequence(seed=int(z["seed"]), n_frames=int(z["n_frames"]))
+    for f in frames:
+        f["pose"][0] = np.float32(f["pose"][0] * 3.0)
+    st.reset()
+    col, vis = helper_maps((st.full_w, st.full_h), seed=int(z["helper_seed"]))
+    st.collision_map.copy_(torch.from_numpy(col.astype(np.uint8)))
+    probes = [tuple(p) for p in z["probes"]]
+    pred_steps, goals, prev = [], [], None
+    from peanut_amd.goal import GeodesicSolver
+    st._goal = GeodesicSolver(st.full_w, st.full_h, int(args.col_rad), device=st.device)
+    worst_probe = 0.0
+    for i, fr in enumerate(frames):
+        obs = torch.from_numpy(mapping_scenes.frame_to_obs(fr))[None].cuda()
+        infos = {"sensor_pose": [float(v) for v in fr["pose"]], "goal_cat_id": int(z["goal_cat"])}
+        if i == 0:
+            st.init_with_obs(obs, infos)
+        predicted = st.update_state(obs, infos)          # select_goal=False: goal selection is driven below, after the trail update
+        cur = (int(st.loc_r + st.lmb[0]), int(st.loc_c + st.lmb[2]))
+        goal_ref.mark_visited(vis, prev if prev is not None else cur, cur)
+        prev = cur
+        if predicted:
+            st.visited_vis.copy_(torch.from_numpy(vis.astype(np.uint8)))
+            k = len(pred_steps)
+            res = st._goal.select(st.full_map[0], st.collision_map, st.visited_vis, st.lmb, (st.loc_r, st.loc_c), st.target_pred,
+                                  500.0, int(args.map_resolution), want_dist=True)
+            new = [res["goal"]]
+            if new != st.last_global_goal:
+                st.last_global_goal = st.global_goals
+                st.global_goals = new
+            pred_steps.append(i)
+            goals.append([int(st.global_goals[0][0]), int(st.global_goals[0][1])])
+            dd = res["dist"].cpu().numpy()
+            ref_probe = z["dd_probe"][k]
+            for p, rv in zip(probes, ref_probe):
+                assert np.isinf(dd[p]) == np.isinf(rv), (i, p)
+                if np.isfinite(rv):
+                    worst_probe = max(worst_probe, abs(dd[p] - rv))
+            assert int(np.isfinite(dd).sum()) == int(z["dd_reach"][k]), f"step {i}: reachable cells"
+            assert abs(res["wt_sum"] - z["wt_sum"][k]) <= 1e-6 * max(1.0, z["wt_sum"][k]) + 0.5 or res["kept_last"]
+            assert [int(v) for v in res["goal"]] == list(z["value_argmax"][k]), f"step {i}: argmax of the value map"
+            last_dd = dd
+    assert pred_steps == list(z["pred_steps"]), "prediction schedule (depends on the selected goals through dist_to_goal)"
+    assert goals == [list(g) for g in z["global_goals"]]
+    ref_last = z["last_dd_f32"].astype(np.float64)
+    fin = ref_last >= 0
+    assert np.array_equal(np.isfinite(last_dd), fin)
+    err = np.abs(last_dd[fin] - ref_last[fin]).max()
+    print(f"golden episode: goals {goals}; probes max |diff| {worst_probe:.2e}; last field max |diff| {err:.2e} (fp32-stored fixture)")
+    assert worst_probe <= FIELD_TOL and err <= FIELD_TOL
+
+
+def test_update_state_selects_goals_and_keeps_last_weights_when_stuck():
+    """Agent_State.update_state with goal selection on (default): update_prediction -> update_global_goal; an agent
+    walled in by obstacles (sum of weights < 10) keeps the previous weights (agent_state.py:398-399)."""
+    from oracle.agent_ref import agent_args
+    from peanut_amd.goal import GeodesicSolver
+    sol = GeodesicSolver(96, 96, 1)
+    obst = torch.zeros((96, 96))
+    tp = torch.zeros((48, 48))
+    tp[40, 40] = 1.0
+    tp[3, 3] = 0.8
+    lmb = (24, 72, 24, 72)
+    r1 = sol.select(obst, None, None, lmb, (10, 10), tp, 500.0, 5, want_value=True)
+    assert not r1["kept_last"] and r1["wt_sum"] > 10 and r1["goal"] in ((40, 40), (3, 3))
+    v1 = r1["value"].cpu()
+    obst2 = obst.clone()
+    obst2[24 + 10 - 3:24 + 10 + 4, 24 + 10 - 3:24 + 10 + 4] = 1.0       # the agent's cell and its surroundings are blocked
+    r2 = sol.select(obst2, None, None, lmb, (10, 10), tp, 500.0, 5, want_value=True)
+    assert r2["kept_last"] and r2["wt_sum"] < 10 and r2["goal"] == r1["goal"] and torch.equal(r2["value"].cpu(), v1)
+    sol.reset()
+    r3 = sol.select(obst2, None, None, lmb, (10, 10), tp, 500.0, 5)
+    assert not r3["kept_last"]                                            # nothing to fall back to after reset
+    r4 = sol.select(obst, None, None, lmb, (10, 10), tp, -1, 5)           # temperature -1: target_pred alone
+    assert r4["goal"] == (40, 40)
+    r5 = sol.select(obst, None, None, lmb, (10, 10), None, 0, 5)          # temperature 0: frontier mode, no target_pred
+    gr, gc = r5["goal"]
+    assert 59.0 <= np.hypot(gr - 10, gc - 10) or r5["value_max"] == 0.0
