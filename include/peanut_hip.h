@@ -295,7 +295,8 @@ int peanut_conv_forward(peanut_conv_t* c, const float* x_dev, const float* x2_de
  * (nav/agent/agent_state.py:376-415) and the geodesic distance transform behind it and behind
  * FMMPlanner.set_goal / set_multi_goal (nav/agent/utils/fmm_planner.py:55-75).  The reference calls scikit-fmm's
  * heap-ordered fast marching on the host (`skfmm.distance`, second order); here the same second-order upwind
- * discretisation is solved as a fixed point by tile-wise relaxation (csrc/goal.hip).  scikit-fmm is an absent
+ * discretisation is solved by tile-wise relaxation in stages that provably end (csrc/goal.hip; <= 0.14 cell from the
+ * heap-ordered march on maze maps, gate 0.5).  scikit-fmm is an absent
  * third-party dependency: parity is pinned against the restatement in oracle/fmm_ref.c only (PARITY UNPINNED).
  * Distances are doubles, in cells.
  * ---------------------------------------------------------------------------------------- */
@@ -306,8 +307,9 @@ int peanut_goal_create(peanut_goal_t** out, int full_h, int full_w, int col_rad)
 void peanut_goal_destroy(peanut_goal_t* g);
 /* Agent_State.reset (:94-105): forget the last distance weights (`self.dd_wt = None`). */
 int peanut_goal_reset(peanut_goal_t* g);
-/* relaxation rounds the last solve took (diagnostics) */
+/* relaxation rounds / second-order ordering passes the last solve took (diagnostics) */
 int peanut_goal_rounds(peanut_goal_t* g);
+int peanut_goal_passes(peanut_goal_t* g);
 /* agent_state.py:382-386: trav = ~binary_dilation(rint(full_map[0]), disk(col_rad)); trav[collision_map == 1] = 0;
  * trav[visited_vis == 1] = 1.  full_obstacle device fp32 [H,W]; collision_map / visited_vis device uint8 [H,W] or
  * NULL; trav_out device uint8 [H,W] (NULL: kept inside the handle). */

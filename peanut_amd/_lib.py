@@ -100,6 +100,7 @@ SIGNATURES = {
     "peanut_goal_destroy": (None, [_P]),
     "peanut_goal_reset": (C.c_int, [_P]),
     "peanut_goal_rounds": (C.c_int, [_P]),
+    "peanut_goal_passes": (C.c_int, [_P]),
     "peanut_goal_traversible": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "peanut_fmm_distance": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_goal_select": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int * 4), C.c_int, C.c_int, _P, C.c_double, C.c_int,

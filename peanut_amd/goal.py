@@ -50,6 +50,10 @@ class GeodesicSolver:
     def rounds(self) -> int:
         return int(self._lib.peanut_goal_rounds(self._h))
 
+    @property
+    def passes(self) -> int:
+        return int(self._lib.peanut_goal_passes(self._h))
+
     def reset(self):
         _lib.check(self._lib.peanut_goal_reset(self._h), "peanut_goal_reset")
 

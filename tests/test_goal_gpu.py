@@ -68,10 +68,12 @@ def test_fmm_field_matches_oracle(shape, seed):
     got = sol.distance(torch.from_numpy(trav), goal=src).cpu().numpy()
     assert np.array_equal(np.isinf(got), np.isinf(ref)), "masked / unreachable pattern"
     fin = np.isfinite(ref)
-    assert fin.sum() > 0.5 * h * w and np.isinf(ref[h // 4 + 10, w // 4 + 10])
+    assert fin.sum() > (0.5 if h > 100 else 0.2) * h * w
+    if h > 100:
+        assert np.isinf(ref[h // 4 + 10, w // 4 + 10]), "the closed box must stay unreached"
     err = np.abs(got[fin] - ref[fin]).max()
     print(f"{h}x{w}: max |GPU - oracle| = {err:.3e} cells over {fin.sum()} reached cells, max distance {ref[fin].max():.1f}, "
-          f"{sol.rounds} relaxation rounds")
+          f"{sol.rounds} relaxation rounds in {sol.passes} ordering passes")
     assert err <= FIELD_TOL
     # fill_max_plus_one = ma.filled(dd, np.max(dd) + 1) (fmm_planner.py:66)
     filled = sol.distance(torch.from_numpy(trav), goal=src, fill_max_plus_one=True).cpu().numpy()
