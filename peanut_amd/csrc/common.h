@@ -74,20 +74,23 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
 bool conv_pw_enabled();
 
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
-// tiles per sub-grid (th x tw), tile count and its padding to whole 128-row GEMM tiles
-void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad);
+// tiles per sub-grid (th x tw), tile count and its padding to whole `gran`-row GEMM tiles (128; 256 when the position
+// GEMMs run on the 256 x 256 S-format kernel)
+void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad, int gran = 128);
 // host: OIHW 3x3 weights -> U [36][cout][cin]
 void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out);
 // x [B,H,W,C] -> V [36][m_pad][C] fp32, or (Vs != null) the same tensor as `planes` bf16 pieces in the S layout
 int launch_wino_input(const float* x, float* V, unsigned short* Vs, int planes, int B, int H, int W, int C, int dil,
-                      hipStream_t s);
+                      hipStream_t s, int gran = 128);
 // Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res); optional S copy ys (rows padded to
 // ys_rows); skip_f32 = 1 leaves y untouched
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
                        unsigned short* ys, int ys_rows, int planes, int skip_f32, int B, int H, int W, int C, int dil, int relu,
-                       hipStream_t s);
+                       hipStream_t s, int gran = 128);
 
 // ---- emulated-fp32 GEMM on pre-split bf16 operands (gemm_sx.hip) ----
+// whether the 256 x 256 kernel runs a [M x cout] output (mt_per_group: 128-row tiles per Winograd position, 0 = plain)
+bool gemm_sx_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
 size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
 void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
 // bytes of an S tensor of `rows` x `channels`

@@ -84,6 +84,7 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
 // gemm_sx.hip: pointwise layer / grouped GEMM on S-format operands (p.xs, p.w = S-packed weights, nkt = cin / 16)
 int launch_gemm_sx(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
 
+
 // Work decomposition of one launch.
 //  * XCD-aware (guide T1): workgroup b runs on XCD b % 8 (observed, used for speed only); every XCD gets
 //    a contiguous run of logical work items so that its private L2 sees neighbouring tiles (n-tile
@@ -125,7 +126,7 @@ __device__ __forceinline__ Work decode_work(const ConvKParams& p) {
 // The accumulators go through LDS (EP row slabs) so that global traffic is whole rows: each thread then handles
 // 16-byte pieces (4 consecutive channels) -- a wave reads the residual and writes the output as contiguous row
 // segments instead of 64 scalar accesses per lane.  The caller's k-loop must have retired every LDS read (barrier).
-template <int BM, int BN, int WM, int WN, int EP, int MI, int NI>
+template <int BM, int BN, int WM, int WN, int EP, int NT = 256, int MI = 0, int NI = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& wk, f32x16 (&acc)[MI][NI], float* smem,
                                               int m0, int n0) {
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, hi = lane >> 5;
   constexpr int NV = BN / 4;               // float4 per output row of the tile
-  constexpr int ROWS_PER_PASS = 256 / NV;  // rows covered by the 256 threads per pass
+  constexpr int ROWS_PER_PASS = NT / NV;   // rows covered by the NT threads per pass
   const int c4 = (tid % NV) * 4, r0 = tid / NV;
   const int n = n0 + c4;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);   // scale/shift are padded to cout_pad
@@ -192,7 +193,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
         // 16-byte piece stores cover 32 consecutive rows of one (chunk, plane): 1 KiB runs of the S layout
         __syncthreads();
         constexpr int HALVES = BN / 8;
-        for (int it = tid; it < ER * HALVES; it += 256) {
+        for (int it = tid; it < ER * HALVES; it += NT) {
           const int half = it & 1, row = (it >> 1) % ER, hc = (it >> 1) / ER;
           const int col = hc * 16 + half * 8;
           const int m = m0 + ep * ER + row, nn = n0 + col;
@@ -282,13 +283,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
 }
 
 // shared host launcher: occupancy query (once per instantiation), tail-split plan, launch, reduce
-template <typename KernelT, int BM, int BN>
+template <typename KernelT, int BM, int BN, int NT = 256>
 int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream,
                            int* cached_slots) {
   if (*cached_slots == 0) {
     int dev = 0, cus = 0, occ = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, NT, 0) != hipSuccess || occ < 1)
       *cached_slots = -1;   // unknown -> never split
     else
       *cached_slots = cus * occ;
@@ -301,7 +302,7 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   p.n_sp = t * sp;
   p.n_full = T - t;
   p.partial = ws;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(NT), 0, stream, p);
   if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));

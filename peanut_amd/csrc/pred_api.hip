@@ -47,6 +47,7 @@ struct Op {
   double flops = 0;
   double bytes = 0;            // algorithmic HBM bytes: every operand read once, the result written once
   int wino_mt_per_group = 0;   // OP_WINO_GEMM: 128-row tiles per Winograd position
+  int wino_gran = 128;         // row padding of the Winograd position GEMMs
   SAct in_s, out_s;            // S-format (pre-split bf16 pieces, gemm_sx.hip) copies of the input / output, if any
   bool skip_f32 = false;       // the fp32 output is not written (only out_s is consumed)
 };
@@ -140,8 +141,11 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
 }
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
-std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_input = false) {
-  if (s_input) return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
+std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_input = false, long long M = 0, int mt_per_group = 0) {
+  if (s_input) {
+    if (gemm_sx_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return d.s_planes == 3 ? "gemm_sx6_256x256" : "gemm_sx3_256x256";
+    return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
+  }
   if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && !two_source && d.cin % 32 == 0 && conv_pw_enabled())
     return "conv_pw_glds_128x" + std::to_string(d.bn_tile);
   return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
@@ -168,19 +172,20 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
     int th, tw;
     long long n_tiles, m_pad;
-    wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad);
     const bool s_gemm = L->wino.w_s != nullptr;
+    const int gran = s_gemm ? 256 : 128;   // the S-format position GEMMs run on 256 x 256 tiles (gemm_sx.hip)
+    wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran);
     Act v;   // fp32 V (unused in the S form)
     SAct vs;
     if (s_gemm) vs = make_sact(*ar, (size_t)(36 * m_pad), in.C, L->wino.s_planes);
     else v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
     Act m = make_act(*ar, 1, 1, (int)(36 * m_pad), L->d.cout);
     Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
-    a.out_s = vs;
+    a.out_s = vs; a.wino_gran = gran;
     a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0);
     pl.ops.push_back(a);
-    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, s_gemm); g.conv = L;
-    g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.in_s = vs; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128);
+    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, s_gemm, 36 * m_pad, (int)(m_pad / 128)); g.conv = L;
+    g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.in_s = vs; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
     g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
     g.bytes = 36.0 * (double)m_pad * (in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0) + L->d.cout * 4.0) +
               36.0 * (s_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
@@ -188,7 +193,7 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
     if (out_s) o.out_s = *out_s;
-    o.skip_f32 = skip_f32;
+    o.skip_f32 = skip_f32; o.wino_gran = gran;
     o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (skip_f32 ? 0.0 : (double)out.bytes) + (res ? (double)out.bytes : 0.0) +
               (out_s ? (double)out_s->bytes : 0.0);
     pl.ops.push_back(o);
@@ -199,7 +204,7 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
   const bool s_in = in_s && in_s->valid && L->d.w_s && !in2;
-  op.kernel = conv_kernel_name(L->d, in2 != nullptr, s_in);
+  op.kernel = conv_kernel_name(L->d, in2 != nullptr, s_in, (long long)out.B * out.H * out.W, 0);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
   if (s_in) op.in_s = *in_s;
@@ -419,7 +424,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
     case OP_WINO_IN:
       return launch_wino_input(P(op.in), op.out_s.valid ? nullptr : P(op.out),
                                op.out_s.valid ? (unsigned short*)(base + op.out_s.off) : nullptr, op.conv->wino.s_planes, op.in.B,
-                               op.in.H, op.in.W, op.in.C, op.conv->d.dil, s);
+                               op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran);
     case OP_WINO_GEMM: {
       ConvArgs a{};
       a.x = P(op.in); a.y = P(op.out);
@@ -438,7 +443,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       return launch_wino_output(P(op.in), op.conv->d.scale, op.conv->d.shift, op.has_res ? P(op.res) : nullptr, P(op.out),
                                 op.out_s.valid ? (unsigned short*)(base + op.out_s.off) : nullptr, op.out_s.rows_pad,
                                 op.conv->d.s_planes, op.skip_f32 ? 1 : 0, op.out.B, op.out.H, op.out.W, op.out.C,
-                                op.conv->d.dil, op.conv->d.relu, s);
+                                op.conv->d.dil, op.conv->d.relu, s, op.wino_gran);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:

@@ -209,12 +209,12 @@ int grid_for(long long total) {
 
 }  // namespace
 
-void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad) {
+void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad, int gran) {
   const int hs = (H + dil - 1) / dil, wsub = (W + dil - 1) / dil;   // largest sub-grid
   *th = (hs + 3) / 4;
   *tw = (wsub + 3) / 4;
   *n_tiles = (long long)B * dil * dil * *th * *tw;
-  *m_pad = (*n_tiles + 127) / 128 * 128;                             // whole 128-row GEMM tiles per position
+  *m_pad = (*n_tiles + gran - 1) / gran * gran;                      // whole GEMM tiles per position
 }
 
 // U[(i*6+l)][n][c] = (G g G^T)[i][l], accumulated in double and rounded once
@@ -240,10 +240,10 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out) 
 }
 
 int launch_wino_input(const float* x, float* V, unsigned short* Vs, int planes, int B, int H, int W, int C, int dil,
-                      hipStream_t s) {
+                      hipStream_t s, int gran) {
   if (C % 4 || (Vs && C % 16)) return fail(-2, "wino_input: channels must be a multiple of 4 (16 for the S layout)");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
-  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad);
+  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran);
   const long long total = (Vs ? (g.n_tiles + 15) / 16 * 16 : g.n_tiles) * (C / 4);
   hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, Vs, planes, g);
   hipError_t e = hipGetLastError();
@@ -253,10 +253,10 @@ int launch_wino_input(const float* x, float* V, unsigned short* Vs, int planes, 
 
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
                        unsigned short* ys, int ys_rows, int planes, int skip_f32, int B, int H, int W, int C, int dil, int relu,
-                       hipStream_t s) {
+                       hipStream_t s, int gran) {
   if (C % 4 || (ys && C % 16)) return fail(-2, "wino_output: channels must be a multiple of 4 (16 for the S layout)");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
-  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad);
+  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran);
   const long long total = (ys ? (g.n_tiles + 15) / 16 * 16 : g.n_tiles) * (C / 4);
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, ys, ys_rows, planes,
                      skip_f32, g, relu);
