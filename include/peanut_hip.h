@@ -201,6 +201,22 @@ typedef struct peanut_rcnn_cfg {
   float bn_eps;            /* FrozenBatchNorm2d eps 1e-5 */
   int precision;           /* PEANUT_PREC_* */
   int conv_algo;           /* PEANUT_ALGO_* (Winograd for the stride-1 3x3 convs with >= 256 input channels) */
+  /* proposal generator and ROI heads (yaml :41-57, :163-253, :312); read by peanut_rcnn_inference only */
+  float anchor_sizes[5];   /* ANCHOR_GENERATOR.SIZES, one per level p2..p6 (32, 64, 128, 256, 512) */
+  float aspect_ratios[8];  /* ANCHOR_GENERATOR.ASPECT_RATIOS (0.5, 1, 2): num_anchors entries */
+  int rpn_pre_nms_topk;    /* RPN.PRE_NMS_TOPK_TEST (1000; <= 1024) */
+  int rpn_post_nms_topk;   /* RPN.POST_NMS_TOPK_TEST (1000) */
+  float rpn_nms_thresh;    /* RPN.NMS_THRESH (0.7) */
+  float rpn_bbox_weights[4];   /* RPN.BBOX_REG_WEIGHTS (1, 1, 1, 1) */
+  int num_classes;         /* ROI_HEADS.NUM_CLASSES (9) */
+  int box_pooler_resolution, mask_pooler_resolution;   /* 7, 14 */
+  int fc_dim;              /* ROI_BOX_HEAD.FC_DIM (1024), NUM_FC 2 */
+  int mask_conv_dim, num_mask_convs;                   /* ROI_MASK_HEAD.CONV_DIM (256), NUM_CONV (4) */
+  float roi_bbox_weights[4];   /* ROI_BOX_HEAD.BBOX_REG_WEIGHTS (10, 10, 5, 5) */
+  float score_thresh_test; /* ROI_HEADS.SCORE_THRESH_TEST (segmentation.py:33 sets it to sem_pred_prob_thr) */
+  float nms_thresh_test;   /* ROI_HEADS.NMS_THRESH_TEST (0.5) */
+  int detections_per_image;    /* TEST.DETECTIONS_PER_IMAGE (100) */
+  float mask_threshold;    /* detector_postprocess (0.5) */
 } peanut_rcnn_cfg;
 
 typedef struct peanut_rcnn peanut_rcnn_t;
@@ -218,6 +234,22 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], i
  * pyramid[l] [B,h_l,w_l,fpn_out], objectness[l] [B,h_l,w_l,A], deltas[l] [B,h_l,w_l,4A]. */
 int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
                               float* const* objectness, float* const* deltas, void* stream);
+
+/* The whole detector: what `DefaultPredictor(img)["instances"]` yields (nav/agent/utils/segmentation.py:45) --
+ * GeneralizedRCNN.inference + detector_postprocess as configured by mask_rcnn_R_101_cat9.yaml -- for a batch of frames.
+ * Needs a handle created with the roi_heads.* tensors in the state dict (box_head.fc1/fc2, box_predictor.cls_score /
+ * bbox_pred, mask_head.mask_fcn1..N / deconv / predictor).  img_bgr: device uint8 [B,H,W,3].  Outputs: n_det_host
+ * [B] (HOST ints: detections per image, at most detections_per_image each); the detections of all images back to
+ * back, image-major, in decreasing score order inside an image: boxes device [sum n, 4] (x0, y0, x1, y1 in pixels of
+ * the ORIGINAL frame), scores device [sum n], classes device int32 [sum n], masks device uint8 [sum n, H, W] (1 where
+ * the pasted mask >= mask_threshold; pass NULL to skip the mask head).  The caller sizes the buffers for
+ * B * detections_per_image instances.  Synchronises the stream once (to read the detection counts). */
+int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
+                          float* scores, int32_t* classes, uint8_t* masks, void* stream);
+/* Test / bisect hook: device pointer (and byte capacity) of a stage buffer of the last peanut_rcnn_inference call:
+ * "rois" [B*cap,5], "roi_level", "roi_logit", "prop_count" [B], "cls" [B*cap,K+1], "bbox" [B*cap,4K], "det_in" /
+ * "det_out" [B,D,4], "det_score", "det_cls", "det_count" [B], "mprobs" [sum n, 2P, 2P], "sel_idx", "sel_score", "nvalid". */
+int peanut_rcnn_debug_stage(peanut_rcnn_t* h, const char* name, const void** dev, size_t* bytes);
 
 /* The non-convolution operators of Mask R-CNN inference (detectron2 implements them natively in
  * `detectron2._C` / torchvision: ROIAlign, nms; paste_masks_in_image is a fused resample+threshold).

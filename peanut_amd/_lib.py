@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 4     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 5     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -50,6 +50,12 @@ class RcnnCfgC(C.Structure):
         ("fpn_out", C.c_int), ("num_anchors", C.c_int), ("min_size", C.c_int), ("max_size", C.c_int),
         ("size_divisibility", C.c_int), ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3),
         ("bn_eps", C.c_float), ("precision", C.c_int), ("conv_algo", C.c_int),
+        ("anchor_sizes", C.c_float * 5), ("aspect_ratios", C.c_float * 8),
+        ("rpn_pre_nms_topk", C.c_int), ("rpn_post_nms_topk", C.c_int), ("rpn_nms_thresh", C.c_float),
+        ("rpn_bbox_weights", C.c_float * 4), ("num_classes", C.c_int), ("box_pooler_resolution", C.c_int),
+        ("mask_pooler_resolution", C.c_int), ("fc_dim", C.c_int), ("mask_conv_dim", C.c_int), ("num_mask_convs", C.c_int),
+        ("roi_bbox_weights", C.c_float * 4), ("score_thresh_test", C.c_float), ("nms_thresh_test", C.c_float),
+        ("detections_per_image", C.c_int), ("mask_threshold", C.c_float),
     ]
 
 
@@ -87,6 +93,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_int * 10), C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "peanut_rcnn_forward_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P),
                                             C.POINTER(_P), _P]),
+    "peanut_rcnn_inference": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
+    "peanut_rcnn_debug_stage": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "peanut_roi_align": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, _P, _P,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_nms_workspace_bytes": (C.c_size_t, [C.c_int]),

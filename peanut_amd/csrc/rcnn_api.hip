@@ -7,12 +7,12 @@
 // nav/agent/utils/COCO-InstSeg/mask_rcnn_R_101_cat9.yaml.  detectron2 itself is not in the reference
 // checkout, so the module graph below follows detectron2 v0.6's published definitions under that yaml
 // (BasicStem, BottleneckBlock with STRIDE_IN_1X1, FrozenBatchNorm2d folded to scale/shift, FPN with sum
-// fusion and LastLevelMaxPool, StandardRPNHead).  Proposal selection / NMS / ROIAlign / box + mask heads
-// are the next rows and are NOT here.  Parity is pinned only against the torch
+// fusion and LastLevelMaxPool, StandardRPNHead).  Proposal selection / NMS / ROIAlign / box + mask heads are
+// rcnn_ops.hip and rcnn_post.hip (peanut_rcnn_inference).  Parity is pinned only against the torch
 // restatement oracle/rcnn_ref.py ("parity unpinned" w.r.t. the reference).
 #include <string.h>
 
-#include "net_common.h"
+#include "rcnn_internal.h"
 
 namespace peanut {
 namespace {
@@ -104,44 +104,10 @@ inline unsigned grid_for(long long items) {
   return (unsigned)g;
 }
 
-enum ROpKind { R_PREPROCESS, R_CONV, R_MAXPOOL, R_ADD_UP, R_SUBSAMPLE };
-
-struct ROp {
-  ROpKind kind;
-  std::string name, kernel;
-  const ConvLayer* conv = nullptr;
-  Act in, res, out;
-  Act wino_v, wino_m;         // scratch of the Winograd form (R_CONV of a layer that carries one)
-  bool has_res = false, has_wino = false;
-  double flops = 0;
-  float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
-  int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
-};
-
-struct RPlan {
-  int B = 0, H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
-  Act splitk;
-  size_t bytes = 0;
-  std::vector<ROp> ops;
-  int lvl_h[5] = {0}, lvl_w[5] = {0};
-};
-
 }  // namespace
 }  // namespace peanut
 
 using namespace peanut;
-
-struct peanut_rcnn {
-  peanut_rcnn_cfg cfg{};
-  std::vector<std::unique_ptr<ConvLayer>> convs;
-  ConvLayer* stem = nullptr;
-  struct Block { ConvLayer *shortcut, *c1, *c2, *c3; };
-  std::vector<std::vector<Block>> stages;
-  ConvLayer *lateral[4] = {nullptr}, *output[4] = {nullptr};   // levels 2..5
-  ConvLayer *rpn_conv = nullptr, *rpn_obj = nullptr, *rpn_delta = nullptr;
-  std::map<std::string, std::unique_ptr<RPlan>> plans;
-  DevBuf ws;
-};
 
 namespace {
 
@@ -357,6 +323,7 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
   if ((rc = add_rconv(h.get(), tm, "proposal_generator.rpn_head.conv", f, f, f, 3, 1, 1, false, 1, &h->rpn_conv))) return rc;
   if ((rc = add_rconv(h.get(), tm, "proposal_generator.rpn_head.objectness_logits", f, f, cfg->num_anchors, 1, 1, 0, false, 0, &h->rpn_obj))) return rc;
   if ((rc = add_rconv(h.get(), tm, "proposal_generator.rpn_head.anchor_deltas", f, f, cfg->num_anchors * 4, 1, 1, 0, false, 0, &h->rpn_delta))) return rc;
+  if (tm.m.count("roi_heads.box_head.fc1.weight") && (rc = peanut_rcnn_build_heads(h.get(), tm))) return rc;
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = h.release();
   return 0;

@@ -1,0 +1,53 @@
+// Types shared by the Mask R-CNN translation units (rcnn_api.hip: front end; rcnn_post.hip: proposal selection,
+// ROI heads, detection selection, mask pasting -- the whole of peanut_rcnn_inference).
+#pragma once
+#include "net_common.h"
+
+namespace peanut {
+
+enum ROpKind { R_PREPROCESS, R_CONV, R_MAXPOOL, R_ADD_UP, R_SUBSAMPLE };
+
+struct ROp {
+  ROpKind kind;
+  std::string name, kernel;
+  const ConvLayer* conv = nullptr;
+  Act in, res, out;
+  Act wino_v, wino_m;         // scratch of the Winograd form (R_CONV of a layer that carries one)
+  bool has_res = false, has_wino = false;
+  double flops = 0;
+  float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
+  int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
+};
+
+struct RPlan {
+  int B = 0, H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
+  Act splitk;
+  size_t bytes = 0;
+  std::vector<ROp> ops;
+  int lvl_h[5] = {0}, lvl_w[5] = {0};
+};
+
+
+}  // namespace peanut
+
+struct peanut_rcnn {
+  peanut_rcnn_cfg cfg{};
+  std::vector<std::unique_ptr<peanut::ConvLayer>> convs;
+  peanut::ConvLayer* stem = nullptr;
+  struct Block { peanut::ConvLayer *shortcut, *c1, *c2, *c3; };
+  std::vector<std::vector<Block>> stages;
+  peanut::ConvLayer *lateral[4] = {nullptr}, *output[4] = {nullptr};   // levels 2..5
+  peanut::ConvLayer *rpn_conv = nullptr, *rpn_obj = nullptr, *rpn_delta = nullptr;
+  std::map<std::string, std::unique_ptr<peanut::RPlan>> plans;
+  peanut::DevBuf ws;
+  // ROI heads (present when the state dict carries roi_heads.*): FC layers as 1x1 convs, mask head convs
+  bool has_heads = false;
+  peanut::ConvLayer *fc1 = nullptr, *fc2 = nullptr, *cls_score = nullptr, *bbox_pred = nullptr, *deconv = nullptr, *mask_pred = nullptr;
+  std::vector<peanut::ConvLayer*> mask_fcn;
+  struct PostBufs;                       // scratch of peanut_rcnn_inference (rcnn_post.hip)
+  std::shared_ptr<PostBufs> post;
+};
+
+
+// rcnn_post.hip: builds the ROI-head layers when the state dict carries roi_heads.* (called by peanut_rcnn_create)
+int peanut_rcnn_build_heads(peanut_rcnn* h, const peanut::TensorMap& tm);

@@ -1,0 +1,804 @@
+// peanut_rcnn_inference: the whole of detectron2's GeneralizedRCNN.inference + detector_postprocess as configured by
+// nav/agent/utils/COCO-InstSeg/mask_rcnn_R_101_cat9.yaml -- what `DefaultPredictor(img)["instances"]` yields at
+// nav/agent/utils/segmentation.py:45 -- behind ONE C entry point, with no torch in it:
+//
+//   front end (rcnn_api.hip)  ->  RPN proposal selection  ->  box head  ->  detection selection  ->  mask head  ->  paste
+//
+// detectron2 is third party and absent from the reference checkout: the stages restate its
+// published v0.6 definitions (find_top_rpn_proposals, Box2BoxTransform.apply_deltas, ROIPooler level assignment,
+// fast_rcnn_inference_single_image, mask_rcnn_inference, detector_postprocess / paste_masks_in_image); parity is
+// pinned against oracle/rcnn_ref.py only (PARITY UNPINNED).
+//
+// Everything data-dependent stays on the device with fixed capacities (1000 proposals and 9000 class candidates per
+// image) and device-side counts; the only host read is the number of detections per image, which the caller needs
+// anyway and which sizes the mask head.  The selection stages that detectron2 writes as torch glue are kernels here:
+//   rpn_topk_kernel      per (level, image) top-k of the objectness logits: three-pass radix select on the
+//                        order-preserving key bits (LDS histogram), then a 1024-wide bitonic sort -- one workgroup
+//   rpn_decode_kernel    anchors (closed form) + apply_deltas + clip + validity, 64-bit sort keys (score | position)
+//   sort_keys_kernel     per image bitonic sort of up to 16384 keys in LDS (ties: first position first, = a stable sort)
+//   nms kernels          the block-bit-matrix NMS of rcnn_ops.hip with device-side segment lengths
+//   compact_*_kernel     ordered compaction of the kept boxes (+ FPN level assignment / output scaling)
+//   box_post_kernel      softmax + per-class box decode + score threshold -> class candidates
+//   mask_prob_kernel     class channel of the mask logits + sigmoid, un-shuffling the 2x2 transposed-conv outputs
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "rcnn_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace peanut {
+namespace {
+
+constexpr int kLevels = 5;
+constexpr int kMaxAnchors = 8;
+constexpr float kScaleClamp = 4.135166556742356f;   // log(1000 / 16), Box2BoxTransform
+
+__device__ __forceinline__ unsigned ord_key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_key_inv(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct RpnLevels {
+  const float* obj[kLevels];      // [B, h, w, A]
+  const float* delta[kLevels];    // [B, h, w, 4A]
+  int h[kLevels], w[kLevels], n[kLevels], k[kLevels], koff[kLevels + 1];
+  float stride[kLevels];
+  float cell[kLevels][kMaxAnchors][4];   // cell anchors (x0, y0, x1, y1) around (0, 0)
+  int A;
+};
+
+// bitonic sort (descending) of n = power of two 64-bit keys in LDS, any thread count that divides n / 2 evenly
+__device__ __forceinline__ void bitonic_desc(unsigned long long* s, int n) {
+  for (int size = 2; size <= n; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));        // index of the lower element of pair t
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a < b) == desc) { s[lo] = b; s[hi] = a; }
+      }
+    }
+  __syncthreads();
+}
+
+// the bin (counting from the top) in which the `need`-th largest element falls, and how many elements lie above it
+__device__ __forceinline__ void find_bin(const int* hist, int nbins, int need, int* s_part, int* s_out) {
+  const int W = nbins / 64;
+  if (threadIdx.x < 64) {
+    int a = 0;
+    for (int i = 0; i < W; ++i) a += hist[threadIdx.x * W + i];
+    s_part[threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0, g = 63;
+    for (; g > 0; --g) {
+      if (acc + s_part[g] >= need) break;
+      acc += s_part[g];
+    }
+    int b = (g + 1) * W - 1;
+    for (; b > g * W; --b) {
+      if (acc + hist[b] >= need) break;
+      acc += hist[b];
+    }
+    s_out[0] = b;
+    s_out[1] = acc;
+  }
+  __syncthreads();
+}
+
+// ---- per (level, image): the k largest objectness logits, sorted descending (ties: lower index first) ----
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int Ktot, int* __restrict__ sel_idx,
+                                                        float* __restrict__ sel_score) {
+  const int l = blockIdx.x, b = blockIdx.y;
+  const int n = lv.n[l], k = lv.k[l];
+  const float* x = lv.obj[l] + (size_t)b * n;
+  __shared__ int hist[2048];
+  __shared__ int part[64];
+  __shared__ int res[2];
+  __shared__ int cnt, taken_eq;
+  __shared__ unsigned long long sbuf[1024];
+  __shared__ int wave_cnt[16];
+  const int tid = threadIdx.x;
+  int need = k;
+  unsigned prefix = 0;   // bits of the threshold key fixed so far
+  // three radix passes: bits 31..21, 20..10, 9..0
+  const int shift[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  int eq_count = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned key = ord_key(x[i]);
+      const bool match = pass == 0 || (key >> (shift[pass] + bits[pass])) == prefix;
+      if (match) atomicAdd(&hist[(key >> shift[pass]) & (nb - 1)], 1);
+    }
+    __syncthreads();
+    find_bin(hist, nb < 64 ? 64 : nb, need, part, res);
+    prefix = (prefix << bits[pass]) | (unsigned)res[0];
+    need -= res[1];
+    if (pass == 2) eq_count = hist[res[0]];
+    __syncthreads();
+  }
+  const unsigned thr = prefix;      // exact key of the k-th largest element; `need` (>= 1) of the elements equal to it are taken
+  if (tid == 0) { cnt = 0; taken_eq = 0; }
+  sbuf[tid] = 0ull;
+  __syncthreads();
+  if (eq_count == need) {           // every element equal to the threshold is in: one unordered pass
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned key = ord_key(x[i]);
+      if (key >= thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+    }
+  } else {                          // ties across the cut: the first `need` of them by index (ordered chunks)
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+      const int i = i0 + tid;
+      const unsigned key = i < n ? ord_key(x[i]) : 0u;
+      if (i < n && key > thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+      const bool eq = i < n && key == thr;
+      const unsigned long long bal = __ballot(eq);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) wave_cnt[wv] = __popcll(bal);
+      __syncthreads();
+      int before = taken_eq;
+      for (int q = 0; q < wv; ++q) before += wave_cnt[q];
+      before += __popcll(bal & ((1ull << lane) - 1ull));
+      if (eq && before < need) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+      __syncthreads();
+      if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wave_cnt[q]; taken_eq += t; }
+      __syncthreads();
+    }
+  }
+  bitonic_desc(sbuf, 1024);
+  if (tid < k) {
+    const unsigned long long e = sbuf[tid];
+    const size_t o = (size_t)b * Ktot + lv.koff[l] + tid;
+    sel_idx[o] = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
+    sel_score[o] = ord_key_inv((unsigned)(e >> 32));
+  }
+}
+
+// Box2BoxTransform.apply_deltas for one box (same operation order as the torch expression)
+__device__ __forceinline__ void apply_deltas1(const float* d, float ax0, float ay0, float ax1, float ay1, float wx, float wy,
+                                              float ww, float wh, float* o) {
+  const float widths = ax1 - ax0, heights = ay1 - ay0;
+  const float ctr_x = ax0 + 0.5f * widths, ctr_y = ay0 + 0.5f * heights;
+  const float dx = d[0] / wx, dy = d[1] / wy;
+  const float dw = fminf(d[2] / ww, kScaleClamp), dh = fminf(d[3] / wh, kScaleClamp);
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+  const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+  o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
+}
+__device__ __forceinline__ bool finite4(const float* b) { return isfinite(b[0]) && isfinite(b[1]) && isfinite(b[2]) && isfinite(b[3]); }
+__device__ __forceinline__ void clip4(float* b, float h, float w) {
+  b[0] = fminf(fmaxf(b[0], 0.f), w); b[1] = fminf(fmaxf(b[1], 0.f), h);
+  b[2] = fminf(fmaxf(b[2], 0.f), w); b[3] = fminf(fmaxf(b[3], 0.f), h);
+}
+
+// ---- decode the selected anchors: RPN.predict_proposals + the validity tests of find_top_rpn_proposals ----
+__global__ __launch_bounds__(256) void rpn_decode_kernel(const RpnLevels lv, int B, int Ktot, int Kpad, const int* __restrict__ sel_idx,
+                                                         const float* __restrict__ sel_score, float img_h, float img_w, float wx,
+                                                         float wy, float ww, float wh, float* __restrict__ cbox,
+                                                         unsigned long long* __restrict__ ckey, int* __restrict__ ccat) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * Kpad) return;
+  const int b = i / Kpad, j = i - b * Kpad;
+  if (j >= Ktot) { ckey[i] = 0ull; return; }
+  int l = 0;
+  while (l + 1 < kLevels && j >= lv.koff[l + 1]) ++l;
+  const size_t o = (size_t)b * Ktot + j;
+  const int idx = sel_idx[o];
+  const float score = sel_score[o];
+  const int A = lv.A, a = idx % A, cellpos = idx / A;
+  const int yy = cellpos / lv.w[l], xx = cellpos - yy * lv.w[l];
+  const float sx = (float)xx * lv.stride[l], sy = (float)yy * lv.stride[l];
+  const float* c = lv.cell[l][a];
+  const float* d = lv.delta[l] + ((size_t)b * lv.n[l] / A + cellpos) * (4 * A) + a * 4;
+  float box[4];
+  apply_deltas1(d, sx + c[0], sy + c[1], sx + c[2], sy + c[3], wx, wy, ww, wh, box);
+  bool valid = finite4(box) && isfinite(score);
+  clip4(box, img_h, img_w);
+  valid = valid && (box[2] - box[0]) > 0.f && (box[3] - box[1]) > 0.f;
+  float* ob = cbox + o * 4;
+  ob[0] = box[0]; ob[1] = box[1]; ob[2] = box[2]; ob[3] = box[3];
+  ccat[o] = l;
+  ckey[i] = valid ? (((unsigned long long)ord_key(score) << 32) | (0xffffffffu - (unsigned)j)) : 0ull;
+}
+
+// ---- per image: sort the keys descending (key 0 = invalid, ends up last); nvalid[b] = number of valid keys ----
+template <int Kpad>
+__global__ __launch_bounds__(1024) void sort_keys_kernel(unsigned long long* __restrict__ keys, int* __restrict__ nvalid) {
+  __shared__ unsigned long long sk[Kpad];
+  unsigned long long* g = keys + (size_t)blockIdx.x * Kpad;
+  for (int i = threadIdx.x; i < Kpad; i += 1024) sk[i] = g[i];
+  bitonic_desc(sk, Kpad);
+  for (int i = threadIdx.x; i < Kpad; i += 1024) {
+    const unsigned long long v = sk[i];
+    g[i] = v;
+    if (v != 0ull && (i + 1 == Kpad || sk[i + 1] == 0ull)) nvalid[blockIdx.x] = i + 1;
+  }
+  if (threadIdx.x == 0 && sk[0] == 0ull) nvalid[blockIdx.x] = 0;
+}
+
+// ---- boxes / categories / scores in sorted order (row r of image b <- candidate position encoded in its key) ----
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const unsigned long long* __restrict__ keys, int Kpad, int Kcap, int B,
+                                                            const float* __restrict__ cbox, const int* __restrict__ ccat,
+                                                            float* __restrict__ sbox, int* __restrict__ scat, float* __restrict__ sscore) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * Kcap) return;
+  const int b = i / Kcap, r = i - b * Kcap;
+  const unsigned long long key = keys[(size_t)b * Kpad + r];
+  float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cat = -1;
+  float sc = 0.f;
+  if (key != 0ull) {
+    const int j = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+    box = *reinterpret_cast<const float4*>(cbox + ((size_t)b * Kcap + j) * 4);
+    cat = ccat[(size_t)b * Kcap + j];
+    sc = ord_key_inv((unsigned)(key >> 32));
+  }
+  *reinterpret_cast<float4*>(sbox + (size_t)i * 4) = box;
+  scat[i] = cat;
+  sscore[i] = sc;
+}
+
+// ---- NMS of score-sorted boxes, equal categories only (rcnn_ops.hip), fixed stride n_cap per image, live length
+//      count[b] read on the device: the bit matrix of image b has n_cap rows of `words` 64-bit words ----
+__global__ __launch_bounds__(64) void nms_mask_dev_kernel(const float* __restrict__ boxes_all, const int* __restrict__ cat_all, int n_cap,
+                                                          int words, const int* __restrict__ count, float thr,
+                                                          unsigned long long* __restrict__ ws) {
+  const int seg = blockIdx.z;
+  const int n = min(count[seg], n_cap);
+  const int nwords = (n + 63) >> 6;
+  const int row_blk = blockIdx.y, col_blk = blockIdx.x;
+  if (row_blk >= nwords || col_blk >= nwords || col_blk < row_blk) return;
+  const float* boxes = boxes_all + (size_t)seg * n_cap * 4;
+  const int* cat = cat_all + (size_t)seg * n_cap;
+  unsigned long long* mask = ws + (size_t)seg * n_cap * words;
+  const int i = row_blk * 64 + threadIdx.x;
+  __shared__ float sb[64][4];
+  __shared__ int sc[64];
+  const int j0 = col_blk * 64;
+  if (j0 + (int)threadIdx.x < n) {
+    const float* bx = boxes + (size_t)(j0 + threadIdx.x) * 4;
+    sb[threadIdx.x][0] = bx[0]; sb[threadIdx.x][1] = bx[1]; sb[threadIdx.x][2] = bx[2]; sb[threadIdx.x][3] = bx[3];
+    sc[threadIdx.x] = cat[j0 + threadIdx.x];
+  }
+  __syncthreads();
+  if (i >= n) return;
+  const float* a = boxes + (size_t)i * 4;
+  const float ax0 = a[0], ay0 = a[1], ax1 = a[2], ay1 = a[3];
+  const float area_a = (ax1 - ax0) * (ay1 - ay0);
+  const int ca = cat[i];
+  unsigned long long bitsv = 0;
+  const int lim = min(64, n - j0);
+  for (int k = (row_blk == col_blk ? (int)threadIdx.x + 1 : 0); k < lim; ++k) {
+    if (sc[k] != ca) continue;
+    const float ix0 = fmaxf(ax0, sb[k][0]), iy0 = fmaxf(ay0, sb[k][1]);
+    const float ix1 = fminf(ax1, sb[k][2]), iy1 = fminf(ay1, sb[k][3]);
+    const float iw = fmaxf(ix1 - ix0, 0.f), ih = fmaxf(iy1 - iy0, 0.f);
+    const float inter = iw * ih;
+    const float area_b = (sb[k][2] - sb[k][0]) * (sb[k][3] - sb[k][1]);
+    if (inter / (area_a + area_b - inter) > thr) bitsv |= 1ull << k;
+  }
+  mask[(size_t)i * words + col_blk] = bitsv;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_dev_kernel(const unsigned long long* __restrict__ ws, int n_cap, int words,
+                                                          const int* __restrict__ count, unsigned char* __restrict__ keep_all) {
+  extern __shared__ unsigned long long removed[];   // [words]
+  const int seg = blockIdx.x;
+  const int n = min(count[seg], n_cap);
+  const int nwords = (n + 63) >> 6;
+  const unsigned long long* mask = ws + (size_t)seg * n_cap * words;
+  unsigned char* keep = keep_all + (size_t)seg * n_cap;
+  const int lane = threadIdx.x;
+  for (int w = lane; w < nwords; w += 64) removed[w] = 0;
+  __syncthreads();
+  for (int b = 0; b < nwords; ++b) {
+    const int i = b * 64 + lane;
+    const unsigned long long diag = i < n ? mask[(size_t)i * words + b] : 0ull;
+    unsigned long long alive = ~removed[b];
+    if (b == nwords - 1 && (n & 63)) alive &= (1ull << (n & 63)) - 1;
+    for (int l = 0; l < 64; ++l) {
+      const unsigned long long d = readlane64(diag, l);
+      if ((alive >> l) & 1ull) alive &= ~d;
+    }
+    if (i < n) keep[i] = (alive >> lane) & 1ull;
+    for (int w = b + 1 + lane; w < nwords; w += 64) {
+      unsigned long long acc = 0;
+      unsigned long long rest = alive;
+      while (rest) {
+        const int r = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        acc |= mask[(size_t)(b * 64 + r) * words + w];
+      }
+      removed[w] |= acc;
+    }
+    __syncthreads();
+  }
+}
+
+// ordered prefix of a predicate over [0, n) with 1024 threads: calls emit(r, position) for the first `limit` hits
+template <class Pred, class Emit>
+__device__ __forceinline__ int ordered_compact(int n, int limit, Pred pred, Emit emit, int* wave_cnt, int* running) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) *running = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 1024) {
+    const int r = r0 + tid;
+    const bool hit = r < n && pred(r);
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int pos = *running;
+    for (int q = 0; q < wv; ++q) pos += wave_cnt[q];
+    pos += __popcll(bal & ((1ull << lane) - 1ull));
+    if (hit && pos < limit) emit(r, pos);
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wave_cnt[q]; *running += t; }
+    __syncthreads();
+    if (*running >= limit) break;
+  }
+  return min(*running, limit);
+}
+
+// ROIPooler.assign_boxes_to_levels (canonical size 224 at level 4, levels 2..5) -> 0..3
+__device__ __forceinline__ int assign_level(const float* b) {
+  const float size = sqrtf((b[2] - b[0]) * (b[3] - b[1]));
+  float lv = floorf(4.f + log2f(size / 224.f + 1e-8f));
+  lv = fminf(fmaxf(lv, 2.f), 5.f);
+  return (int)lv - 2;
+}
+
+// ---- post-NMS top-k proposals of every image -> rois [B * cap, 5], FPN level, objectness logit, count ----
+__global__ __launch_bounds__(1024) void compact_proposals_kernel(const float* __restrict__ sbox, const float* __restrict__ sscore,
+                                                                 const unsigned char* __restrict__ keep, const int* __restrict__ nvalid,
+                                                                 int Kcap, int cap, float* __restrict__ rois, int* __restrict__ levels,
+                                                                 float* __restrict__ logits, int* __restrict__ count) {
+  __shared__ int wave_cnt[16], running;
+  const int b = blockIdx.x;
+  const int n = min(nvalid[b], Kcap);
+  const float* bx = sbox + (size_t)b * Kcap * 4;
+  const unsigned char* kp = keep + (size_t)b * Kcap;
+  float* ro = rois + (size_t)b * cap * 5;
+  int* lo = levels + (size_t)b * cap;
+  for (int p = threadIdx.x; p < cap; p += 1024) {      // rows past the count: an empty roi on image 0
+    ro[p * 5 + 0] = 0.f; ro[p * 5 + 1] = 0.f; ro[p * 5 + 2] = 0.f; ro[p * 5 + 3] = 0.f; ro[p * 5 + 4] = 0.f;
+    lo[p] = 0;
+    logits[(size_t)b * cap + p] = 0.f;
+  }
+  __syncthreads();
+  const int c = ordered_compact(
+      n, cap, [&](int r) { return kp[r] != 0; },
+      [&](int r, int pos) {
+        const float* s = bx + (size_t)r * 4;
+        float* d = ro + (size_t)pos * 5;
+        d[0] = (float)b; d[1] = s[0]; d[2] = s[1]; d[3] = s[2]; d[4] = s[3];
+        lo[pos] = assign_level(s);
+        logits[(size_t)b * cap + pos] = sscore[(size_t)b * Kcap + r];
+      },
+      wave_cnt, &running);
+  if (threadIdx.x == 0) count[b] = c;
+}
+
+// ---- FastRCNNOutputLayers.inference for one roi: softmax, per-class decode, clip, score threshold ----
+__global__ __launch_bounds__(256) void box_post_kernel(const float* __restrict__ cls_logits, const float* __restrict__ deltas,
+                                                       const float* __restrict__ rois, const int* __restrict__ count, int B, int cap,
+                                                       int K, int Kpad, float img_h, float img_w, float wx, float wy, float ww, float wh,
+                                                       float score_thresh, float* __restrict__ dbox, unsigned long long* __restrict__ dkey,
+                                                       int* __restrict__ dcat) {
+  const int i = blockIdx.x * 256 + threadIdx.x;      // roi index
+  if (i >= B * cap) return;
+  const int b = i / cap, p = i - b * cap;
+  unsigned long long* keys = dkey + (size_t)b * Kpad;
+  if (p >= count[b]) {
+    for (int k = 0; k < K; ++k) keys[p * K + k] = 0ull;
+    return;
+  }
+  const float* lg = cls_logits + (size_t)i * (K + 1);
+  float m = lg[0];
+  for (int k = 1; k <= K; ++k) m = fmaxf(m, lg[k]);
+  float e[32], s = 0.f;
+  for (int k = 0; k <= K; ++k) { e[k] = expf(lg[k] - m); s += e[k]; }
+  bool ok = true;
+  for (int k = 0; k <= K; ++k) { e[k] = e[k] / s; ok = ok && isfinite(e[k]); }
+  const float* r = rois + (size_t)i * 5;
+  float boxes[32][4];
+  for (int k = 0; k < K; ++k) {
+    apply_deltas1(deltas + (size_t)i * 4 * K + 4 * k, r[1], r[2], r[3], r[4], wx, wy, ww, wh, boxes[k]);
+    ok = ok && finite4(boxes[k]);
+  }
+  for (int k = 0; k < K; ++k) {
+    const int c = p * K + k;
+    clip4(boxes[k], img_h, img_w);
+    float* ob = dbox + ((size_t)b * cap * K + c) * 4;
+    ob[0] = boxes[k][0]; ob[1] = boxes[k][1]; ob[2] = boxes[k][2]; ob[3] = boxes[k][3];
+    dcat[(size_t)b * cap * K + c] = k;
+    keys[c] = (ok && e[k] > score_thresh) ? (((unsigned long long)ord_key(e[k]) << 32) | (0xffffffffu - (unsigned)c)) : 0ull;
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_tail_keys_kernel(unsigned long long* __restrict__ keys, int B, int from, int Kpad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int span = Kpad - from;
+  if (i >= B * span) return;
+  keys[(size_t)(i / span) * Kpad + from + i % span] = 0ull;
+}
+
+// ---- the first `cap` kept detections of every image; detector_postprocess scaling / clipping / non-empty filter ----
+__global__ __launch_bounds__(1024) void compact_dets_kernel(const float* __restrict__ sbox, const int* __restrict__ scat,
+                                                            const float* __restrict__ sscore, const unsigned char* __restrict__ keep,
+                                                            const int* __restrict__ nvalid, int Kcap, int cap, float sx, float sy,
+                                                            float out_h, float out_w, float* __restrict__ box_in,
+                                                            float* __restrict__ box_out, float* __restrict__ score, int* __restrict__ cls,
+                                                            int* __restrict__ count) {
+  __shared__ int wave_cnt[16], running;
+  __shared__ int sel[1024];
+  const int b = blockIdx.x;
+  const int n = min(nvalid[b], Kcap);
+  const unsigned char* kp = keep + (size_t)b * Kcap;
+  // 1) the first `cap` survivors of the NMS, in score order
+  const int c1 = ordered_compact(n, min(cap, 1024), [&](int r) { return kp[r] != 0; }, [&](int r, int pos) { sel[pos] = r; }, wave_cnt,
+                                 &running);
+  __syncthreads();
+  // 2) scale to the output resolution, clip, drop empty boxes (keeps the order)
+  const int c2 = ordered_compact(
+      c1, cap,
+      [&](int q) {
+        const float* s = sbox + ((size_t)b * Kcap + sel[q]) * 4;
+        float o[4] = {s[0] * sx, s[1] * sy, s[2] * sx, s[3] * sy};
+        clip4(o, out_h, out_w);
+        return (o[2] - o[0]) > 0.f && (o[3] - o[1]) > 0.f;
+      },
+      [&](int q, int pos) {
+        const size_t src = (size_t)b * Kcap + sel[q], dst = (size_t)b * cap + pos;
+        const float* s = sbox + src * 4;
+        float o[4] = {s[0] * sx, s[1] * sy, s[2] * sx, s[3] * sy};
+        clip4(o, out_h, out_w);
+        for (int t = 0; t < 4; ++t) { box_in[dst * 4 + t] = s[t]; box_out[dst * 4 + t] = o[t]; }
+        score[dst] = sscore[src];
+        cls[dst] = scat[src];
+      },
+      wave_cnt, &running);
+  if (threadIdx.x == 0) count[b] = c2;
+}
+
+struct Offsets64 { int off[65]; };
+
+// ---- compact per-image detection lists -> one list (image-major): mask rois, levels, caller outputs ----
+__global__ __launch_bounds__(256) void pack_dets_kernel(const float* __restrict__ box_in, const float* __restrict__ box_out,
+                                                        const float* __restrict__ score, const int* __restrict__ cls, int cap, int B,
+                                                        Offsets64 of, float* __restrict__ mrois, int* __restrict__ mlevels,
+                                                        float* __restrict__ o_boxes, float* __restrict__ o_scores, int* __restrict__ o_cls) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= of.off[B]) return;
+  int b = 0;
+  while (i >= of.off[b + 1]) ++b;
+  const size_t src = (size_t)b * cap + (i - of.off[b]);
+  const float* s = box_in + src * 4;
+  float* r = mrois + (size_t)i * 5;
+  r[0] = (float)b; r[1] = s[0]; r[2] = s[1]; r[3] = s[2]; r[4] = s[3];
+  mlevels[i] = assign_level(s);
+  for (int t = 0; t < 4; ++t) o_boxes[(size_t)i * 4 + t] = box_out[src * 4 + t];
+  o_scores[i] = score[src];
+  o_cls[i] = cls[src];
+}
+
+// ---- mask_rcnn_inference: logits [n, P, 4P, K] (2x2 sub-pixels of the transposed conv along the width) ->
+//      probabilities [n, 2P, 2P] of each instance's class ----
+__global__ __launch_bounds__(256) void mask_prob_kernel(const float* __restrict__ logits, const int* __restrict__ cls, int n, int P, int K,
+                                                        float* __restrict__ probs) {
+  const int M = 2 * P;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * M * M) return;
+  const int X = i % M, Y = (i / M) % M, inst = i / (M * M);
+  const float v = logits[(((size_t)inst * P + (Y >> 1)) * (4 * P) + (X >> 1) * 4 + (Y & 1) * 2 + (X & 1)) * K + cls[inst]];
+  probs[i] = 1.f / (1.f + expf(-v));
+}
+
+inline int launch_sort_keys(unsigned long long* keys, int Kpad, int B, int* nvalid, hipStream_t s) {
+  switch (Kpad) {
+    case 16384: hipLaunchKernelGGL(sort_keys_kernel<16384>, dim3(B), dim3(1024), 0, s, keys, nvalid); break;
+    case 8192: hipLaunchKernelGGL(sort_keys_kernel<8192>, dim3(B), dim3(1024), 0, s, keys, nvalid); break;
+    case 4096: hipLaunchKernelGGL(sort_keys_kernel<4096>, dim3(B), dim3(1024), 0, s, keys, nvalid); break;
+    case 2048: hipLaunchKernelGGL(sort_keys_kernel<2048>, dim3(B), dim3(1024), 0, s, keys, nvalid); break;
+    default: return fail(PEANUT_EINVAL, "rcnn: unsupported sort size");
+  }
+  return 0;
+}
+
+inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)std::max<long long>(1, (n + per - 1) / per); }
+inline int pow2_at_least(int n) { int p = 2048; while (p < n) p <<= 1; return p; }
+
+}  // namespace
+}  // namespace peanut
+
+using namespace peanut;
+
+struct peanut_rcnn::PostBufs {
+  DevBuf pyr[5], obj[5], dl[5];
+  DevBuf sel_idx, sel_score, cbox, ckey, ccat, sbox, scat, sscore, keep, nms_ws, nvalid;
+  DevBuf rois, roi_level, roi_logit, prop_count;
+  DevBuf x7, f1, f2, cls, bbox;
+  DevBuf dbox, dkey, dcat, dsbox, dscat, dsscore, dkeep, dnvalid;
+  DevBuf det_in, det_out, det_score, det_cls, det_count;
+  DevBuf mrois, mlevel, mx0, mx1, mdeconv, mlogits, mprobs, splitk, wino_v, wino_m;
+};
+
+namespace {
+
+int conv_on(const ConvLayer* L, const float* x, float* y, int B, int H, int W, float* splitk, float* wv, float* wm, hipStream_t s) {
+  ConvArgs a{};
+  a.x = x; a.y = y; a.B = B; a.H = H; a.W = W; a.c1 = L->d.cin; a.c2 = 0;
+  a.Ho = conv_out_dim(H, L->d.kh, L->d.stride, L->d.pad, L->d.dil);
+  a.Wo = conv_out_dim(W, L->d.kw, L->d.stride, L->d.pad, L->d.dil);
+  a.ws = splitk; a.ws_floats = kSplitKScratchFloats;
+  return launch_conv_layer(*L, a, wv, wm, s);
+}
+
+int add_head_conv(peanut_rcnn* h, const std::string& name, const float* w_oihw, const float* bias, int cout, int cin, int k, int pad,
+                  int relu, bool allow_wino, ConvLayer** out) {
+  auto L = std::make_unique<ConvLayer>();
+  L->name = name;
+  std::vector<float> shift(bias, bias + cout);
+  int rc = upload_conv(*L, w_oihw, nullptr, shift.data(), cout, cin, cin, k, k, 1, pad, 1, relu, h->cfg.precision);
+  if (rc) return rc;
+  if (allow_wino && h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin, cout, k, k, 1, pad, 1, h->cfg.precision) &&
+      (rc = upload_wino(*L, w_oihw, cout, cin, cin, h->cfg.precision)))
+    return rc;
+  *out = L.get();
+  h->convs.push_back(std::move(L));
+  return 0;
+}
+
+}  // namespace
+
+// called by peanut_rcnn_create when the state dict carries roi_heads.* (rcnn_api.hip)
+int peanut_rcnn_build_heads(peanut_rcnn* h, const TensorMap& tm) {
+  const peanut_rcnn_cfg& c = h->cfg;
+  const int P = c.box_pooler_resolution, F = c.fpn_out, K = c.num_classes, fc = c.fc_dim, mc = c.mask_conv_dim;
+  if (K < 1 || K > 31 || P < 1 || c.mask_pooler_resolution < 1 || fc % 32 || mc % 32 || c.num_anchors > kMaxAnchors ||
+      c.rpn_pre_nms_topk < 1 || c.rpn_pre_nms_topk > 1024 || c.rpn_post_nms_topk < 1 || c.detections_per_image < 1 ||
+      c.detections_per_image > 1024 || (long long)c.rpn_post_nms_topk * K > 16384)
+    return fail(PEANUT_EINVAL, "rcnn: unsupported ROI-head configuration");
+  int rc = 0;
+  auto get = [&](const std::string& k, std::initializer_list<int64_t> shp) -> const peanut_tensor* {
+    int64_t sh[4] = {0, 0, 0, 0};
+    int nd = 0;
+    for (int64_t v : shp) sh[nd++] = v;
+    return tm.get(k, nd, sh, &rc);
+  };
+  // fc1 consumes the ROIAlign output flattened NHWC ((y*P+x)*C + c); detectron2 flattens NCHW (c*P*P + y*P + x)
+  const peanut_tensor *w1 = get("roi_heads.box_head.fc1.weight", {fc, (int64_t)F * P * P}), *b1 = get("roi_heads.box_head.fc1.bias", {fc});
+  const peanut_tensor *w2 = get("roi_heads.box_head.fc2.weight", {fc, fc}), *b2 = get("roi_heads.box_head.fc2.bias", {fc});
+  const peanut_tensor *wc = get("roi_heads.box_predictor.cls_score.weight", {K + 1, fc}), *bc = get("roi_heads.box_predictor.cls_score.bias", {K + 1});
+  const peanut_tensor *wb = get("roi_heads.box_predictor.bbox_pred.weight", {4 * K, fc}), *bb = get("roi_heads.box_predictor.bbox_pred.bias", {4 * K});
+  if (!w1 || !b1 || !w2 || !b2 || !wc || !bc || !wb || !bb) return rc;
+  {
+    std::vector<float> perm((size_t)fc * F * P * P);
+    for (int f = 0; f < fc; ++f)
+      for (int ch = 0; ch < F; ++ch)
+        for (int y = 0; y < P; ++y)
+          for (int x = 0; x < P; ++x)
+            perm[(size_t)f * F * P * P + (size_t)(y * P + x) * F + ch] = w1->data[(size_t)f * F * P * P + (size_t)ch * P * P + y * P + x];
+    if ((rc = add_head_conv(h, "roi_heads.box_head.fc1", perm.data(), b1->data, fc, F * P * P, 1, 0, 1, false, &h->fc1))) return rc;
+  }
+  if ((rc = add_head_conv(h, "roi_heads.box_head.fc2", w2->data, b2->data, fc, fc, 1, 0, 1, false, &h->fc2))) return rc;
+  if ((rc = add_head_conv(h, "roi_heads.box_predictor.cls_score", wc->data, bc->data, K + 1, fc, 1, 0, 0, false, &h->cls_score))) return rc;
+  if ((rc = add_head_conv(h, "roi_heads.box_predictor.bbox_pred", wb->data, bb->data, 4 * K, fc, 1, 0, 0, false, &h->bbox_pred))) return rc;
+  int cin = F;
+  for (int i = 0; i < c.num_mask_convs; ++i) {
+    const std::string n = "roi_heads.mask_head.mask_fcn" + std::to_string(i + 1);
+    const peanut_tensor *w = get(n + ".weight", {mc, cin, 3, 3}), *b = get(n + ".bias", {mc});
+    if (!w || !b) return rc;
+    ConvLayer* L = nullptr;
+    if ((rc = add_head_conv(h, n, w->data, b->data, mc, cin, 3, 1, 1, true, &L))) return rc;
+    h->mask_fcn.push_back(L);
+    cin = mc;
+  }
+  const peanut_tensor *wd = get("roi_heads.mask_head.deconv.weight", {mc, mc, 2, 2}), *bd = get("roi_heads.mask_head.deconv.bias", {mc});
+  const peanut_tensor *wp = get("roi_heads.mask_head.predictor.weight", {K, mc, 1, 1}), *bp = get("roi_heads.mask_head.predictor.bias", {K});
+  if (!wd || !bd || !wp || !bp) return rc;
+  {
+    // ConvTranspose2d(k = 2, s = 2) = four 1x1 convs, one per output sub-pixel (dy, dx): rows (dy*2+dx)*C + n; the
+    // ConvTranspose2d weight is [in c][out n][dy][dx]
+    std::vector<float> w4((size_t)4 * mc * mc), b4((size_t)4 * mc);
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx)
+        for (int n = 0; n < mc; ++n) {
+          b4[(size_t)(dy * 2 + dx) * mc + n] = bd->data[n];
+          for (int ch = 0; ch < mc; ++ch)
+            w4[((size_t)(dy * 2 + dx) * mc + n) * mc + ch] = wd->data[(((size_t)ch * mc + n) * 2 + dy) * 2 + dx];
+        }
+    if ((rc = add_head_conv(h, "roi_heads.mask_head.deconv", w4.data(), b4.data(), 4 * mc, mc, 1, 0, 1, false, &h->deconv))) return rc;
+  }
+  if ((rc = add_head_conv(h, "roi_heads.mask_head.predictor", wp->data, bp->data, K, mc, 1, 0, 0, false, &h->mask_pred))) return rc;
+  h->has_heads = true;
+  return 0;
+}
+
+extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
+                                     float* scores, int32_t* classes, uint8_t* masks, void* stream) {
+  if (!h || !img_bgr || !n_det_host || !boxes || !scores || !classes) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: null argument");
+  if (!h->has_heads) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: the handle was created without roi_heads.* tensors");
+  if (B < 1 || B > 64) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: 1 <= B <= 64");
+  const peanut_rcnn_cfg& c = h->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  int rs[2], pd[2], lhw[10];
+  if ((rc = peanut_rcnn_plan(h, B, H, W, rs, pd, lhw, nullptr, nullptr))) return rc;
+  const int nh = rs[0], nw = rs[1];
+  if (!h->post) h->post = std::make_shared<peanut_rcnn::PostBufs>();
+  peanut_rcnn::PostBufs& pb = *h->post;
+  const int A = c.num_anchors, F = c.fpn_out, K = c.num_classes;
+
+  // ---- geometry of the selection stages ----
+  RpnLevels lv{};
+  lv.A = A;
+  int Ktot = 0;
+  for (int l = 0; l < kLevels; ++l) {
+    lv.h[l] = lhw[2 * l]; lv.w[l] = lhw[2 * l + 1];
+    lv.n[l] = lv.h[l] * lv.w[l] * A;
+    lv.k[l] = std::min(lv.n[l], c.rpn_pre_nms_topk);
+    lv.koff[l] = Ktot;
+    Ktot += lv.k[l];
+    lv.stride[l] = (float)(4 << l);
+    for (int a = 0; a < A; ++a) {   // DefaultAnchorGenerator.generate_cell_anchors (double arithmetic, then float32)
+      const double size = c.anchor_sizes[l], r = c.aspect_ratios[a];
+      const double w = sqrt(size * size / r), hh = r * w;
+      lv.cell[l][a][0] = (float)(-w / 2.0); lv.cell[l][a][1] = (float)(-hh / 2.0);
+      lv.cell[l][a][2] = (float)(w / 2.0); lv.cell[l][a][3] = (float)(hh / 2.0);
+    }
+  }
+  lv.koff[kLevels] = Ktot;
+  const int Kpad = pow2_at_least(Ktot);
+  if (Kpad > 16384) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: too many proposal candidates per image");
+  const int cap = c.rpn_post_nms_topk, N = B * cap;
+  const int D = c.detections_per_image;
+  const int Kc = cap * K, Kcpad = pow2_at_least(Kc);
+
+  // ---- buffers ----
+  for (int l = 0; l < kLevels; ++l) {
+    if ((rc = pb.pyr[l].ensure((size_t)B * lv.h[l] * lv.w[l] * F * 4)) || (rc = pb.obj[l].ensure((size_t)B * lv.n[l] * 4)) ||
+        (rc = pb.dl[l].ensure((size_t)B * lv.n[l] * 16)))
+      return rc;
+  }
+  const int words = (Ktot + 63) / 64, dwords = (Kc + 63) / 64;
+  if ((rc = pb.sel_idx.ensure((size_t)B * Ktot * 4)) || (rc = pb.sel_score.ensure((size_t)B * Ktot * 4)) ||
+      (rc = pb.cbox.ensure((size_t)B * Ktot * 16)) || (rc = pb.ckey.ensure((size_t)B * Kpad * 8)) || (rc = pb.ccat.ensure((size_t)B * Ktot * 4)) ||
+      (rc = pb.sbox.ensure((size_t)B * Ktot * 16)) || (rc = pb.scat.ensure((size_t)B * Ktot * 4)) || (rc = pb.sscore.ensure((size_t)B * Ktot * 4)) ||
+      (rc = pb.keep.ensure((size_t)B * Ktot)) || (rc = pb.nvalid.ensure((size_t)B * 4)) ||
+      (rc = pb.nms_ws.ensure(std::max((size_t)B * Ktot * words, (size_t)B * Kc * dwords) * 8)) ||
+      (rc = pb.rois.ensure((size_t)N * 20)) || (rc = pb.roi_level.ensure((size_t)N * 4)) || (rc = pb.roi_logit.ensure((size_t)N * 4)) ||
+      (rc = pb.prop_count.ensure((size_t)B * 4)) ||
+      (rc = pb.x7.ensure((size_t)N * c.box_pooler_resolution * c.box_pooler_resolution * F * 4)) || (rc = pb.f1.ensure((size_t)N * c.fc_dim * 4)) ||
+      (rc = pb.f2.ensure((size_t)N * c.fc_dim * 4)) || (rc = pb.cls.ensure((size_t)N * (K + 1) * 4)) || (rc = pb.bbox.ensure((size_t)N * 4 * K * 4)) ||
+      (rc = pb.dbox.ensure((size_t)B * Kc * 16)) || (rc = pb.dkey.ensure((size_t)B * Kcpad * 8)) || (rc = pb.dcat.ensure((size_t)B * Kc * 4)) ||
+      (rc = pb.dsbox.ensure((size_t)B * Kc * 16)) || (rc = pb.dscat.ensure((size_t)B * Kc * 4)) || (rc = pb.dsscore.ensure((size_t)B * Kc * 4)) ||
+      (rc = pb.dkeep.ensure((size_t)B * Kc)) || (rc = pb.dnvalid.ensure((size_t)B * 4)) ||
+      (rc = pb.det_in.ensure((size_t)B * D * 16)) || (rc = pb.det_out.ensure((size_t)B * D * 16)) || (rc = pb.det_score.ensure((size_t)B * D * 4)) ||
+      (rc = pb.det_cls.ensure((size_t)B * D * 4)) || (rc = pb.det_count.ensure((size_t)B * 4)) ||
+      (rc = pb.splitk.ensure(kSplitKScratchFloats * sizeof(float))))
+    return rc;
+
+  // ---- front end: pyramid p2..p6, objectness, anchor deltas ----
+  float *pyr[5], *obj[5], *dl[5];
+  for (int l = 0; l < kLevels; ++l) { pyr[l] = (float*)pb.pyr[l].p; obj[l] = (float*)pb.obj[l].p; dl[l] = (float*)pb.dl[l].p; }
+  if ((rc = peanut_rcnn_forward_front(h, img_bgr, B, H, W, pyr, obj, dl, stream))) return rc;
+  for (int l = 0; l < kLevels; ++l) { lv.obj[l] = obj[l]; lv.delta[l] = dl[l]; }
+
+  // ---- RPN: per-level top-k, decode, per-image sort, NMS (per level), post-NMS top-k ----
+  hipLaunchKernelGGL(rpn_topk_kernel, dim3(kLevels, B), dim3(1024), 0, s, lv, Ktot, (int*)pb.sel_idx.p, (float*)pb.sel_score.p);
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3(blocks_for((long long)B * Kpad)), dim3(256), 0, s, lv, B, Ktot, Kpad, (const int*)pb.sel_idx.p,
+                     (const float*)pb.sel_score.p, (float)nh, (float)nw, c.rpn_bbox_weights[0], c.rpn_bbox_weights[1], c.rpn_bbox_weights[2],
+                     c.rpn_bbox_weights[3], (float*)pb.cbox.p, (unsigned long long*)pb.ckey.p, (int*)pb.ccat.p);
+  if ((rc = launch_sort_keys((unsigned long long*)pb.ckey.p, Kpad, B, (int*)pb.nvalid.p, s))) return rc;
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Ktot)), dim3(256), 0, s, (const unsigned long long*)pb.ckey.p, Kpad,
+                     Ktot, B, (const float*)pb.cbox.p, (const int*)pb.ccat.p, (float*)pb.sbox.p, (int*)pb.scat.p, (float*)pb.sscore.p);
+  PEANUT_HIP_CHECK(hipMemsetAsync(pb.nms_ws.p, 0, (size_t)B * Ktot * words * 8, s));
+  hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(words, words, B), dim3(64), 0, s, (const float*)pb.sbox.p, (const int*)pb.scat.p, Ktot, words,
+                     (const int*)pb.nvalid.p, c.rpn_nms_thresh, (unsigned long long*)pb.nms_ws.p);
+  hipLaunchKernelGGL(nms_scan_dev_kernel, dim3(B), dim3(64), (size_t)words * 8, s, (const unsigned long long*)pb.nms_ws.p, Ktot, words,
+                     (const int*)pb.nvalid.p, (unsigned char*)pb.keep.p);
+  hipLaunchKernelGGL(compact_proposals_kernel, dim3(B), dim3(1024), 0, s, (const float*)pb.sbox.p, (const float*)pb.sscore.p,
+                     (const unsigned char*)pb.keep.p, (const int*)pb.nvalid.p, Ktot, cap, (float*)pb.rois.p, (int*)pb.roi_level.p,
+                     (float*)pb.roi_logit.p, (int*)pb.prop_count.p);
+
+  // ---- box head: ROIAlignV2 7x7 over p2..p5, two FC layers, class scores and box deltas ----
+  const float* feats[4] = {pyr[0], pyr[1], pyr[2], pyr[3]};
+  const int fhw[8] = {lv.h[0], lv.w[0], lv.h[1], lv.w[1], lv.h[2], lv.w[2], lv.h[3], lv.w[3]};
+  const float fsc[4] = {1.f / 4, 1.f / 8, 1.f / 16, 1.f / 32};
+  const int P = c.box_pooler_resolution;
+  if ((rc = peanut_roi_align(feats, fhw, fsc, 4, F, (const float*)pb.rois.p, (const int*)pb.roi_level.p, N, P, 0, 1, (float*)pb.x7.p, stream))) return rc;
+  float* sk = (float*)pb.splitk.p;
+  if ((rc = conv_on(h->fc1, (const float*)pb.x7.p, (float*)pb.f1.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
+  if ((rc = conv_on(h->fc2, (const float*)pb.f1.p, (float*)pb.f2.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
+  if ((rc = conv_on(h->cls_score, (const float*)pb.f2.p, (float*)pb.cls.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
+  if ((rc = conv_on(h->bbox_pred, (const float*)pb.f2.p, (float*)pb.bbox.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
+
+  // ---- fast_rcnn_inference: class candidates, per-image sort, class-wise NMS, top detections ----
+  hipLaunchKernelGGL(box_post_kernel, dim3(blocks_for(N)), dim3(256), 0, s, (const float*)pb.cls.p, (const float*)pb.bbox.p, (const float*)pb.rois.p,
+                     (const int*)pb.prop_count.p, B, cap, K, Kcpad, (float)nh, (float)nw, c.roi_bbox_weights[0], c.roi_bbox_weights[1],
+                     c.roi_bbox_weights[2], c.roi_bbox_weights[3], c.score_thresh_test, (float*)pb.dbox.p, (unsigned long long*)pb.dkey.p,
+                     (int*)pb.dcat.p);
+  if (Kcpad > Kc)
+    hipLaunchKernelGGL(zero_tail_keys_kernel, dim3(blocks_for((long long)B * (Kcpad - Kc))), dim3(256), 0, s, (unsigned long long*)pb.dkey.p, B, Kc, Kcpad);
+  if ((rc = launch_sort_keys((unsigned long long*)pb.dkey.p, Kcpad, B, (int*)pb.dnvalid.p, s))) return rc;
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Kc)), dim3(256), 0, s, (const unsigned long long*)pb.dkey.p, Kcpad, Kc, B,
+                     (const float*)pb.dbox.p, (const int*)pb.dcat.p, (float*)pb.dsbox.p, (int*)pb.dscat.p, (float*)pb.dsscore.p);
+  PEANUT_HIP_CHECK(hipMemsetAsync(pb.nms_ws.p, 0, (size_t)B * Kc * dwords * 8, s));
+  hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(dwords, dwords, B), dim3(64), 0, s, (const float*)pb.dsbox.p, (const int*)pb.dscat.p, Kc, dwords,
+                     (const int*)pb.dnvalid.p, c.nms_thresh_test, (unsigned long long*)pb.nms_ws.p);
+  hipLaunchKernelGGL(nms_scan_dev_kernel, dim3(B), dim3(64), (size_t)dwords * 8, s, (const unsigned long long*)pb.nms_ws.p, Kc, dwords,
+                     (const int*)pb.dnvalid.p, (unsigned char*)pb.dkeep.p);
+  // detector_postprocess scales boxes by (W / nw, H / nh): python doubles narrowed to float32 by the tensor product
+  const float sx = (float)((double)W / (double)nw), sy = (float)((double)H / (double)nh);
+  hipLaunchKernelGGL(compact_dets_kernel, dim3(B), dim3(1024), 0, s, (const float*)pb.dsbox.p, (const int*)pb.dscat.p, (const float*)pb.dsscore.p,
+                     (const unsigned char*)pb.dkeep.p, (const int*)pb.dnvalid.p, Kc, D, sx, sy, (float)H, (float)W, (float*)pb.det_in.p,
+                     (float*)pb.det_out.p, (float*)pb.det_score.p, (int*)pb.det_cls.p, (int*)pb.det_count.p);
+
+  // ---- the one host read: detections per image ----
+  PEANUT_HIP_CHECK(hipMemcpyAsync(n_det_host, pb.det_count.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+  Offsets64 of{};
+  for (int b = 0; b < B; ++b) of.off[b + 1] = of.off[b] + n_det_host[b];
+  const int n = of.off[B];
+  if (n == 0) return 0;
+  const int Pm = c.mask_pooler_resolution, mc = c.mask_conv_dim;
+  size_t vf = 0, mf = 0;
+  for (const ConvLayer* L : h->mask_fcn)
+    if (L->has_wino) { size_t v, m; wino_scratch_floats(*L, n, Pm, Pm, &v, &m); vf = std::max(vf, v); mf = std::max(mf, m); }
+  const size_t act = (size_t)n * Pm * Pm * std::max(F, mc) * 4;
+  if ((rc = pb.mrois.ensure((size_t)n * 20)) || (rc = pb.mlevel.ensure((size_t)n * 4)) || (rc = pb.mx0.ensure(act)) || (rc = pb.mx1.ensure(act)) ||
+      (rc = pb.mdeconv.ensure((size_t)n * Pm * Pm * 4 * mc * 4)) || (rc = pb.mlogits.ensure((size_t)n * Pm * Pm * 4 * K * 4)) ||
+      (rc = pb.mprobs.ensure((size_t)n * 4 * Pm * Pm * 4)) || (vf && (rc = pb.wino_v.ensure(vf * 4))) || (mf && (rc = pb.wino_m.ensure(mf * 4))))
+    return rc;
+  hipLaunchKernelGGL(pack_dets_kernel, dim3(blocks_for(n)), dim3(256), 0, s, (const float*)pb.det_in.p, (const float*)pb.det_out.p,
+                     (const float*)pb.det_score.p, (const int*)pb.det_cls.p, D, B, of, (float*)pb.mrois.p, (int*)pb.mlevel.p, boxes, scores, classes);
+  if (!masks) {
+    hipError_t e0 = hipGetLastError();
+    return e0 == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_rcnn_inference: ") + hipGetErrorString(e0));
+  }
+  // ---- mask head: ROIAlignV2 14x14, conv stack, 2x2 transposed conv, class logits, sigmoid; paste at 0.5 ----
+  if ((rc = peanut_roi_align(feats, fhw, fsc, 4, F, (const float*)pb.mrois.p, (const int*)pb.mlevel.p, n, Pm, 0, 1, (float*)pb.mx0.p, stream))) return rc;
+  float *cur = (float*)pb.mx0.p, *nxt = (float*)pb.mx1.p;
+  for (const ConvLayer* L : h->mask_fcn) {
+    if ((rc = conv_on(L, cur, nxt, n, Pm, Pm, sk, L->has_wino ? (float*)pb.wino_v.p : nullptr, L->has_wino ? (float*)pb.wino_m.p : nullptr, s))) return rc;
+    std::swap(cur, nxt);
+  }
+  if ((rc = conv_on(h->deconv, cur, (float*)pb.mdeconv.p, n, Pm, Pm, sk, nullptr, nullptr, s))) return rc;
+  if ((rc = conv_on(h->mask_pred, (const float*)pb.mdeconv.p, (float*)pb.mlogits.p, n, Pm, Pm * 4, sk, nullptr, nullptr, s))) return rc;
+  hipLaunchKernelGGL(mask_prob_kernel, dim3(blocks_for((long long)n * 4 * Pm * Pm)), dim3(256), 0, s, (const float*)pb.mlogits.p, (const int*)classes, n,
+                     Pm, K, (float*)pb.mprobs.p);
+  if ((rc = peanut_paste_masks((const float*)pb.mprobs.p, boxes, n, 2 * Pm, H, W, c.mask_threshold, masks, stream))) return rc;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_rcnn_inference: ") + hipGetErrorString(e));
+}
+
+// test / bisect hook: device pointers of the stage outputs of the last peanut_rcnn_inference call
+extern "C" int peanut_rcnn_debug_stage(peanut_rcnn_t* h, const char* name, const void** dev, size_t* bytes) {
+  if (!h || !h->post || !name || !dev) return fail(PEANUT_EINVAL, "peanut_rcnn_debug_stage: no inference has run");
+  peanut_rcnn::PostBufs& pb = *h->post;
+  const struct { const char* n; DevBuf* b; } tab[] = {
+      {"rois", &pb.rois}, {"roi_level", &pb.roi_level}, {"roi_logit", &pb.roi_logit}, {"prop_count", &pb.prop_count}, {"cls", &pb.cls},
+      {"bbox", &pb.bbox}, {"det_in", &pb.det_in}, {"det_out", &pb.det_out}, {"det_score", &pb.det_score}, {"det_cls", &pb.det_cls},
+      {"det_count", &pb.det_count}, {"mprobs", &pb.mprobs}, {"sel_idx", &pb.sel_idx}, {"sel_score", &pb.sel_score}, {"nvalid", &pb.nvalid}};
+  for (const auto& t : tab)
+    if (!strcmp(t.n, name)) { *dev = t.b->p; if (bytes) *bytes = t.b->bytes; return 0; }
+  return fail(PEANUT_EINVAL, std::string("peanut_rcnn_debug_stage: unknown stage ") + name);
+}

@@ -22,7 +22,7 @@ class MaskRCNNFront:
         self.cfg, self.device, self.precision = cfg, torch.device(device), precision
         self._lib = _lib.load()
         tensors = []
-        for key, shape in front_keys(cfg):
+        for key, shape in list(front_keys(cfg)) + list(self._extra_keys(cfg, state_dict)):
             if key not in state_dict:
                 raise KeyError(f"checkpoint is missing '{key}'")
             t = state_dict[key]
@@ -42,9 +42,25 @@ class MaskRCNNFront:
         self.conv_algo = conv_algo
         for i in range(3):
             c.pixel_mean[i], c.pixel_std[i] = cfg.pixel_mean[i], cfg.pixel_std[i]
+        # proposal generator / ROI heads (read by peanut_rcnn_inference)
+        for i, v in enumerate(cfg.anchor_sizes):
+            c.anchor_sizes[i] = float(v)
+        for i, v in enumerate(cfg.aspect_ratios):
+            c.aspect_ratios[i] = float(v)
+        c.rpn_pre_nms_topk, c.rpn_post_nms_topk, c.rpn_nms_thresh = cfg.rpn_pre_nms_topk, cfg.rpn_post_nms_topk, cfg.rpn_nms_thresh
+        c.num_classes, c.box_pooler_resolution, c.mask_pooler_resolution = cfg.num_classes, cfg.box_pooler_resolution, cfg.mask_pooler_resolution
+        c.fc_dim, c.mask_conv_dim, c.num_mask_convs = cfg.fc_dim, cfg.mask_conv_dim, cfg.num_mask_convs
+        for i in range(4):
+            c.rpn_bbox_weights[i], c.roi_bbox_weights[i] = cfg.rpn_bbox_weights[i], cfg.roi_bbox_weights[i]
+        c.score_thresh_test, c.nms_thresh_test = cfg.score_thresh_test, cfg.nms_thresh_test
+        c.detections_per_image, c.mask_threshold = cfg.detections_per_image, cfg.mask_threshold
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.peanut_rcnn_create(C.byref(self._h), C.byref(c), arr, len(tensors)), "peanut_rcnn_create")
+
+    def _extra_keys(self, cfg, state_dict):
+        """State-dict entries beyond the front end that the library should also receive (none here)."""
+        return []
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -233,13 +249,17 @@ class MaskRCNN(MaskRCNNFront):
     """``GeneralizedRCNN.inference`` + ``detector_postprocess`` as configured by mask_rcnn_R_101_cat9.yaml:
     what ``DefaultPredictor(img)["instances"]`` yields (segmentation.py:45), batched."""
 
+    def _extra_keys(self, cfg, state_dict):
+        from .rcnn_weights import roi_head_keys
+        return roi_head_keys(cfg)          # the library builds the ROI heads for peanut_rcnn_inference
+
     def __init__(self, cfg: RcnnCfg, state_dict, device="cuda:0", precision: str = "fp32", conv_algo: str = "auto"):
-        super().__init__(cfg, state_dict, device=device, precision=precision, conv_algo=conv_algo)
-        self._anchor_cache = {}
         from .rcnn_weights import roi_head_keys
         for key, shape in roi_head_keys(cfg):
             if key not in state_dict or tuple(state_dict[key].shape) != tuple(shape):
                 raise KeyError(f"checkpoint is missing or mis-shapes '{key}'")
+        super().__init__(cfg, state_dict, device=device, precision=precision, conv_algo=conv_algo)
+        self._anchor_cache = {}
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if k.startswith("roi_heads.")}
         P, Fo, K = cfg.box_pooler_resolution, cfg.fpn_out, cfg.num_classes
         # fc1 consumes ROIAlign output flattened NHWC ((y*P+x)*C + c); detectron2 flattens NCHW (c*P*P + y*P + x)
@@ -343,9 +363,54 @@ class MaskRCNN(MaskRCNNFront):
         logits = logits.reshape(n, P, P, 2, 2, Kc).permute(0, 5, 1, 3, 2, 4).reshape(n, Kc, 2 * P, 2 * P)
         return logits[torch.arange(n, device=rois.device), classes].sigmoid()
 
-    def inference(self, img_bgr: torch.Tensor):
+    def inference(self, img_bgr: torch.Tensor, want_masks: bool = True):
         """img_bgr uint8 [B,H,W,3] (device) -> list of dict(pred_boxes [n,4], scores [n], pred_classes [n],
-        pred_masks bool [n,H,W]) at the original resolution (detector_postprocess)."""
+        pred_masks bool [n,H,W]) at the original resolution (detector_postprocess): ONE call of the library's
+        ``peanut_rcnn_inference`` (csrc/rcnn_post.hip) -- proposal selection, box head, detection selection, mask head
+        and pasting all run as HIP kernels behind the C ABI; the only host read is the detection count per image."""
+        assert img_bgr.is_cuda and img_bgr.dtype == torch.uint8 and img_bgr.dim() == 4 and img_bgr.shape[3] == 3
+        img_bgr = img_bgr.contiguous()
+        B, H, W, _ = img_bgr.shape
+        D = self.cfg.detections_per_image
+        dev = img_bgr.device
+        boxes = torch.empty((B * D, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((B * D,), dtype=torch.float32, device=dev)
+        classes = torch.empty((B * D,), dtype=torch.int32, device=dev)
+        masks = torch.empty((B * D, H, W), dtype=torch.uint8, device=dev) if want_masks else None
+        n_det = (C.c_int * B)()
+        with torch.cuda.device(dev):
+            rc = self._lib.peanut_rcnn_inference(self._h, img_bgr.data_ptr(), B, H, W, n_det, boxes.data_ptr(), scores.data_ptr(),
+                                                 classes.data_ptr(), None if masks is None else masks.data_ptr(),
+                                                 _lib.current_stream_ptr(dev))
+        _lib.check(rc, "peanut_rcnn_inference")
+        out, start = [], 0
+        for b in range(B):
+            n = int(n_det[b])
+            sl = slice(start, start + n)
+            out.append(dict(pred_boxes=boxes[sl], scores=scores[sl], pred_classes=classes[sl].long(),
+                            pred_masks=(masks[sl].bool() if masks is not None else None)))
+            start += n
+        return out
+
+    def debug_stage(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        """Copy of a stage buffer of the last ``inference`` call (peanut_rcnn_debug_stage)."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _lib.check(self._lib.peanut_rcnn_debug_stage(self._h, name.encode(), C.byref(ptr), C.byref(nbytes)), "peanut_rcnn_debug_stage")
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        need = out.numel() * out.element_size()
+        if need > nbytes.value:
+            raise ValueError(f"stage {name} holds {nbytes.value} bytes, {need} requested")
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        torch.cuda.synchronize(self.device)
+        rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), ptr, C.c_size_t(need), 3)    # hipMemcpyDeviceToDevice
+        if rc != 0:
+            raise _lib.PeanutHipError(f"hipMemcpy failed ({rc})")
+        return out
+
+    def inference_glue(self, img_bgr: torch.Tensor):
+        """The same pipeline with the selection stages as torch ops around the operator exports (the form the stage
+        tests bisect with); ``inference`` is the product path."""
         cfg = self.cfg
         B, H, W, _ = img_bgr.shape
         nh, nw = self.plan(B, H, W)["resized"]

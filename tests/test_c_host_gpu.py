@@ -54,3 +54,43 @@ def test_cpp_host_reproduces_python_path(tmp_path, precision):
     want = m.get_prediction_batch(x.cuda(), apply_sigmoid=True).cpu().numpy()
     assert np.array_equal(got, want)
     assert 0.0 < got.min() and got.max() < 1.0
+
+
+def test_cpp_detector_host_reproduces_python_path(tmp_path):
+    """The whole Mask R-CNN (peanut_rcnn_create + peanut_rcnn_inference) from a torch-free C++ host: detections, scores,
+    boxes, classes and pasted masks equal the Python path's (same library underneath) bit for bit."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    from peanut_amd.rcnn import MaskRCNN
+    from peanut_amd.rcnn_weights import RcnnCfg, front_keys, make_seeded_rcnn_state_dict, roi_head_keys
+    lib_dir = os.path.join(ROOT, "peanut_amd")
+    exe = str(tmp_path / "rcnn_host")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_abi", "rcnn_host.cpp"), "-L", lib_dir, "-lpeanut_hip",
+                        f"-Wl,-rpath,{lib_dir}", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cfg = RcnnCfg(depth=50, rpn_pre_nms_topk=300, rpn_post_nms_topk=100, detections_per_image=20, score_thresh_test=0.3)
+    sd = make_seeded_rcnn_state_dict(cfg, seed=7)
+    keys = [k for k, _ in list(front_keys(cfg)) + list(roi_head_keys(cfg))]
+    _write_state_dict(tmp_path / "weights.bin", [(k, sd[k].numpy()) for k in keys])
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 192, 256
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    img.numpy().tofile(tmp_path / "image.bin")
+    pre = str(tmp_path / "out")
+    r = subprocess.run([exe, str(tmp_path / "weights.bin"), str(tmp_path / "image.bin"), pre, str(B), str(H), str(W), "50", "300", "100",
+                        "20", "0.3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+    counts = np.fromfile(pre + ".counts.bin", np.int32)
+    want = MaskRCNN(cfg, sd).inference(img.cuda())
+    assert counts.tolist() == [len(w["scores"]) for w in want] and counts.sum() > 0
+    n = int(counts.sum())
+    boxes = np.fromfile(pre + ".boxes.bin", np.float32).reshape(n, 4)
+    scores = np.fromfile(pre + ".scores.bin", np.float32)
+    classes = np.fromfile(pre + ".classes.bin", np.int32)
+    masks = np.fromfile(pre + ".masks.bin", np.uint8).reshape(n, H, W)
+    assert np.array_equal(boxes, torch.cat([w["pred_boxes"] for w in want]).cpu().numpy())
+    assert np.array_equal(scores, torch.cat([w["scores"] for w in want]).cpu().numpy())
+    assert np.array_equal(classes, torch.cat([w["pred_classes"] for w in want]).cpu().numpy().astype(np.int32))
+    assert np.array_equal(masks.astype(bool), torch.cat([w["pred_masks"] for w in want]).cpu().numpy())

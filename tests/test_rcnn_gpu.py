@@ -296,3 +296,38 @@ def test_roi_align_kernel_reproduces_detectron2_known_answers():
         _lib.check(rc, "peanut_roi_align")
         assert torch.allclose(out[0, :, :, 0].cpu(), want, atol=1e-6), aligned
         assert torch.allclose(out[0, :, :, 1].cpu(), torch.ones(4, 4), atol=1e-6)
+
+
+def test_c_entry_matches_the_stagewise_glue(small_net):
+    """``MaskRCNN.inference`` (ONE peanut_rcnn_inference call: radix-select top-k, decode, LDS bitonic sorts, NMS with
+    device-side counts, ordered compaction, softmax / class candidates, mask un-shuffle -- csrc/rcnn_post.hip) against
+    ``inference_glue`` (the same operators driven by torch glue): identical detections; the proposal stage buffers
+    against the oracle's find_top_rpn_proposals on the HIP front end's own outputs."""
+    from oracle import rcnn_ref
+    s = small_net
+    net, cfg = s["net"], s["cfg"]
+    img = s["img"].cuda()
+    a = net.inference(img)
+    b = net.inference_glue(img)
+    assert len(a) == len(b) == img.shape[0]
+    for x, y in zip(a, b):
+        assert len(x["scores"]) == len(y["scores"]) > 0
+        assert x["pred_classes"].tolist() == y["pred_classes"].tolist()
+        assert (x["scores"] - y["scores"]).abs().max().item() <= 1e-6
+        assert (x["pred_boxes"] - y["pred_boxes"]).abs().max().item() <= 1e-3
+        assert (x["pred_masks"] != y["pred_masks"]).float().mean().item() <= 1e-4
+    # proposals: stage buffers of the C path vs the oracle's selection on the same objectness / deltas
+    B = img.shape[0]
+    pyr, obj, dl = net.forward_front(img)
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()    # noqa: E731
+    nh, nw = net.plan(B, img.shape[1], img.shape[2])["resized"]
+    props = rcnn_ref.rpn_proposals([nchw(o) for o in obj], [nchw(d) for d in dl], (nh, nw), cfg)
+    net.inference(img, want_masks=False)
+    cap = cfg.rpn_post_nms_topk
+    rois = net.debug_stage("rois", (B * cap, 5)).cpu()
+    cnt = net.debug_stage("prop_count", (B,), torch.int32).cpu()
+    for n_, (pb, _) in enumerate(props):
+        assert int(cnt[n_]) == len(pb)
+        got = rois[n_ * cap:n_ * cap + len(pb)]
+        assert torch.all(got[:, 0] == n_)
+        assert (got[:, 1:] - pb).abs().max().item() <= 1e-3
