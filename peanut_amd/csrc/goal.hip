@@ -20,8 +20,10 @@
 //     is not monotone in its second neighbour: keeping minima would freeze transients) and none of the feedback that
 //     makes an unrestricted second-order relaxation oscillate (two cells each taking the other for its upwind
 //     neighbour) can occur;
-//   * stage B is repeated with `ord` = its own result until a pass changes nothing (3-5 passes; warm-started, so
-//     later passes only touch the cells whose order moved): the result is then a self-consistent second-order field.
+//   * stage B is repeated with `ord` = its own result, warm-started (later passes only touch the cells whose order
+//     moved).  Iterated until nothing changes (5-6 passes) the result is the self-consistent second-order field, 0.14
+//     cell from the heap-ordered march on maze maps (reached within six passes, the cap),
+//     which bounds the cost: every pass is a front propagation across the map, ~1.5 ms at 960 x 960.
 //
 // Difference to the heap-ordered march: when the two-axis root falls BELOW the value of the later of its two
 // neighbours (possible with second-order terms next to walls), scikit-fmm's march keeps it -- the neighbour was
@@ -46,7 +48,7 @@ namespace {
 constexpr int TILE = 32, HALO = 2, LT = TILE + 2 * HALO;   // 36
 constexpr int MAX_SWEEPS = 96;                             // per round and tile (a front crosses a tile in <= 64)
 constexpr int ROUNDS_PER_CHECK = 8;
-constexpr int MAX_ORDER_PASSES = 8;
+constexpr int MAX_ORDER_PASSES = 6;     // measured distance to the heap-ordered march: 3 passes 0.39 / 0.70 cell (maze / cluttered map), 4 passes 0.14 / 0.47, fixed point (5-6) 0.14 / 0.03
 
 enum : unsigned char { ST_MASKED = 0, ST_FREE = 1, ST_SEED = 2 };
 

@@ -48,12 +48,25 @@ def main():
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--detector", action="store_true", help="run Mask R-CNN on every frame instead of canned masks")
+    ap.add_argument("--no-goal", action="store_true", help="skip the long-term goal selection (round-1 behaviour of this tool)")
     a = ap.parse_args()
     rank, local_rank, world = pdist.init_process_group()
     dev = torch.device("cuda", torch.cuda.current_device())
     from peanut_amd.agent_state import default_args   # nav/arguments.py defaults
-    args = default_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=a.precision)
+    args = default_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=a.precision, select_goal=not a.no_goal)
     st = Agent_State(args, state_dict=make_seeded_state_dict(PredCfg(), 0))
+    goal_ms, goal_n, goal_rounds = [0.0], [0], [0]
+    if not a.no_goal:      # time the goal selection separately (it synchronises anyway: the goal cell goes to the host)
+        inner = st.update_global_goal
+
+        def timed():
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            inner()
+            goal_ms[0] += (time.perf_counter() - t) * 1e3
+            goal_n[0] += 1
+            goal_rounds[0] += st.goal_rounds
+        st.update_global_goal = timed
     mine = episode_shard(a.episodes)
     eps = {e: synth_episode(1000 + e, a.frames, dev) for e in mine}
     det = None
@@ -69,6 +82,7 @@ def main():
         run_episode(st, eps[mine[0]][:12], goal_cat=3, detector=det)     # warm-up (plans, workspaces)
     torch.cuda.synchronize()
     pdist.barrier()
+    goal_ms[0], goal_n[0], goal_rounds[0] = 0.0, 0, 0
     t0 = time.perf_counter()
     n_pred = 0
     for e in mine:
@@ -79,10 +93,13 @@ def main():
     if rank == 0:
         steps = a.episodes * a.frames
         seg = "Mask R-CNN R-101-FPN inference + mask accumulation" if a.detector else "seg-accumulate (canned instance masks)"
+        goal = "" if a.no_goal else " + long-term goal selection (geodesic field on the 960x960 map)"
         print(json.dumps({"workload": f"config 4: {a.episodes} synthetic episodes x {a.frames} frames, {seg} + "
-                                      "obs formatting + map projection per step, 720x720 map prediction every 10 steps",
+                                      f"obs formatting + map projection per step, 720x720 map prediction{goal} every 10 steps",
                           "n_gpus": world, "steps_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-                          "predictions_rank0": n_pred, "precision": a.precision}))
+                          "predictions_rank0": n_pred, "precision": a.precision,
+                          "goal_selection_ms_per_call": round(goal_ms[0] / goal_n[0], 3) if goal_n[0] else None,
+                          "goal_selection_rounds_per_call": round(goal_rounds[0] / goal_n[0], 1) if goal_n[0] else None}))
 
 
 if __name__ == "__main__":

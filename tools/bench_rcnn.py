@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json config 3: Mask R-CNN R-101-FPN (cat9 yaml) inference on 640x480 RGB frames, batch 16, one
 MI355X.  Whole ``SemanticPredMaskRCNN`` device path: preprocess + backbone + FPN + RPN + proposal selection +
-ROI heads + mask paste + per-category accumulation; wall clock around a synchronised loop (the proposal
-stage has data-dependent host syncs, so HIP events alone would under-count).  Seeded random weights: the
+ROI heads + mask paste (ONE peanut_rcnn_inference call) + per-category accumulation; wall clock around a synchronised
+loop (the call reads the detection counts back once).  Seeded random weights: the
 number of detections (hence ROI-head work) is whatever those weights produce -- reported alongside."""
 import json
 import os
@@ -48,7 +48,7 @@ def main():
         print(json.dumps({"workload": f"config 3: Mask R-CNN R-101-FPN full inference + mask accumulation, {B} x 640x480 RGB",
                           "precision": prec, "conv_algo": algo, "ms_per_batch": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1),
                           "front_end_ms": round(front_ms, 2), "proposal_roi_paste_ms": round(ms - front_ms, 2),
-                          "proposals_per_image": round(sum(len(r["proposals"]) for r in res) / B, 1),
+                          "proposals_per_image": round(float(m.debug_stage("prop_count", (B,), torch.int32).float().mean()), 1),
                           "detections_per_image": round(sum(len(r["scores"]) for r in res) / B, 1)}), flush=True)
         del m
 
