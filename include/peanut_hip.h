@@ -171,7 +171,8 @@ int peanut_map_dims(peanut_map_t* h, int dims[4]);
  * fp32: obs [1,C,h,w] (ch 3 = depth in cm, ch 4.. = semantic), pose_obs [3] = (dx, dy, dtheta),
  * maps_last [C,M,M], poses_inout [3] = (x m, y m, theta deg) updated IN PLACE (the reference's
  * returned pose_pred / current_poses both alias poses_last, mapping.py:143-160), fp_map_pred
- * [1,V,V], map_pred [C,M,M] (must not alias maps_last).  Enqueues ~14 launches, no host sync. */
+ * [1,V,V], map_pred [C,M,M] (must not alias maps_last).  Enqueues 7 launches (all own kernels; the points are grouped by voxel without a sort:
+ * count, claim a segment, fill, rank inside the segment), no host sync. */
 int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
                        float* poses_inout, float* fp_map_pred, float* map_pred, void* stream);
 /* hipGraph replay of the step's launches, keyed on the seven pointer/stream arguments (an agent ping-pongs two map

@@ -8,14 +8,18 @@
 //   map_points   depth pixel -> normalised (x,y,z), SAME fp32 operation order as the reference
 //                (+ the five statistics that decide the low-stairs branch, mapping.py:90-97, exactly)
 //   map_keys     mask, splat position, base-cell key of every point
-//   (sort)       stable radix sort of (key, point index)  [rocPRIM via hipcub::DeviceRadixSort]
-//   map_gather   per sorted point: 1-D splat weights + feature values, contiguous
-//   map_heads    first sorted position of every occupied base cell -> dense lookup table
+//   map_alloc / map_fill / map_place   group the points by base cell WITHOUT a sort: every cell gets a contiguous
+//                segment (its size counted by map_keys, its start taken from one atomic cursor by the cell's
+//                first point), the points drop into their cell's segment in arrival order, and every point then
+//                finds its final slot as segment start + (number of points of the segment with a smaller index)
+//                -- the order inside a cell is point order by construction, which is all the replay needs; where a
+//                cell's segment lies is irrelevant.  map_place also writes, per placed point, the 1-D splat
+//                weights + feature values (contiguous); the segment starts are the dense cell lookup table
 //   map_voxels   one thread per (touched voxel, feature): replays the reference's 8 corner passes for
 //                that voxel only -- contributions added IN POINT ORDER, rintf after every pass -- and
 //                adds the (integer-valued, hence order-free) result into the two height projections
-//   map_view     thresholds/clamps -> the 100x100 egocentric window (+ fp_map_pred), clears scratch
-//   map_pose     pose integration + the two affine_grid theta rows
+//   map_finish   thresholds/clamps -> the 100x100 egocentric window (+ fp_map_pred), clears scratch; pose integration
+//                + the two affine_grid theta rows; re-arms the per-cell tables (seven launches per step in all)
 //   map_warp     rotation resample -> translation resample -> max with the previous map, fused
 //
 // Why the voxel trick is exact: splat_feat_nd rounds the WHOLE grid after each corner pass
@@ -28,9 +32,9 @@
 //
 // fp32 contraction is OFF in this file: where the reference's CPU kernels use fused multiply-adds
 // (affine_grid's bmm, grid_sample's blend, lerp) fmaf is written explicitly.
-#include <hipcub/hipcub.hpp>
-
+#include <algorithm>
 #include <memory>
+#include <vector>
 
 #include "../../include/peanut_hip.h"
 #include "common.h"
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict
 // ---- 3. splat position + base-cell key (depth_utils.py:217-236) ----
 __global__ __launch_bounds__(256) void map_keys_kernel(const float* __restrict__ obs, const float* __restrict__ coords,
                                                        const StairStats* __restrict__ stats, float* __restrict__ pos,
-                                                       unsigned* __restrict__ keys, unsigned* __restrict__ idx, MapP P) {
+                                                       unsigned* __restrict__ keys, int* __restrict__ cell_cnt,
+                                                       int* __restrict__ cell_first, MapP P) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.N) return;
   float xs = coords[p], ys = coords[P.N + p], zs = coords[2 * P.N + p];
@@ -156,33 +161,53 @@ __global__ __launch_bounds__(256) void map_keys_kernel(const float* __restrict__
       fz <= (float)(P.zb - 1))
     key = ((unsigned)fx * (unsigned)P.vr + (unsigned)fy) * (unsigned)P.zb + (unsigned)fz;
   keys[p] = key;
-  idx[p] = (unsigned)p;
+  if (key != INVALID_KEY) {
+    atomicAdd(&cell_cnt[key], 1);        // points of the cell (order-free)
+    atomicMin(&cell_first[key], p);      // its first point: the one that will claim the segment
+  }
 }
 
-// ---- 4. group heads ----
-__global__ __launch_bounds__(256) void map_heads_kernel(const unsigned* __restrict__ skey, int* __restrict__ cell_head,
-                                                        int N, int set) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const unsigned k = skey[i];
-  if (k != INVALID_KEY && (i == 0 || skey[i - 1] != k)) cell_head[k] = set ? i : -1;
+// ---- 3b. grouping by base cell, point order inside a cell (what a stable sort by cell would give) ----
+// The voxel replay needs every cell's points contiguous and in point order (CPU scatter_add_ adds them in that order,
+// and fp32 sums depend on it).  A sort would also order the CELLS, which nobody needs; so: count, claim, fill, rank.
+__global__ __launch_bounds__(256) void map_alloc_kernel(const unsigned* __restrict__ keys, const int* __restrict__ cell_cnt,
+                                                        const int* __restrict__ cell_first, int* __restrict__ cell_head,
+                                                        int* __restrict__ cursor, int N) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const unsigned k = keys[p];
+  if (k != INVALID_KEY && cell_first[k] == p) cell_head[k] = atomicAdd(cursor, cell_cnt[k]);
 }
 
-// ---- 4b. per sorted point: the two 1-D weights per dimension and the feature values, in sorted order,
-// so that the voxel replay below reads contiguous memory instead of chasing sidx ----
-__global__ __launch_bounds__(256) void map_gather_kernel(const float* __restrict__ obs, const float* __restrict__ pos,
-                                                         const unsigned* __restrict__ skey,
-                                                         const unsigned* __restrict__ sidx, float* __restrict__ wts6,
-                                                         float* __restrict__ feat_s, MapP P) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= P.N) return;
-  const unsigned k = skey[j];
+__global__ __launch_bounds__(256) void map_fill_kernel(const unsigned* __restrict__ keys, const int* __restrict__ cell_head,
+                                                       int* __restrict__ cell_fill, unsigned* __restrict__ seg, int N) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const unsigned k = keys[p];
+  if (k != INVALID_KEY) seg[cell_head[k] + atomicAdd(&cell_fill[k], 1)] = (unsigned)p;    // arrival order
+}
+
+__global__ __launch_bounds__(256) void map_place_kernel(const unsigned* __restrict__ keys, const int* __restrict__ cell_head,
+                                                        const int* __restrict__ cell_cnt, const unsigned* __restrict__ seg,
+                                                        const int* __restrict__ cursor, const float* __restrict__ obs,
+                                                        const float* __restrict__ pos, unsigned* __restrict__ skey,
+                                                        unsigned* __restrict__ sidx, float* __restrict__ wts6,
+                                                        float* __restrict__ feat_s, MapP P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.N) return;
+  if (p >= *cursor) skey[p] = INVALID_KEY;           // the tail behind the last segment holds no point
+  const unsigned k = keys[p];
   if (k == INVALID_KEY) return;
-  const int q = (int)sidx[j];
+  const int s0 = cell_head[k], m = cell_cnt[k];
+  int rank = 0;
+  for (int i = 0; i < m; ++i) rank += seg[s0 + i] < (unsigned)p;     // points of my cell that precede me
+  const int j = s0 + rank;
+  skey[j] = k;
+  sidx[j] = (unsigned)p;
   const float g2 = (float)(k % (unsigned)P.zb);
   const float g1 = (float)((k / (unsigned)P.zb) % (unsigned)P.vr);
   const float g0 = (float)(k / ((unsigned)P.zb * (unsigned)P.vr));
-  const float p0 = pos[q], p1 = pos[P.N + q], p2 = pos[2 * P.N + q];
+  const float p0 = pos[p], p1 = pos[P.N + p], p2 = pos[2 * P.N + p];
   // wts_ix = 1 - |pos - (floor + ix)|  (depth_utils.py:229)
   wts6[0 * P.N + j] = 1.0f - fabsf(p0 - g0);
   wts6[1 * P.N + j] = 1.0f - fabsf(p0 - (g0 + 1.0f));
@@ -190,7 +215,18 @@ __global__ __launch_bounds__(256) void map_gather_kernel(const float* __restrict
   wts6[3 * P.N + j] = 1.0f - fabsf(p1 - (g1 + 1.0f));
   wts6[4 * P.N + j] = 1.0f - fabsf(p2 - g2);
   wts6[5 * P.N + j] = 1.0f - fabsf(p2 - (g2 + 1.0f));
-  for (int f = 1; f < P.F; ++f) feat_s[(f - 1) * P.N + j] = obs[(3 + f) * P.N + q];
+  for (int f = 1; f < P.F; ++f) feat_s[(f - 1) * P.N + j] = obs[(3 + f) * P.N + p];
+}
+
+// ---- 4. re-arm the per-cell tables for the next frame (only the touched entries) ----
+__device__ __forceinline__ void map_rearm(int p, const unsigned* __restrict__ keys, int* __restrict__ cell_head,
+                                          int* __restrict__ cell_cnt, int* __restrict__ cell_first, int* __restrict__ cell_fill,
+                                          int* __restrict__ cursor, int N) {
+  if (p == 0) *cursor = 0;
+  if (p >= N) return;
+  const unsigned k = keys[p];
+  if (k == INVALID_KEY) return;
+  cell_head[k] = -1; cell_cnt[k] = 0; cell_first[k] = 0x7fffffff; cell_fill[k] = 0;
 }
 
 // ---- 5. per-voxel replay of the 8 corner passes ----
@@ -246,10 +282,8 @@ __global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict
 }
 
 // ---- 6. thresholds -> egocentric window, fp_map_pred; clears the projections for the next frame ----
-__global__ __launch_bounds__(256) void map_view_kernel(float* __restrict__ proj, float* __restrict__ view,
-                                                       float* __restrict__ fp_map_pred, StairStats* __restrict__ stats,
-                                                       MapP P) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void map_view(int t, float* __restrict__ proj, float* __restrict__ view,
+                                         float* __restrict__ fp_map_pred, StairStats* __restrict__ stats, const MapP& P) {
   if (t == 0) { stats->n = 0; stats->mid = 0; stats->le = 0; stats->max_le = 0u; stats->min_gt = 0xffffffffu; }
   const int cells = P.vr * P.vr;
   if (t >= cells) return;
@@ -273,9 +307,8 @@ __global__ __launch_bounds__(256) void map_view_kernel(float* __restrict__ proj,
 // ---- 7. pose integration (mapping.py:143-167) + affine thetas (model.py:19-38) ----
 struct WarpT { float c, s, tx, ty; };
 
-__global__ void map_pose_kernel(const float* __restrict__ rel, float* __restrict__ pose, WarpT* __restrict__ wt,
-                                MapP P) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void map_pose(const float* __restrict__ rel, float* __restrict__ pose, WarpT* __restrict__ wt,
+                                         const MapP& P) {
   const float k = 57.29577951308232f;
   float p0 = pose[0], p1 = pose[1], p2 = pose[2];
   const float r0 = rel[0], r1 = rel[1], r2 = rel[2];
@@ -294,6 +327,19 @@ __global__ void map_pose_kernel(const float* __restrict__ rel, float* __restrict
   wt->s = sinf(tr);
   wt->tx = sx;
   wt->ty = sy;
+}
+
+// ---- 6+7+4 in one launch: egocentric view, pose integration, re-arming of the per-cell tables ----
+__global__ __launch_bounds__(256) void map_finish_kernel(float* __restrict__ proj, float* __restrict__ view,
+                                                         float* __restrict__ fp_map_pred, StairStats* __restrict__ stats,
+                                                         const float* __restrict__ rel, float* __restrict__ pose, WarpT* __restrict__ wt,
+                                                         const unsigned* __restrict__ keys, int* __restrict__ cell_head,
+                                                         int* __restrict__ cell_cnt, int* __restrict__ cell_first,
+                                                         int* __restrict__ cell_fill, int* __restrict__ cursor, MapP P) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) map_pose(rel, pose, wt, P);
+  map_view(t, proj, view, fp_map_pred, stats, P);
+  map_rearm(t, keys, cell_head, cell_cnt, cell_first, cell_fill, cursor, P.N);
 }
 
 // F.affine_grid base coordinate (align_corners=False): linspace(-1,1,n)[i] * (n-1) / n with ATen's
@@ -399,22 +445,22 @@ struct peanut_map {
   MapP P{};
   float* coords = nullptr;   // [3][N]
   float* pos = nullptr;      // [3][N]
-  unsigned *keys = nullptr, *idx = nullptr, *skeys = nullptr, *sidx = nullptr;
-  int* cell_head = nullptr;  // [vr*vr*zb], -1 = empty
+  unsigned *keys = nullptr, *seg = nullptr, *skeys = nullptr, *sidx = nullptr;
+  int* cell_head = nullptr;  // [vr*vr*zb], -1 = empty: start of the cell's segment
+  int *cell_cnt = nullptr, *cell_first = nullptr, *cell_fill = nullptr, *cursor = nullptr;
   StairStats* stats = nullptr;
   float* wts6 = nullptr;     // [6][N]
   float* feat_s = nullptr;   // [ncat][N]
   float* proj = nullptr;     // [2][F][vr][vr]
   float* view = nullptr;     // [C][vr][vr]
   WarpT* wt = nullptr;
-  void* sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
-  bool use_graph = false;    // peanut_map_use_graph: the ten launches of a step replayed as one hipGraph
+  bool use_graph = false;    // peanut_map_use_graph: the launches of a step replayed as one hipGraph
   GraphCache graphs;
   ~peanut_map() {
     graphs.clear();
-    for (void* p : {(void*)coords, (void*)pos, (void*)keys, (void*)idx, (void*)skeys, (void*)sidx, (void*)cell_head,
-                    (void*)stats, (void*)wts6, (void*)feat_s, (void*)proj, (void*)view, (void*)wt, sort_tmp})
+    for (void* p : {(void*)coords, (void*)pos, (void*)keys, (void*)seg, (void*)skeys, (void*)sidx, (void*)cell_head,
+                    (void*)cell_cnt, (void*)cell_first, (void*)cell_fill, (void*)cursor,
+                    (void*)stats, (void*)wts6, (void*)feat_s, (void*)proj, (void*)view, (void*)wt})
       if (p) (void)hipFree(p);
   }
 };
@@ -464,11 +510,22 @@ int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
   PEANUT_HIP_CHECK(hipMalloc(&h->coords, 3 * N * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->pos, 3 * N * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->keys, N * sizeof(unsigned)));
-  PEANUT_HIP_CHECK(hipMalloc(&h->idx, N * sizeof(unsigned)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->seg, N * sizeof(unsigned)));
   PEANUT_HIP_CHECK(hipMalloc(&h->skeys, N * sizeof(unsigned)));
   PEANUT_HIP_CHECK(hipMalloc(&h->sidx, N * sizeof(unsigned)));
   PEANUT_HIP_CHECK(hipMalloc(&h->cell_head, cells * P.zb * sizeof(int)));
   PEANUT_HIP_CHECK(hipMemset(h->cell_head, 0xff, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->cell_cnt, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMemset(h->cell_cnt, 0, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->cell_fill, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMemset(h->cell_fill, 0, cells * P.zb * sizeof(int)));
+  PEANUT_HIP_CHECK(hipMalloc(&h->cell_first, cells * P.zb * sizeof(int)));
+  {
+    std::vector<int> big(cells * P.zb, 0x7fffffff);
+    PEANUT_HIP_CHECK(hipMemcpy(h->cell_first, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  PEANUT_HIP_CHECK(hipMalloc(&h->cursor, sizeof(int)));
+  PEANUT_HIP_CHECK(hipMemset(h->cursor, 0, sizeof(int)));
   PEANUT_HIP_CHECK(hipMalloc(&h->stats, sizeof(StairStats)));
   {
     const StairStats init = {0u, 0u, 0u, 0u, 0xffffffffu};   // map_view re-arms it after every frame
@@ -480,9 +537,6 @@ int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
   PEANUT_HIP_CHECK(hipMemset(h->proj, 0, 2 * P.F * cells * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->view, P.C * cells * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->wt, sizeof(WarpT)));
-  PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, h->sort_tmp_bytes, h->keys, h->skeys, h->idx, h->sidx,
-                                                      (int)N, 0, 21, (hipStream_t)0));
-  PEANUT_HIP_CHECK(hipMalloc(&h->sort_tmp, h->sort_tmp_bytes ? h->sort_tmp_bytes : 16));
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = h.release();
   return 0;
@@ -506,18 +560,18 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
     const MapP& P = h->P;
     const int nb = (P.N + 255) / 256;
     hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, P);
-    hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, h->pos, h->keys, h->idx, P);
-    size_t tmp = h->sort_tmp_bytes;
-    PEANUT_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tmp, h->keys, h->skeys, h->idx, h->sidx, P.N, 0, 21, s));
-    hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 1);
+    hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, h->pos, h->keys, h->cell_cnt,
+                       h->cell_first, P);
+    hipLaunchKernelGGL(map_alloc_kernel, dim3(nb), dim3(256), 0, s, h->keys, h->cell_cnt, h->cell_first, h->cell_head, h->cursor, P.N);
+    hipLaunchKernelGGL(map_fill_kernel, dim3(nb), dim3(256), 0, s, h->keys, h->cell_head, h->cell_fill, h->seg, P.N);
+    hipLaunchKernelGGL(map_place_kernel, dim3(nb), dim3(256), 0, s, h->keys, h->cell_head, h->cell_cnt, h->seg, h->cursor, obs, h->pos,
+                       h->skeys, h->sidx, h->wts6, h->feat_s, P);
     const long long vt = (long long)P.N * 8 * P.F;
-    hipLaunchKernelGGL(map_gather_kernel, dim3(nb), dim3(256), 0, s, obs, h->pos, h->skeys, h->sidx, h->wts6, h->feat_s, P);
     hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, h->wts6, h->feat_s, h->skeys,
                        h->cell_head, h->proj, P);
-    hipLaunchKernelGGL(map_heads_kernel, dim3(nb), dim3(256), 0, s, h->skeys, h->cell_head, P.N, 0);
-    hipLaunchKernelGGL(map_view_kernel, dim3((P.vr * P.vr + 255) / 256), dim3(256), 0, s, h->proj, h->view, fp_map_pred,
-                       h->stats, P);
-    hipLaunchKernelGGL(map_pose_kernel, dim3(1), dim3(64), 0, s, pose_obs, poses_inout, h->wt, P);
+    const int nfin = (std::max(P.vr * P.vr, P.N) + 255) / 256;
+    hipLaunchKernelGGL(map_finish_kernel, dim3(nfin), dim3(256), 0, s, h->proj, h->view, fp_map_pred, h->stats, pose_obs, poses_inout,
+                       h->wt, h->keys, h->cell_head, h->cell_cnt, h->cell_first, h->cell_fill, h->cursor, P);
     hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
                        h->wt, P);
     hipError_t e = hipGetLastError();
