@@ -103,3 +103,25 @@ def test_box_transform_nms_and_paste_definitions():
     want = torch.zeros((10, 12), dtype=torch.bool)
     want[2:7, 3:9] = True
     assert torch.equal(m, want)
+
+
+def test_nms_iou_matches_published_known_answers():
+    """The IoU behind rcnn_ref.nms_sorted against detectron2's tests/structures/test_boxes.py::TestBoxIOU::
+    test_pairwise_iou (unit box vs six boxes: 1, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)), probed through the
+    suppression decision on either side of each value; and torchvision's test/test_ops.py::TestNMS::test_nms_float16
+    boxes (three near-duplicates, scores 0.6370 / 0.7569 / 0.3966, threshold 0.2: only the top-scoring box survives)."""
+    unit = [0.0, 0.0, 1.0, 1.0]
+    others = [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 1.0], [0.0, 0.0, 1.0, 0.5], [0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 1.0, 1.0],
+              [0.5, 0.5, 1.5, 1.5]]
+    expected = [1.0, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)]
+    for box, iou in zip(others, expected):
+        pair = torch.tensor([unit, box])
+        cats = torch.zeros(2, dtype=torch.int64)
+        assert rcnn_ref.nms_sorted(pair, cats, iou - 1e-4).tolist() == [True, False], (box, iou)     # IoU > thr: suppressed
+        assert rcnn_ref.nms_sorted(pair, cats, iou + 1e-4).tolist() == [True, True], (box, iou)      # IoU <= thr: kept
+        assert rcnn_ref.nms_sorted(pair, torch.tensor([0, 1]), 0.0).tolist() == [True, True]         # other category: never
+    boxes = torch.tensor([[285.3538, 185.5758, 1193.5110, 851.4551], [285.1472, 188.7374, 1192.4984, 851.0669],
+                          [279.2440, 197.9812, 1189.4746, 849.2019]])
+    scores = torch.tensor([0.6370, 0.7569, 0.3966])
+    keep = rcnn_ref.batched_nms(boxes, scores, torch.zeros(3, dtype=torch.int64), 0.2)
+    assert keep.tolist() == [1]
