@@ -9,6 +9,8 @@
 //   models/decode_heads/psp_head.py:109       torch.cat(psp_outs, dim=1)
 //   models/segmentors/encoder_decoder.py:75-79 resize(out, size=img.shape[2:], bilinear)
 //   nav/agent/prediction.py:158               scipy.special.expit (optional fused sigmoid)
+#include <algorithm>
+
 #include "common.h"
 
 namespace peanut {
@@ -24,30 +26,35 @@ static inline unsigned grid_for(long long work_items, int block = 256) {
 // ---- NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] with zero channel padding ----
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int C, long long HW, long long npix, int Cpad) {
-  // one thread per (pixel, 4-channel group): reads are coalesced per channel plane across the
-  // 64/ (Cpad/4) pixels of a wave, writes are contiguous 16-byte pieces of the NHWC rows.
-  const int groups = Cpad >> 2;
-  const long long total = npix * groups;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / groups;
-    const int g = (int)(i - pix * groups);
-    const long long b = pix / HW, hw = pix - b * HW;
-    const float* src = x + (b * C) * HW + hw;
-    float4 v;
-    const int c0 = g * 4;
-    v.x = c0 + 0 < C ? src[(long long)(c0 + 0) * HW] : 0.f;
-    v.y = c0 + 1 < C ? src[(long long)(c0 + 1) * HW] : 0.f;
-    v.z = c0 + 2 < C ? src[(long long)(c0 + 2) * HW] : 0.f;
-    v.w = c0 + 3 < C ? src[(long long)(c0 + 3) * HW] : 0.f;
-    *reinterpret_cast<float4*>(y + pix * Cpad + c0) = v;
+  // a workgroup transposes 256 consecutive pixels x 16 channels through LDS: every channel-plane read is a fully
+  // coalesced 256-byte run per wave, every NHWC store a fully contiguous 1 KiB run per wave.  (Measured alternatives,
+  // profiles/r2h: one lane per pixel with strided 16-byte stores 0.235 ms, four pixels per lane with 16-byte plane
+  // loads and 256-byte-strided stores 0.45 ms; this form 0.186 ms.)
+  __shared__ float t[256][17];
+  const long long p0 = (long long)blockIdx.x * 256;
+  for (int c0 = 0; c0 < Cpad; c0 += 16) {
+    const long long pix = p0 + threadIdx.x;
+    if (pix < npix) {
+      const long long b = pix / HW, hw = pix - b * HW;
+      const float* src = x + (b * C) * HW + hw;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t[threadIdx.x][j] = (c0 + j < C) ? src[(long long)(c0 + j) * HW] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = k * 256 + threadIdx.x;          // float4 index inside the 256 x 16 tile
+      const int px = q >> 2, c4 = (q & 3) * 4;
+      if (p0 + px < npix && c0 + c4 < Cpad)
+        *reinterpret_cast<float4*>(y + (p0 + px) * Cpad + c0 + c4) = make_float4(t[px][c4], t[px][c4 + 1], t[px][c4 + 2], t[px][c4 + 3]);
+    }
+    __syncthreads();
   }
 }
 
 int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s) {
   const long long HW = (long long)H * W, npix = HW * B;
-  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(npix * (Cpad / 4))), dim3(256), 0, s, x, y, C, HW, npix,
-                     Cpad);
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, y, C, HW, npix, Cpad);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(-3, std::string("nchw_to_nhwc: ") + hipGetErrorString(e));
 }
@@ -144,8 +151,13 @@ int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, cons
 #define PPM_MAX_SLOTS 16
 struct PpmSlots { short x0[PPM_MAX_SLOTS], x1[PPM_MAX_SLOTS]; int n; };
 
+// Row pass.  The bins of all scales cut a row into at most 2 * PPM_MAX_SLOTS segments (the union of their edges);
+// a segment lies inside at most one bin-column per scale.  Per segment: a branch-free run of 16-byte loads summed in
+// registers, then ONE round of (wave-uniform) slot tests -- per pixel the loop is a load and four adds.
+struct PpmSegs { short x0[2 * PPM_MAX_SLOTS], x1[2 * PPM_MAX_SLOTS]; unsigned mask[2 * PPM_MAX_SLOTS]; int n; };
+
 __global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict__ x, float* __restrict__ rowsum, int H,
-                                                         int W, int C, PpmSlots sl) {
+                                                         int W, int C, PpmSlots sl, PpmSegs sg) {
   const int y = blockIdx.x, b = blockIdx.y;
   const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
   if (c >= C) return;
@@ -153,32 +165,30 @@ __global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict
 #pragma unroll
   for (int s = 0; s < PPM_MAX_SLOTS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* row = x + (((size_t)b * H + y) * W) * C + c;
-  // six pixels per step: six independent 16-byte loads in flight per lane (the row walk is latency-bound
-  // otherwise); the bin tests are wave-uniform (kernel arguments vs the loop counter)
-  constexpr int U = 6;
-  int xx = 0;
-  for (; xx + U <= W; xx += U) {
-    float4 v[U];
+  for (int g = 0; g < sg.n; ++g) {
+    const int x0 = sg.x0[g], x1 = sg.x1[g];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a;
+    int xx = x0;
+    constexpr int U = 10;      // ten independent 16-byte loads in flight per lane
+    for (; xx + U <= x1; xx += U) {
+      float4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(row + (size_t)(xx + u) * C);
+      for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(row + (size_t)(xx + u) * C);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int s = 0; s < PPM_MAX_SLOTS; ++s) {
-        if (s < sl.n && xx + u >= sl.x0[s] && xx + u < sl.x1[s]) {
-          acc[s].x += v[u].x; acc[s].y += v[u].y; acc[s].z += v[u].z; acc[s].w += v[u].w;
-        }
+      for (int u = 0; u < U; u += 2) {
+        a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+        a2.x += v[u + 1].x; a2.y += v[u + 1].y; a2.z += v[u + 1].z; a2.w += v[u + 1].w;
       }
     }
-  }
-  for (; xx < W; ++xx) {
-    const float4 v = *reinterpret_cast<const float4*>(row + (size_t)xx * C);
-#pragma unroll
-    for (int s = 0; s < PPM_MAX_SLOTS; ++s) {
-      if (s < sl.n && xx >= sl.x0[s] && xx < sl.x1[s]) {
-        acc[s].x += v.x; acc[s].y += v.y; acc[s].z += v.z; acc[s].w += v.w;
-      }
+    for (; xx < x1; ++xx) {
+      const float4 v = *reinterpret_cast<const float4*>(row + (size_t)xx * C);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+    const unsigned m = sg.mask[g];
+#pragma unroll
+    for (int s = 0; s < PPM_MAX_SLOTS; ++s)
+      if ((m >> s) & 1u) { acc[s].x += a.x; acc[s].y += a.y; acc[s].z += a.z; acc[s].w += a.w; }
   }
   float* out = rowsum + (((size_t)b * H + y) * sl.n) * C + c;
 #pragma unroll
@@ -240,8 +250,27 @@ int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, i
     }
   }
   if (!scratch) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+  // segments between consecutive bin edges, each with the set of bin-columns (slots) that contain it
+  PpmSegs sg;
+  sg.n = 0;
+  {
+    short edges[4 * PPM_MAX_SLOTS];
+    int ne = 0;
+    for (int i = 0; i < sl.n; ++i) { edges[ne++] = sl.x0[i]; edges[ne++] = sl.x1[i]; }
+    std::sort(edges, edges + ne);
+    ne = (int)(std::unique(edges, edges + ne) - edges);
+    for (int i = 0; i + 1 < ne; ++i) {
+      unsigned m = 0;
+      for (int q = 0; q < sl.n; ++q)
+        if (edges[i] >= sl.x0[q] && edges[i + 1] <= sl.x1[q]) m |= 1u << q;
+      if (!m) continue;
+      if (sg.n >= 2 * PPM_MAX_SLOTS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+      sg.x0[sg.n] = edges[i]; sg.x1[sg.n] = edges[i + 1]; sg.mask[sg.n] = m;
+      ++sg.n;
+    }
+  }
   const int slabs = (C / 4 + 255) / 256;
-  hipLaunchKernelGGL(ppm_rowsum_kernel, dim3(H, B, slabs), dim3(256), 0, s, x, scratch, H, W, C, sl);
+  hipLaunchKernelGGL(ppm_rowsum_kernel, dim3(H, B, slabs), dim3(256), 0, s, x, scratch, H, W, C, sl, sg);
   hipLaunchKernelGGL(ppm_binsum_kernel, dim3(nbins, B, slabs), dim3(256), 0, s, scratch, out, H, W, C, sc, sl.n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(-3, std::string("ppm_pool2: ") + hipGetErrorString(e));
