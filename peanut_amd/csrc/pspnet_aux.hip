@@ -462,7 +462,10 @@ __global__ __launch_bounds__(256) void ppm_conv_term_lds_kernel(const float* __r
   float* srow = reinterpret_cast<float*>(taps + (size_t)sc.n * 2 * L);       // [slots][3][CH], slots = sum_s k_s
   int slots = 0;
   for (int s = 0; s < sc.n; ++s) slots += sc.s[s];
-  for (int yy = 0; yy < H; ++yy) {
+  // rows are split over gridDim.z workgroups (small batches: (C/32) x B workgroups alone would leave the chip idle)
+  const int rows_per = (H + gridDim.z - 1) / gridDim.z;
+  const int y_begin = blockIdx.z * rows_per, y_end = min(H, y_begin + rows_per);
+  for (int yy = y_begin; yy < y_end; ++yy) {
     for (int i = threadIdx.x; i < slots * 3 * (CH / 4); i += blockDim.x) {
       const int g = i % (CH / 4), r = i / (CH / 4), dx = r % 3, slot = r / 3;
       int s = 0, gx = slot, base = 0;
@@ -528,7 +531,9 @@ int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, c
         if (e != hipSuccess) return fail(-3, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         raised = true;
       }
-      hipLaunchKernelGGL(ppm_conv_term_lds_kernel, dim3(C / 32, B), dim3(256), lds, s, Q, R, H, W, C, sc, B, nbins,
+      int row_splits = (512 + (C / 32) * B - 1) / ((C / 32) * B);      // aim at >= 512 workgroups
+      row_splits = std::max(1, std::min(row_splits, H / 4 > 0 ? H / 4 : 1));
+      hipLaunchKernelGGL(ppm_conv_term_lds_kernel, dim3(C / 32, B, row_splits), dim3(256), lds, s, Q, R, H, W, C, sc, B, nbins,
                          align_corners);
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : fail(-3, std::string("ppm_conv_term_lds: ") + hipGetErrorString(e));
