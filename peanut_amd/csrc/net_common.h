@@ -106,6 +106,8 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   ConvDesc& d = L.d;
   d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
   conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
+  // the S-format GEMMs (emulated-fp32 modes) run 256 x 256 tiles built from 128-row packed weight tiles
+  if (s_planes_of(precision) && kh == 1 && kw == 1 && pad == 0 && cout >= 128) d.bn_tile = 128;
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
   const bool split_mode = precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3;
   if (split_mode && cin_pad % 32 == 0) d.bk = 32;            // split kernels are BK = 32 only
@@ -151,6 +153,7 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   ConvDesc& g = L.wino;
   g.cin = cin_pad; g.cout = cout; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
   conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
+  if (s_planes_of(precision) && cout >= 128) g.bn_tile = 128;   // see upload_conv
   g.bk = 32;
   g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
   g.mode = (precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3) ? precision : 0;
