@@ -50,11 +50,17 @@ struct Op {
   int wino_gran = 128;         // row padding of the Winograd position GEMMs
   SAct in_s, out_s;            // S-format (pre-split bf16 pieces, gemm_sx.hip) copies of the input / output, if any
   bool skip_f32 = false;       // the fp32 output is not written (only out_s is consumed)
+  // two-stream schedule of the PSP head (build_plan): branch 1 ops run on the handle's side stream; the first of them
+  // waits for everything enqueued so far on the caller's stream (fork), join_before makes the caller's stream wait for
+  // the side stream before this op
+  int branch = 0;
+  bool fork_before = false, join_before = false;
 };
 
 struct Plan {
   int B = 0, H = 0, W = 0;
   Act splitk;   // scratch for tail split-K partial tiles, alive for the whole forward
+  Act splitk2;  // the same for convs on the side stream (valid when the plan has branch 1 ops)
   bool keep_all = false;
   size_t bytes = 0;
   std::vector<Op> ops;
@@ -98,9 +104,15 @@ struct peanut_pred {
   Plan* probe_plan = nullptr;
   std::vector<std::vector<hipEvent_t>> probe_events;  // one vector (n_ops + 1 events) per forward
   std::vector<hipEvent_t> event_pool;
+  // side stream of the two-stream PSP-head schedule (created on first use) and its fork / join events
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   ~peanut_pred() {
     for (auto& v : probe_events) for (auto e : v) (void)hipEventDestroy(e);
     for (auto e : event_pool) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
   }
 };
 
@@ -292,7 +304,23 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     pl->named["layer" + std::to_string(li + 1)] = x;
   }
   if (xs.valid) { ar.release(xs.off, xs.bytes); xs = SAct(); }
-  // PSP head
+  // PSP head.  In the folded form the pyramid branch (pooling, the per-scale 1x1 convs, the Q tables and the 9-tap
+  // term R: small, latency- or HBM-bound kernels) only meets the 3x3 bottleneck conv over x at that conv's residual
+  // input, so it runs on a side stream underneath the bottleneck's Winograd input transform and GEMM.  Its buffers
+  // then stay allocated until the bottleneck is planned (nothing of the main branch may reuse them) and its convs
+  // get their own split-K scratch.  Measured (profiles/r2m): +0.6 % at batch 32, +0.8 % on one 720 x 720 map, -3 % on
+  // one 240 x 240 map (the GEMM is then shorter than the branch and the two event waits cost more than they hide), so
+  // the branch only forks when the GEMM has >= 4096 rows.  PEANUT_PPM_OVERLAP=0 / 1 forces it off / on.
+  static const int overlap_env = [] { const char* e = getenv("PEANUT_PPM_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool overlap = h->bottleneck_x != nullptr && (overlap_env >= 0 ? overlap_env == 1 : (long long)B * x.H * x.W >= 4096);
+  const size_t side_first = pl->ops.size();
+  if (overlap) {
+    pl->splitk2.bytes = kSplitKScratchFloats * sizeof(float);
+    pl->splitk2.off = ar.alloc(pl->splitk2.bytes);
+    pl->splitk2.B = pl->splitk2.H = pl->splitk2.W = 1; pl->splitk2.C = 0;
+  }
+  std::vector<Act> side_bufs;   // released after the bottleneck when the branch overlaps it
+  auto rel_side = [&](const Act& t) { if (overlap) side_bufs.push_back(t); else rel(t); };
   int nbins = 0;
   for (int i = 0; i < h->cfg.n_pool_scales; ++i) nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
   Act pooled = make_act(ar, B, 1, nbins, x.C);
@@ -303,7 +331,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       Act scr; scr.B = 1; scr.H = 1; scr.W = 1; scr.C = 0; scr.bytes = sf * sizeof(float); scr.off = ar.alloc(scr.bytes);
       op.in2 = scr; op.has_in2 = true;
       pl->ops.push_back(op);
-      rel(scr);
+      rel_side(scr);
     } else {
       pl->ops.push_back(op);
     }
@@ -325,7 +353,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     }
   }
   pl->named["ppm_table"] = table;
-  rel(pooled);
+  rel_side(pooled);
   Act bt;
   if (h->bottleneck_x) {
     // folded pyramid half (pspnet_aux.hip: ppm_conv_term_kernel): Q_s = table_s x W_s, then the 9-tap
@@ -343,12 +371,20 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       push_conv(*pl, h->ppm_q[i], in, nullptr, nullptr, out);
       row0 += (size_t)B * k * k;
     }
-    rel(table);
+    rel_side(table);
     Act r = make_act(ar, B, x.H, x.W, hc);
     { Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; pl->ops.push_back(op); }
-    rel(q);
+    rel_side(q);
+    const size_t side_end = pl->ops.size();
     bt = make_act(ar, B, x.H, x.W, h->bottleneck_x->d.cout);
     push_conv(*pl, h->bottleneck_x, x, nullptr, &r, bt, &ar);
+    if (overlap) {
+      for (size_t i = side_first; i < side_end; ++i) pl->ops[i].branch = 1;
+      pl->ops[side_first].fork_before = true;
+      for (size_t i = side_end; i < pl->ops.size(); ++i)
+        if (pl->ops[i].has_res) { pl->ops[i].join_before = true; break; }   // the one consumer of R
+      for (const auto& t : side_bufs) rel(t);
+    }
     rel(r);
   } else {
     Act up = make_act(ar, B, x.H, x.W, h->cfg.n_pool_scales * h->cfg.head_channels);
@@ -384,6 +420,7 @@ static size_t plan_high_water(const Plan& pl) {
   }
   for (const auto& kv : pl.named) upd(kv.second);
   upd(pl.splitk);
+  upd(pl.splitk2);
   return hw;
 }
 
@@ -415,7 +452,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       a.B = op.in.B; a.H = op.in.H; a.W = op.in.W;
       a.c1 = op.in.C; a.c2 = op.has_in2 ? op.in2.C : 0;
       a.Ho = op.out.H; a.Wo = op.out.W;
-      a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
+      a.ws = P(op.branch ? pl.splitk2 : pl.splitk); a.ws_floats = kSplitKScratchFloats;
       if (op.in_s.valid) { a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad; }
       if (op.out_s.valid) { a.ys = (unsigned short*)(base + op.out_s.off); a.ys_rows = op.out_s.rows_pad; }
       a.skip_f32 = op.skip_f32;
@@ -429,7 +466,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       ConvArgs a{};
       a.x = P(op.in); a.y = P(op.out);
       a.B = 1; a.H = 1; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = 1; a.Wo = op.in.W;
-      a.ws = P(pl.splitk); a.ws_floats = kSplitKScratchFloats;
+      a.ws = P(op.branch ? pl.splitk2 : pl.splitk); a.ws_floats = kSplitKScratchFloats;
       a.mt_per_group = op.wino_mt_per_group;
       if (op.in_s.valid) {
         a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad;
@@ -622,9 +659,25 @@ int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, i
   h->last_plan = pl;
   hipStream_t s = (hipStream_t)stream;
   if (!h->probe) {
+    bool two_streams = false;
+    for (const auto& op : pl->ops) two_streams |= op.branch != 0;
+    if (two_streams && !h->side) {
+      PEANUT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      PEANUT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      PEANUT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     auto enqueue = [&]() -> int {
-      for (const auto& op : pl->ops)
-        if (int r = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, s)) return r;
+      for (const auto& op : pl->ops) {
+        if (op.fork_before) {
+          PEANUT_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+          PEANUT_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        }
+        if (op.join_before) {
+          PEANUT_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+          PEANUT_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
+        }
+        if (int r = run_op(h, *pl, op, in_dev, out_dev, apply_sigmoid, op.branch ? h->side : s)) return r;
+      }
       return 0;
     };
     if (!h->use_graph || h->keep_all) return enqueue();

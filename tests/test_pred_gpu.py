@@ -483,3 +483,37 @@ def test_constructor_from_files_on_disk(tmp_path):
     got = m.get_prediction(full_map)
     ref = pspnet_ref.get_prediction(sd, full_map, cfg)
     assert got.shape == (6, 104, 88) and np.abs(got - ref).max() <= TOL
+
+
+_SCHEDULE_PROBE = r"""
+import hashlib, sys, torch
+from types import SimpleNamespace
+from peanut_amd.prediction import PEANUT_Prediction_Model
+from peanut_amd.weights import PredCfg, make_seeded_state_dict
+cfg = PredCfg()
+out = []
+for precision in ("fp32", "bf16x6"):
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg, 0), cfg=cfg, precision=precision)
+    for B, S in ((1, 240), (3, 176), (1, 720)):
+        g = torch.Generator().manual_seed(B * 1000 + S)
+        x = (torch.rand((B, cfg.in_channels, S, S), generator=g) > 0.7).float().cuda()
+        for _ in range(2):
+            y = m.get_prediction_batch(x)
+        out.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
+print("HASHES " + " ".join(out))
+"""
+
+
+def test_two_stream_head_schedule_is_bit_identical():
+    """The pyramid branch of the PSP head runs on a side stream underneath the bottleneck GEMM: not a bit may change
+    against the one-stream schedule.  Same forwards in fresh processes with the switch on and off."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("default", {"PEANUT_PPM_OVERLAP": "1"}), ("one_stream", {"PEANUT_PPM_OVERLAP": "0"})):
+        r = subprocess.run([sys.executable, "-c", _SCHEDULE_PROBE], cwd=root, env={**os.environ, **env}, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = [l for l in r.stdout.splitlines() if l.startswith("HASHES ")][-1]
+    assert got["default"] == got["one_stream"]

@@ -20,6 +20,17 @@ def main():
     cur = db.cursor()
     rows = cur.execute("select name, duration, dispatch_id, grid_x, workgroup_x, lds_size, vgpr_count, "
                        "accum_vgpr_count, sgpr_count from kernels order by start").fetchall()
+    if "--timeline" in sys.argv:   # the last N dispatches in start order: duration and idle gap before each
+        n = int(sys.argv[sys.argv.index("--timeline") + 1])
+        tl = cur.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()[-n:]
+        t0, prev_end, busy = tl[0][1], tl[0][1], 0
+        print(f"# timeline of the last {len(tl)} dispatches: start_us  dur_us  gap_before_us  workgroups  kernel")
+        for name, st, en, gx, wx in tl:
+            print(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:8.1f} {(st - prev_end) / 1e3:8.1f} {gx // max(wx, 1):7d}  {short(name)}")
+            busy += en - st
+            prev_end = max(prev_end, en)
+        print(f"# span {(prev_end - t0) / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us")
+        return
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0, None])
     for name, dur, did, gx, wx, lds, vg, ag, sg in rows:
         a = agg[short(name)]
