@@ -298,39 +298,113 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void nms_scan_dev_kernel(const unsigned long long* __restrict__ ws, int n_cap, int words,
-                                                          const int* __restrict__ count, unsigned char* __restrict__ keep_all) {
+// Greedy scan over the suppression matrix of one image, 64 boxes (one matrix word) per step, 16 waves.
+//   wave 0: the step's 64 x 64 diagonal block decides which of its still-alive boxes survive (64 readlane rounds);
+//   all waves: wave g ORs rows 4g .. 4g+3 of the step (if they survived) into the `removed` words right of the diagonal.
+// The rows of step b+1 are loaded -- unconditionally, survivors are only known later -- while step b is decided
+// (WPL words per lane in registers, words <= 64 * WPL; WPL = 0: any width, loaded when needed).  The scan stops once
+// max_keep boxes are kept: both consumers take the first `cap` survivors in score order, later flags are zero.
+template <int WPL>
+__global__ __launch_bounds__(1024) void nms_scan_dev_kernel(const unsigned long long* __restrict__ ws, int n_cap, int words,
+                                                            const int* __restrict__ count, unsigned char* __restrict__ keep_all,
+                                                            int max_keep) {
   extern __shared__ unsigned long long removed[];   // [words]
+  __shared__ unsigned long long s_alive;
+  __shared__ int s_done;
   const int seg = blockIdx.x;
   const int n = min(count[seg], n_cap);
   const int nwords = (n + 63) >> 6;
   const unsigned long long* mask = ws + (size_t)seg * n_cap * words;
   unsigned char* keep = keep_all + (size_t)seg * n_cap;
-  const int lane = threadIdx.x;
-  for (int w = lane; w < nwords; w += 64) removed[w] = 0;
-  __syncthreads();
-  for (int b = 0; b < nwords; ++b) {
-    const int i = b * 64 + lane;
-    const unsigned long long diag = i < n ? mask[(size_t)i * words + b] : 0ull;
-    unsigned long long alive = ~removed[b];
-    if (b == nwords - 1 && (n & 63)) alive &= (1ull << (n & 63)) - 1;
-    for (int l = 0; l < 64; ++l) {
-      const unsigned long long d = readlane64(diag, l);
-      if ((alive >> l) & 1ull) alive &= ~d;
-    }
-    if (i < n) keep[i] = (alive >> lane) & 1ull;
-    for (int w = b + 1 + lane; w < nwords; w += 64) {
-      unsigned long long acc = 0;
-      unsigned long long rest = alive;
-      while (rest) {
-        const int r = __builtin_ctzll(rest);
-        rest &= rest - 1;
-        acc |= mask[(size_t)(b * 64 + r) * words + w];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int w = tid; w < nwords; w += 1024) removed[w] = 0;
+  constexpr int R = WPL > 0 ? WPL : 1;
+  unsigned long long cur[4][R], nxt[4][R], diag_cur = 0, diag_nxt = 0;
+  auto load_step = [&](int b, unsigned long long (&dst)[4][R], unsigned long long& dg) {
+    if constexpr (WPL > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = b * 64 + wave * 4 + r;
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) {
+          const int w = lane + 64 * q;
+          dst[r][q] = (row < n && w > b && w < nwords) ? mask[(size_t)row * words + w] : 0ull;
+        }
       }
-      removed[w] |= acc;
+    }
+    if (wave == 0) {
+      const int i = b * 64 + lane;
+      dg = i < n ? mask[(size_t)i * words + b] : 0ull;
+    }
+  };
+  if (nwords > 0) load_step(0, cur, diag_cur);
+  __syncthreads();
+  int kept = 0;
+  for (int b = 0; b < nwords; ++b) {
+    if (b + 1 < nwords) load_step(b + 1, nxt, diag_nxt);
+    if (wave == 0) {
+      unsigned long long alive = ~removed[b];
+      if (b == nwords - 1 && (n & 63)) alive &= (1ull << (n & 63)) - 1;
+      for (int l = 0; l < 64; ++l) {
+        const unsigned long long d = readlane64(diag_cur, l);
+        if ((alive >> l) & 1ull) alive &= ~d;
+      }
+      int done = 0;
+      if (kept + __builtin_popcountll(alive) >= max_keep) {   // keep the first max_keep - kept of them
+        unsigned long long a = alive, t = 0;
+        for (int k = kept; k < max_keep; ++k) { const unsigned long long low = a & (0ull - a); t |= low; a ^= low; }
+        alive = t;
+        done = 1;
+      }
+      kept += __builtin_popcountll(alive);
+      const int i = b * 64 + lane;
+      if (i < n) keep[i] = (alive >> lane) & 1ull;
+      if (lane == 0) { s_alive = alive; s_done = done; }
     }
     __syncthreads();
+    const unsigned long long alive = s_alive;
+    const int done = s_done;
+    if (done) {
+      for (int i = (b + 1) * 64 + tid; i < n; i += 1024) keep[i] = 0;
+      break;
+    }
+    if constexpr (WPL > 0) {
+#pragma unroll
+      for (int q = 0; q < WPL; ++q) {
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((alive >> (wave * 4 + r)) & 1ull) acc |= cur[r][q];
+        if (acc) atomicOr(&removed[lane + 64 * q], acc);
+      }
+    } else {
+      for (int w = b + 1 + lane; w < nwords; w += 64) {
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = b * 64 + wave * 4 + r;
+          if ((alive >> (wave * 4 + r)) & 1ull) acc |= mask[(size_t)row * words + w];
+        }
+        if (acc) atomicOr(&removed[w], acc);
+      }
+    }
+    __syncthreads();
+    if constexpr (WPL > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) cur[r][q] = nxt[r][q];
+    }
+    diag_cur = diag_nxt;
   }
+}
+
+void launch_nms_scan(const unsigned long long* ws, int n_cap, int words, const int* count, unsigned char* keep, int max_keep, int B,
+                     hipStream_t s) {
+  const size_t lds = (size_t)words * 8;
+  if (words <= 128) hipLaunchKernelGGL(nms_scan_dev_kernel<2>, dim3(B), dim3(1024), lds, s, ws, n_cap, words, count, keep, max_keep);
+  else if (words <= 256) hipLaunchKernelGGL(nms_scan_dev_kernel<4>, dim3(B), dim3(1024), lds, s, ws, n_cap, words, count, keep, max_keep);
+  else hipLaunchKernelGGL(nms_scan_dev_kernel<0>, dim3(B), dim3(1024), lds, s, ws, n_cap, words, count, keep, max_keep);
 }
 
 // ordered prefix of a predicate over [0, n) with 1024 threads: calls emit(r, position) for the first `limit` hits
@@ -710,11 +784,9 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
   if ((rc = launch_sort_keys((unsigned long long*)pb.ckey.p, Kpad, B, (int*)pb.nvalid.p, s))) return rc;
   hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Ktot)), dim3(256), 0, s, (const unsigned long long*)pb.ckey.p, Kpad,
                      Ktot, B, (const float*)pb.cbox.p, (const int*)pb.ccat.p, (float*)pb.sbox.p, (int*)pb.scat.p, (float*)pb.sscore.p);
-  PEANUT_HIP_CHECK(hipMemsetAsync(pb.nms_ws.p, 0, (size_t)B * Ktot * words * 8, s));
   hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(words, words, B), dim3(64), 0, s, (const float*)pb.sbox.p, (const int*)pb.scat.p, Ktot, words,
                      (const int*)pb.nvalid.p, c.rpn_nms_thresh, (unsigned long long*)pb.nms_ws.p);
-  hipLaunchKernelGGL(nms_scan_dev_kernel, dim3(B), dim3(64), (size_t)words * 8, s, (const unsigned long long*)pb.nms_ws.p, Ktot, words,
-                     (const int*)pb.nvalid.p, (unsigned char*)pb.keep.p);
+  launch_nms_scan((const unsigned long long*)pb.nms_ws.p, Ktot, words, (const int*)pb.nvalid.p, (unsigned char*)pb.keep.p, cap, B, s);
   hipLaunchKernelGGL(compact_proposals_kernel, dim3(B), dim3(1024), 0, s, (const float*)pb.sbox.p, (const float*)pb.sscore.p,
                      (const unsigned char*)pb.keep.p, (const int*)pb.nvalid.p, Ktot, cap, (float*)pb.rois.p, (int*)pb.roi_level.p,
                      (float*)pb.roi_logit.p, (int*)pb.prop_count.p);
@@ -741,11 +813,9 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
   if ((rc = launch_sort_keys((unsigned long long*)pb.dkey.p, Kcpad, B, (int*)pb.dnvalid.p, s))) return rc;
   hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Kc)), dim3(256), 0, s, (const unsigned long long*)pb.dkey.p, Kcpad, Kc, B,
                      (const float*)pb.dbox.p, (const int*)pb.dcat.p, (float*)pb.dsbox.p, (int*)pb.dscat.p, (float*)pb.dsscore.p);
-  PEANUT_HIP_CHECK(hipMemsetAsync(pb.nms_ws.p, 0, (size_t)B * Kc * dwords * 8, s));
   hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(dwords, dwords, B), dim3(64), 0, s, (const float*)pb.dsbox.p, (const int*)pb.dscat.p, Kc, dwords,
                      (const int*)pb.dnvalid.p, c.nms_thresh_test, (unsigned long long*)pb.nms_ws.p);
-  hipLaunchKernelGGL(nms_scan_dev_kernel, dim3(B), dim3(64), (size_t)dwords * 8, s, (const unsigned long long*)pb.nms_ws.p, Kc, dwords,
-                     (const int*)pb.dnvalid.p, (unsigned char*)pb.dkeep.p);
+  launch_nms_scan((const unsigned long long*)pb.nms_ws.p, Kc, dwords, (const int*)pb.dnvalid.p, (unsigned char*)pb.dkeep.p, std::min(D, 1024), B, s);
   // detector_postprocess scales boxes by (W / nw, H / nh): python doubles narrowed to float32 by the tensor product
   const float sx = (float)((double)W / (double)nw), sy = (float)((double)H / (double)nh);
   hipLaunchKernelGGL(compact_dets_kernel, dim3(B), dim3(1024), 0, s, (const float*)pb.dsbox.p, (const int*)pb.dscat.p, (const float*)pb.dsscore.p,
