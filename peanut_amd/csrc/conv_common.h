@@ -1,5 +1,7 @@
 // Shared pieces of the implicit-GEMM conv kernels (fp32-MFMA and split-precision variants).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace peanut {
@@ -221,19 +223,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
   }
 }
 
-// host side: pick split_p for T tiles over S slots; returns the number of tail tiles (0 = no split)
-inline int plan_tail_split(int T, int S, int nkt, size_t tile_floats, size_t ws_floats, int* split_p) {
+// host side: pick split_p for T tiles over S resident workgroup slots on `cus` CUs; returns the number of tail tiles
+// (0 = no split).  The tail's t tiles cut p ways put ceil(t * p / cus) workgroups on the busiest CU, and co-resident
+// workgroups share that CU's matrix core, so the tail takes about
+//     ceil(t * p / cus) * (nkt / p + fill)            k-tile times,  fill ~ 3 (pipeline fill + epilogue),
+// plus, when split, the reduce launch (~5 us, 3 k-tile times).  (Counting slots instead of CUs -- two workgroups per
+// CU as one "round" -- picked 7-way splits of 378 workgroups for the R-101 res4 layers at batch 1: half the CUs then
+// carry two parts and the launch takes twice the balanced time.)
+inline int plan_tail_split(int T, int S, int cus, int nkt, size_t tile_floats, size_t ws_floats, int* split_p) {
   *split_p = 1;
   if (S <= 0 || ws_floats == 0) return 0;
   const int t = T % S;
   if (t == 0) return 0;
-  double best = 1.0;   // cost of the tail round without splitting, in tile-times
+  static const bool cu_model = [] { const char* e = getenv("PEANUT_SPLIT_MODEL"); return !(e && e[0] == '0'); }();
+  if (!cu_model || cus <= 0) {
+    double best = 1.0;   // cost of the tail round without splitting, in tile-times
+    int best_p = 1;
+    for (int p = 2; p <= 32 && nkt / p >= 4; ++p) {
+      if ((size_t)t * p * tile_floats > ws_floats) break;
+      const int rounds = (int)(((long long)t * p + S - 1) / S);
+      const double cost = (double)rounds / p * (1.0 + 3.0 * p / nkt);   // ~3 k-tiles of fill/drain per part
+      if (cost < best - 0.02) { best = cost; best_p = p; }
+    }
+    if (best_p == 1) return 0;
+    *split_p = best_p;
+    return t;
+  }
+  auto stacked = [&](int p) { return (double)(((long long)t * p + cus - 1) / cus); };
+  double best = stacked(1) * (nkt + 3.0);
   int best_p = 1;
   for (int p = 2; p <= 32 && nkt / p >= 4; ++p) {
     if ((size_t)t * p * tile_floats > ws_floats) break;
-    const int rounds = (int)(((long long)t * p + S - 1) / S);
-    const double cost = (double)rounds / p * (1.0 + 3.0 * p / nkt);   // ~3 k-tiles of fill/drain per part
-    if (cost < best - 0.02) { best = cost; best_p = p; }
+    const double cost = stacked(p) * ((double)nkt / p + 3.0) + 3.0;
+    if (cost < best * 0.98) { best = cost; best_p = p; }
   }
   if (best_p == 1) return 0;
   *split_p = best_p;
@@ -286,8 +308,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
 template <typename KernelT, int BM, int BN, int NT = 256>
 int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream,
                            int* cached_slots) {
+  static int cus = 0;
   if (*cached_slots == 0) {
-    int dev = 0, cus = 0, occ = 0;
+    int dev = 0, occ = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, NT, 0) != hipSuccess || occ < 1)
       *cached_slots = -1;   // unknown -> never split
@@ -297,7 +320,7 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   const int mtiles = (p.M + BM - 1) / BM;
   const int T = mtiles * p.ntiles;
   int sp = 1;
-  const int t = plan_tail_split(T, *cached_slots, p.nkt, (size_t)BM * BN, ws ? ws_floats : 0, &sp);
+  const int t = plan_tail_split(T, *cached_slots, cus, p.nkt, (size_t)BM * BN, ws ? ws_floats : 0, &sp);
   p.split_p = sp;
   p.n_sp = t * sp;
   p.n_full = T - t;
