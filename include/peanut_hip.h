@@ -247,6 +247,16 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
  * B * detections_per_image instances.  Synchronises the stream once (to read the detection counts). */
 int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
                           float* scores, int32_t* classes, uint8_t* masks, void* stream);
+/* SemanticPredMaskRCNN.get_prediction (nav/agent/utils/segmentation.py:41-62) for a batch of frames: the detector as
+ * above, then `semantic_input[:, :, cls] += pred_masks[j] * 1.` for every instance with cls in range(n_cats), score >=
+ * sem_pred_prob_thr and, for the frame's goal category, score >= goal_thr -- evaluated per output pixel straight from
+ * the 28 x 28 mask probabilities (same arithmetic as peanut_paste_masks), so the [n,H,W] instance masks are never
+ * materialised.  semantic: device float [B,H,W,n_cats+1] (channel n_cats stays 0, as in the reference);
+ * goal_cat_host: HOST int32 [B] (-1 = no goal gate) or NULL.  masks may be NULL (the usual case); the other outputs
+ * are those of peanut_rcnn_inference. */
+int peanut_rcnn_semantic(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int n_cats, float sem_pred_prob_thr,
+                         float goal_thr, const int32_t* goal_cat_host, float* semantic, int* n_det_host, float* boxes,
+                         float* scores, int32_t* classes, uint8_t* masks, void* stream);
 /* Test / bisect hook: device pointer (and byte capacity) of a stage buffer of the last peanut_rcnn_inference call:
  * "rois" [B*cap,5], "roi_level", "roi_logit", "prop_count" [B], "cls" [B*cap,K+1], "bbox" [B*cap,4K], "det_in" /
  * "det_out" [B,D,4], "det_score", "det_cls", "det_count" [B], "mprobs" [sum n, 2P, 2P], "sel_idx", "sel_score", "nvalid". */

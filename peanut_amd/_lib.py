@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 5     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 6     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -94,6 +94,8 @@ SIGNATURES = {
     "peanut_rcnn_forward_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P),
                                             C.POINTER(_P), _P]),
     "peanut_rcnn_inference": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
+    "peanut_rcnn_semantic": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int32), _P,
+                                       C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "peanut_rcnn_debug_stage": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "peanut_roi_align": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int, _P, _P,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -227,15 +227,29 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(unsigned long long* __r
   }
   if (threadIdx.x == 0 && sk[0] == 0ull) nvalid[blockIdx.x] = 0;
 }
+// the same for the first count[b] keys of each segment (all non-zero): sorts the next power of two, at least 64
+template <int KMAX>
+__global__ __launch_bounds__(1024) void sort_keys_counted_kernel(unsigned long long* __restrict__ keys, const int* __restrict__ count,
+                                                                 int* __restrict__ nvalid) {
+  __shared__ unsigned long long sk[KMAX];
+  unsigned long long* g = keys + (size_t)blockIdx.x * KMAX;
+  const int n = min(count[blockIdx.x], KMAX);
+  int n2 = 64;
+  while (n2 < n) n2 <<= 1;
+  for (int i = threadIdx.x; i < n2; i += 1024) sk[i] = i < n ? g[i] : 0ull;
+  bitonic_desc(sk, n2);
+  for (int i = threadIdx.x; i < n; i += 1024) g[i] = sk[i];
+  if (threadIdx.x == 0) nvalid[blockIdx.x] = n;
+}
 
 // ---- boxes / categories / scores in sorted order (row r of image b <- candidate position encoded in its key) ----
-__global__ __launch_bounds__(256) void gather_sorted_kernel(const unsigned long long* __restrict__ keys, int Kpad, int Kcap, int B,
-                                                            const float* __restrict__ cbox, const int* __restrict__ ccat,
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ nvalid,
+                                                            int Kpad, int Kcap, int B, const float* __restrict__ cbox, const int* __restrict__ ccat,
                                                             float* __restrict__ sbox, int* __restrict__ scat, float* __restrict__ sscore) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * Kcap) return;
   const int b = i / Kcap, r = i - b * Kcap;
-  const unsigned long long key = keys[(size_t)b * Kpad + r];
+  const unsigned long long key = r < nvalid[b] ? keys[(size_t)b * Kpad + r] : 0ull;   // past the count: whatever an earlier call left
   float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
   int cat = -1;
   float sc = 0.f;
@@ -443,7 +457,8 @@ __device__ __forceinline__ int assign_level(const float* b) {
 __global__ __launch_bounds__(1024) void compact_proposals_kernel(const float* __restrict__ sbox, const float* __restrict__ sscore,
                                                                  const unsigned char* __restrict__ keep, const int* __restrict__ nvalid,
                                                                  int Kcap, int cap, float* __restrict__ rois, int* __restrict__ levels,
-                                                                 float* __restrict__ logits, int* __restrict__ count) {
+                                                                 float* __restrict__ logits, int* __restrict__ count,
+                                                                 int* __restrict__ n_keys) {
   __shared__ int wave_cnt[16], running;
   const int b = blockIdx.x;
   const int n = min(nvalid[b], Kcap);
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(1024) void compact_proposals_kernel(const float* __
         logits[(size_t)b * cap + pos] = sscore[(size_t)b * Kcap + r];
       },
       wave_cnt, &running);
-  if (threadIdx.x == 0) count[b] = c;
+  if (threadIdx.x == 0) { count[b] = c; n_keys[b] = 0; }   // n_keys: the detection candidates box_post_kernel appends
 }
 
 // ---- FastRCNNOutputLayers.inference for one roi: softmax, per-class decode, clip, score threshold ----
@@ -475,15 +490,12 @@ __global__ __launch_bounds__(256) void box_post_kernel(const float* __restrict__
                                                        const float* __restrict__ rois, const int* __restrict__ count, int B, int cap,
                                                        int K, int Kpad, float img_h, float img_w, float wx, float wy, float ww, float wh,
                                                        float score_thresh, float* __restrict__ dbox, unsigned long long* __restrict__ dkey,
-                                                       int* __restrict__ dcat) {
+                                                       int* __restrict__ dcat, int* __restrict__ n_keys) {
   const int i = blockIdx.x * 256 + threadIdx.x;      // roi index
   if (i >= B * cap) return;
   const int b = i / cap, p = i - b * cap;
   unsigned long long* keys = dkey + (size_t)b * Kpad;
-  if (p >= count[b]) {
-    for (int k = 0; k < K; ++k) keys[p * K + k] = 0ull;
-    return;
-  }
+  if (p >= count[b]) return;
   const float* lg = cls_logits + (size_t)i * (K + 1);
   float m = lg[0];
   for (int k = 1; k <= K; ++k) m = fmaxf(m, lg[k]);
@@ -503,16 +515,13 @@ __global__ __launch_bounds__(256) void box_post_kernel(const float* __restrict__
     float* ob = dbox + ((size_t)b * cap * K + c) * 4;
     ob[0] = boxes[k][0]; ob[1] = boxes[k][1]; ob[2] = boxes[k][2]; ob[3] = boxes[k][3];
     dcat[(size_t)b * cap * K + c] = k;
-    keys[c] = (ok && e[k] > score_thresh) ? (((unsigned long long)ord_key(e[k]) << 32) | (0xffffffffu - (unsigned)c)) : 0ull;
+    // candidates above the threshold are appended (n_keys[b] zeroed by compact_proposals_kernel); the order of arrival
+    // does not matter: the keys carry their candidate index and are unique, the sort that follows is total
+    if (ok && e[k] > score_thresh)
+      keys[atomicAdd(n_keys + b, 1)] = ((unsigned long long)ord_key(e[k]) << 32) | (0xffffffffu - (unsigned)c);
   }
 }
 
-__global__ __launch_bounds__(256) void zero_tail_keys_kernel(unsigned long long* __restrict__ keys, int B, int from, int Kpad) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int span = Kpad - from;
-  if (i >= B * span) return;
-  keys[(size_t)(i / span) * Kpad + from + i % span] = 0ull;
-}
 
 // ---- the first `cap` kept detections of every image; detector_postprocess scaling / clipping / non-empty filter ----
 __global__ __launch_bounds__(1024) void compact_dets_kernel(const float* __restrict__ sbox, const int* __restrict__ scat,
@@ -596,6 +605,67 @@ inline int launch_sort_keys(unsigned long long* keys, int Kpad, int B, int* nval
   return 0;
 }
 
+// Mask pasting (paste_masks_in_image, restated in rcnn_ops.hip: paste_masks_kernel) and the per-category accumulation
+// of SemanticPredMaskRCNN.get_prediction (seg_accum.hip) in one pass over the output pixels: a pixel walks its image's
+// detections in score order, evaluates the pasted mask bit of those that pass the score gates with the arithmetic of
+// paste_masks_kernel -- skipping, as that arithmetic would, instances whose four bilinear taps all fall outside the
+// M x M mask -- and adds it to the class channel.  The [n, H, W] instance masks (30 MB per frame) are never written.
+struct SemGoal { int cat[64]; };
+__global__ __launch_bounds__(256) void paste_accumulate_kernel(const float* __restrict__ mprobs, const float* __restrict__ boxes,
+                                                               const float* __restrict__ scores, const int* __restrict__ classes,
+                                                               const Offsets64 of, int M, int H, int W, float mask_thr, int n_cats,
+                                                               float thr, float goal_thr, const SemGoal goal, float* __restrict__ out,
+                                                               long long total) {
+  const int ch = n_cats + 1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long long t = i / W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    const int goal_cat = goal.cat[b];
+    for (int j = of.off[b]; j < of.off[b + 1]; ++j) {
+      const int cls = classes[j];
+      if (cls < 0 || cls >= n_cats) continue;
+      const float sc = scores[j];
+      if (sc < thr) continue;
+      if (cls == goal_cat && sc < goal_thr) continue;
+      const float* bx = boxes + (size_t)j * 4;
+      const float gx = ((float)x + 0.5f - bx[0]) / (bx[2] - bx[0]) * 2.f - 1.f;
+      const float gy = ((float)y + 0.5f - bx[1]) / (bx[3] - bx[1]) * 2.f - 1.f;
+      const float ix = ((gx + 1.f) * (float)M - 1.f) / 2.f, iy = ((gy + 1.f) * (float)M - 1.f) / 2.f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)M + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)M + 1.f);
+      if (x0 < -1 || x0 >= M || y0 < -1 || y0 >= M) continue;   // all four taps read zero padding: v = 0 < mask_thr
+      const float lx = ix - fx, ly = iy - fy;
+      const float* m = mprobs + (size_t)j * M * M;
+      auto at = [&](int yy, int xx) -> float {
+        return ((unsigned)yy < (unsigned)M && (unsigned)xx < (unsigned)M) ? m[yy * M + xx] : 0.f;
+      };
+      const float v = at(y0, x0) * (1.f - ly) * (1.f - lx) + at(y0, x0 + 1) * (1.f - ly) * lx +
+                      at(y0 + 1, x0) * ly * (1.f - lx) + at(y0 + 1, x0 + 1) * ly * lx;
+      const float bit = v >= mask_thr ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c)
+        if (c == cls) acc[c] += bit;
+    }
+    for (int c = 0; c < ch; ++c) out[(size_t)i * ch + c] = c < 32 ? acc[c] : 0.f;
+  }
+}
+
+inline int launch_sort_keys_counted(unsigned long long* keys, int Kpad, int B, const int* count, int* nvalid, hipStream_t s) {
+  switch (Kpad) {
+    case 16384: hipLaunchKernelGGL(sort_keys_counted_kernel<16384>, dim3(B), dim3(1024), 0, s, keys, count, nvalid); break;
+    case 8192: hipLaunchKernelGGL(sort_keys_counted_kernel<8192>, dim3(B), dim3(1024), 0, s, keys, count, nvalid); break;
+    case 4096: hipLaunchKernelGGL(sort_keys_counted_kernel<4096>, dim3(B), dim3(1024), 0, s, keys, count, nvalid); break;
+    case 2048: hipLaunchKernelGGL(sort_keys_counted_kernel<2048>, dim3(B), dim3(1024), 0, s, keys, count, nvalid); break;
+    default: return fail(PEANUT_EINVAL, "rcnn: unsupported sort size");
+  }
+  return 0;
+}
+
 inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)std::max<long long>(1, (n + per - 1) / per); }
 inline int pow2_at_least(int n) { int p = 2048; while (p < n) p <<= 1; return p; }
 
@@ -609,7 +679,7 @@ struct peanut_rcnn::PostBufs {
   DevBuf sel_idx, sel_score, cbox, ckey, ccat, sbox, scat, sscore, keep, nms_ws, nvalid;
   DevBuf rois, roi_level, roi_logit, prop_count;
   DevBuf x7, f1, f2, cls, bbox;
-  DevBuf dbox, dkey, dcat, dsbox, dscat, dsscore, dkeep, dnvalid;
+  DevBuf dbox, dkey, dcat, dsbox, dscat, dsscore, dkeep, dnvalid, dkeys;
   DevBuf det_in, det_out, det_score, det_cls, det_count;
   DevBuf mrois, mlevel, mx0, mx1, mdeconv, mlogits, mprobs, splitk, wino_v, wino_m;
 };
@@ -706,8 +776,18 @@ int peanut_rcnn_build_heads(peanut_rcnn* h, const TensorMap& tm) {
   return 0;
 }
 
-extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
-                                     float* scores, int32_t* classes, uint8_t* masks, void* stream) {
+namespace {
+// what SemanticPredMaskRCNN.get_prediction makes of the instances (segmentation.py:47-60), or nothing (out == null)
+struct SemanticOut {
+  float* out = nullptr;          // [B,H,W,n_cats+1]
+  int n_cats = 0;
+  float thr = 0.f, goal_thr = 0.f;
+  const int32_t* goal_cat = nullptr;   // host [B], -1 = none; null = none
+};
+}  // namespace
+
+static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
+                               float* scores, int32_t* classes, uint8_t* masks, const SemanticOut& sem, void* stream) {
   if (!h || !img_bgr || !n_det_host || !boxes || !scores || !classes) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: null argument");
   if (!h->has_heads) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: the handle was created without roi_heads.* tensors");
   if (B < 1 || B > 64) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: 1 <= B <= 64");
@@ -764,7 +844,7 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
       (rc = pb.f2.ensure((size_t)N * c.fc_dim * 4)) || (rc = pb.cls.ensure((size_t)N * (K + 1) * 4)) || (rc = pb.bbox.ensure((size_t)N * 4 * K * 4)) ||
       (rc = pb.dbox.ensure((size_t)B * Kc * 16)) || (rc = pb.dkey.ensure((size_t)B * Kcpad * 8)) || (rc = pb.dcat.ensure((size_t)B * Kc * 4)) ||
       (rc = pb.dsbox.ensure((size_t)B * Kc * 16)) || (rc = pb.dscat.ensure((size_t)B * Kc * 4)) || (rc = pb.dsscore.ensure((size_t)B * Kc * 4)) ||
-      (rc = pb.dkeep.ensure((size_t)B * Kc)) || (rc = pb.dnvalid.ensure((size_t)B * 4)) ||
+      (rc = pb.dkeep.ensure((size_t)B * Kc)) || (rc = pb.dnvalid.ensure((size_t)B * 4)) || (rc = pb.dkeys.ensure((size_t)B * 4)) ||
       (rc = pb.det_in.ensure((size_t)B * D * 16)) || (rc = pb.det_out.ensure((size_t)B * D * 16)) || (rc = pb.det_score.ensure((size_t)B * D * 4)) ||
       (rc = pb.det_cls.ensure((size_t)B * D * 4)) || (rc = pb.det_count.ensure((size_t)B * 4)) ||
       (rc = pb.splitk.ensure(kSplitKScratchFloats * sizeof(float))))
@@ -782,14 +862,14 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
                      (const float*)pb.sel_score.p, (float)nh, (float)nw, c.rpn_bbox_weights[0], c.rpn_bbox_weights[1], c.rpn_bbox_weights[2],
                      c.rpn_bbox_weights[3], (float*)pb.cbox.p, (unsigned long long*)pb.ckey.p, (int*)pb.ccat.p);
   if ((rc = launch_sort_keys((unsigned long long*)pb.ckey.p, Kpad, B, (int*)pb.nvalid.p, s))) return rc;
-  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Ktot)), dim3(256), 0, s, (const unsigned long long*)pb.ckey.p, Kpad,
-                     Ktot, B, (const float*)pb.cbox.p, (const int*)pb.ccat.p, (float*)pb.sbox.p, (int*)pb.scat.p, (float*)pb.sscore.p);
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Ktot)), dim3(256), 0, s, (const unsigned long long*)pb.ckey.p,
+                     (const int*)pb.nvalid.p, Kpad, Ktot, B, (const float*)pb.cbox.p, (const int*)pb.ccat.p, (float*)pb.sbox.p, (int*)pb.scat.p, (float*)pb.sscore.p);
   hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(words, words, B), dim3(64), 0, s, (const float*)pb.sbox.p, (const int*)pb.scat.p, Ktot, words,
                      (const int*)pb.nvalid.p, c.rpn_nms_thresh, (unsigned long long*)pb.nms_ws.p);
   launch_nms_scan((const unsigned long long*)pb.nms_ws.p, Ktot, words, (const int*)pb.nvalid.p, (unsigned char*)pb.keep.p, cap, B, s);
   hipLaunchKernelGGL(compact_proposals_kernel, dim3(B), dim3(1024), 0, s, (const float*)pb.sbox.p, (const float*)pb.sscore.p,
                      (const unsigned char*)pb.keep.p, (const int*)pb.nvalid.p, Ktot, cap, (float*)pb.rois.p, (int*)pb.roi_level.p,
-                     (float*)pb.roi_logit.p, (int*)pb.prop_count.p);
+                     (float*)pb.roi_logit.p, (int*)pb.prop_count.p, (int*)pb.dkeys.p);
 
   // ---- box head: ROIAlignV2 7x7 over p2..p5, two FC layers, class scores and box deltas ----
   const float* feats[4] = {pyr[0], pyr[1], pyr[2], pyr[3]};
@@ -807,11 +887,10 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
   hipLaunchKernelGGL(box_post_kernel, dim3(blocks_for(N)), dim3(256), 0, s, (const float*)pb.cls.p, (const float*)pb.bbox.p, (const float*)pb.rois.p,
                      (const int*)pb.prop_count.p, B, cap, K, Kcpad, (float)nh, (float)nw, c.roi_bbox_weights[0], c.roi_bbox_weights[1],
                      c.roi_bbox_weights[2], c.roi_bbox_weights[3], c.score_thresh_test, (float*)pb.dbox.p, (unsigned long long*)pb.dkey.p,
-                     (int*)pb.dcat.p);
-  if (Kcpad > Kc)
-    hipLaunchKernelGGL(zero_tail_keys_kernel, dim3(blocks_for((long long)B * (Kcpad - Kc))), dim3(256), 0, s, (unsigned long long*)pb.dkey.p, B, Kc, Kcpad);
-  if ((rc = launch_sort_keys((unsigned long long*)pb.dkey.p, Kcpad, B, (int*)pb.dnvalid.p, s))) return rc;
-  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Kc)), dim3(256), 0, s, (const unsigned long long*)pb.dkey.p, Kcpad, Kc, B,
+                     (int*)pb.dcat.p, (int*)pb.dkeys.p);
+  if ((rc = launch_sort_keys_counted((unsigned long long*)pb.dkey.p, Kcpad, B, (const int*)pb.dkeys.p, (int*)pb.dnvalid.p, s))) return rc;
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Kc)), dim3(256), 0, s, (const unsigned long long*)pb.dkey.p,
+                     (const int*)pb.dnvalid.p, Kcpad, Kc, B,
                      (const float*)pb.dbox.p, (const int*)pb.dcat.p, (float*)pb.dsbox.p, (int*)pb.dscat.p, (float*)pb.dsscore.p);
   hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(dwords, dwords, B), dim3(64), 0, s, (const float*)pb.dsbox.p, (const int*)pb.dscat.p, Kc, dwords,
                      (const int*)pb.dnvalid.p, c.nms_thresh_test, (unsigned long long*)pb.nms_ws.p);
@@ -828,7 +907,10 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
   Offsets64 of{};
   for (int b = 0; b < B; ++b) of.off[b + 1] = of.off[b] + n_det_host[b];
   const int n = of.off[B];
-  if (n == 0) return 0;
+  if (n == 0) {
+    if (sem.out) PEANUT_HIP_CHECK(hipMemsetAsync(sem.out, 0, (size_t)B * H * W * (sem.n_cats + 1) * sizeof(float), s));
+    return 0;
+  }
   const int Pm = c.mask_pooler_resolution, mc = c.mask_conv_dim;
   size_t vf = 0, mf = 0;
   for (const ConvLayer* L : h->mask_fcn)
@@ -840,7 +922,7 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
     return rc;
   hipLaunchKernelGGL(pack_dets_kernel, dim3(blocks_for(n)), dim3(256), 0, s, (const float*)pb.det_in.p, (const float*)pb.det_out.p,
                      (const float*)pb.det_score.p, (const int*)pb.det_cls.p, D, B, of, (float*)pb.mrois.p, (int*)pb.mlevel.p, boxes, scores, classes);
-  if (!masks) {
+  if (!masks && !sem.out) {
     hipError_t e0 = hipGetLastError();
     return e0 == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_rcnn_inference: ") + hipGetErrorString(e0));
   }
@@ -855,9 +937,32 @@ extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, i
   if ((rc = conv_on(h->mask_pred, (const float*)pb.mdeconv.p, (float*)pb.mlogits.p, n, Pm, Pm * 4, sk, nullptr, nullptr, s))) return rc;
   hipLaunchKernelGGL(mask_prob_kernel, dim3(blocks_for((long long)n * 4 * Pm * Pm)), dim3(256), 0, s, (const float*)pb.mlogits.p, (const int*)classes, n,
                      Pm, K, (float*)pb.mprobs.p);
-  if ((rc = peanut_paste_masks((const float*)pb.mprobs.p, boxes, n, 2 * Pm, H, W, c.mask_threshold, masks, stream))) return rc;
+  if (masks && (rc = peanut_paste_masks((const float*)pb.mprobs.p, boxes, n, 2 * Pm, H, W, c.mask_threshold, masks, stream))) return rc;
+  if (sem.out) {
+    SemGoal goal{};
+    for (int b = 0; b < B; ++b) goal.cat[b] = sem.goal_cat ? sem.goal_cat[b] : -1;
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(paste_accumulate_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const float*)pb.mprobs.p, (const float*)boxes,
+                       (const float*)scores, (const int*)classes, of, 2 * Pm, H, W, c.mask_threshold, sem.n_cats, sem.thr, sem.goal_thr, goal,
+                       sem.out, total);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_rcnn_inference: ") + hipGetErrorString(e));
+}
+
+extern "C" int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
+                                     float* scores, int32_t* classes, uint8_t* masks, void* stream) {
+  return rcnn_inference_impl(h, img_bgr, B, H, W, n_det_host, boxes, scores, classes, masks, SemanticOut{}, stream);
+}
+
+extern "C" int peanut_rcnn_semantic(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int n_cats, float sem_pred_prob_thr,
+                                    float goal_thr, const int32_t* goal_cat_host, float* semantic, int* n_det_host, float* boxes,
+                                    float* scores, int32_t* classes, uint8_t* masks, void* stream) {
+  if (!semantic) return fail(PEANUT_EINVAL, "peanut_rcnn_semantic: null output");
+  if (n_cats < 1 || n_cats > 31) return fail(PEANUT_EINVAL, "peanut_rcnn_semantic: 1 <= n_cats <= 31 required");
+  SemanticOut so;
+  so.out = semantic; so.n_cats = n_cats; so.thr = sem_pred_prob_thr; so.goal_thr = goal_thr; so.goal_cat = goal_cat_host;
+  return rcnn_inference_impl(h, img_bgr, B, H, W, n_det_host, boxes, scores, classes, masks, so, stream);
 }
 
 // test / bisect hook: device pointers of the stage outputs of the last peanut_rcnn_inference call

@@ -388,9 +388,33 @@ class MaskRCNN(MaskRCNNFront):
             n = int(n_det[b])
             sl = slice(start, start + n)
             out.append(dict(pred_boxes=boxes[sl], scores=scores[sl], pred_classes=classes[sl].long(),
-                            pred_masks=(masks[sl].bool() if masks is not None else None)))
+                            pred_masks=(masks[sl].view(torch.bool) if masks is not None else None)))   # 0/1 bytes: a view, not a copy
             start += n
         return out
+
+    def semantic(self, img_bgr: torch.Tensor, n_cats: int, sem_pred_prob_thr: float, goal_thr: float, goal_cats=None):
+        """``SemanticPredMaskRCNN.get_prediction`` for a batch (segmentation.py:41-62): img_bgr uint8 [B,H,W,3] (device)
+        -> float32 [B,H,W,n_cats+1] per-category sums of the gated instance masks, in ONE ``peanut_rcnn_semantic`` call
+        (the instance masks are evaluated per pixel and never written).  ``goal_cats``: per-frame goal category or None."""
+        assert img_bgr.is_cuda and img_bgr.dtype == torch.uint8 and img_bgr.dim() == 4 and img_bgr.shape[3] == 3
+        img_bgr = img_bgr.contiguous()
+        B, H, W, _ = img_bgr.shape
+        D = self.cfg.detections_per_image
+        dev = img_bgr.device
+        boxes = torch.empty((B * D, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((B * D,), dtype=torch.float32, device=dev)
+        classes = torch.empty((B * D,), dtype=torch.int32, device=dev)
+        sem = torch.empty((B, H, W, n_cats + 1), dtype=torch.float32, device=dev)
+        n_det = (C.c_int * B)()
+        goals = None
+        if goal_cats is not None:
+            goals = (C.c_int32 * B)(*[-1 if g is None else int(g) for g in goal_cats])
+        with torch.cuda.device(dev):
+            rc = self._lib.peanut_rcnn_semantic(self._h, img_bgr.data_ptr(), B, H, W, int(n_cats), float(sem_pred_prob_thr), float(goal_thr),
+                                                goals, sem.data_ptr(), n_det, boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(), None,
+                                                _lib.current_stream_ptr(dev))
+        _lib.check(rc, "peanut_rcnn_semantic")
+        return sem
 
     def debug_stage(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         """Copy of a stage buffer of the last ``inference`` call (peanut_rcnn_debug_stage)."""

@@ -28,13 +28,17 @@ def run_episode(state: Agent_State, frames: Iterable[Dict], goal_cat: int,
         if "obs" in fr:
             obs = fr["obs"]
         else:
-            if "masks" not in fr:
-                if detector is None:
-                    raise ValueError("frame carries no instance masks and no detector was given")
-                fr = dict(fr)
-                fr["masks"], fr["classes"], fr["scores"] = detector(fr["rgb"].flip(-1))     # RGB -> BGR
-            sem = accumulate_instances(fr["masks"], fr["classes"], fr["scores"], args.num_sem_categories - 1,
-                                       args.sem_pred_prob_thr, args.goal_thr, goal_cat)
+            if "masks" not in fr and detector is None:
+                raise ValueError("frame carries no instance masks and no detector was given")
+            if "masks" not in fr and hasattr(detector, "semantic"):     # detector + accumulation in one library call
+                sem = detector.semantic(fr["rgb"].flip(-1), args.num_sem_categories - 1, args.sem_pred_prob_thr, args.goal_thr,
+                                        goal_cat)                       # RGB -> BGR
+            else:
+                if "masks" not in fr:
+                    fr = dict(fr)
+                    fr["masks"], fr["classes"], fr["scores"] = detector(fr["rgb"].flip(-1))
+                sem = accumulate_instances(fr["masks"], fr["classes"], fr["scores"], args.num_sem_categories - 1,
+                                           args.sem_pred_prob_thr, args.goal_thr, goal_cat)
             obs = preprocess_obs(fr["rgb"], fr["depth"], sem, args)
         infos = {"sensor_pose": fr["sensor_pose"], "goal_cat_id": goal_cat}
         if i == 0:

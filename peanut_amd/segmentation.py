@@ -23,7 +23,7 @@ def accumulate_instances(pred_masks: torch.Tensor, pred_classes: torch.Tensor, s
     if not pred_masks.is_cuda:
         raise _lib.PeanutHipError("accumulate_instances needs HIP tensors (no CPU fallback)")
     n, H, W = pred_masks.shape
-    masks = pred_masks.to(torch.uint8).contiguous()
+    masks = (pred_masks.view(torch.uint8) if pred_masks.dtype == torch.bool else pred_masks.to(torch.uint8)).contiguous()
     classes = pred_classes.to(torch.int32).contiguous()
     sc = scores.to(torch.float32).contiguous()
     out = torch.empty((H, W, n_cats + 1), dtype=torch.float32, device=pred_masks.device)
@@ -53,6 +53,11 @@ class HipDetector:
         x = torch.from_numpy(np.ascontiguousarray(img_bgr)) if isinstance(img_bgr, np.ndarray) else img_bgr
         return self.batch(x.to(self.device)[None])[0]
 
+    def semantic(self, img_bgr, n_cats: int, sem_pred_prob_thr: float, goal_thr: float, goal_cat=None) -> torch.Tensor:
+        """One frame straight to the per-category mask sums [H,W,n_cats+1] (``peanut_rcnn_semantic``)."""
+        x = torch.from_numpy(np.ascontiguousarray(img_bgr)) if isinstance(img_bgr, np.ndarray) else img_bgr
+        return self.net.semantic(x.to(self.device)[None], n_cats, sem_pred_prob_thr, goal_thr, [goal_cat])[0]
+
 
 class SemanticPredMaskRCNN():
     """Same call surface as the reference class (segmentation.py:28-62): ``SemanticPredMaskRCNN(args)``,
@@ -79,6 +84,8 @@ class SemanticPredMaskRCNN():
     def get_prediction(self, img, depth=None, goal_cat=None):
         args = self.args
         img = img[:, :, ::-1]                                   # RGB -> BGR (segmentation.py:44)
+        if isinstance(self.predictor, HipDetector):             # detector + accumulation in one library call
+            return self.predictor.semantic(img, self.n_cats, args.sem_pred_prob_thr, args.goal_thr, goal_cat).cpu().numpy(), img
         masks, classes, scores = self.predictor(img)
         semantic_input = accumulate_instances(masks, classes, scores, self.n_cats, args.sem_pred_prob_thr,
                                               args.goal_thr, goal_cat)
