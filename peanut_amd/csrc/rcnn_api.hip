@@ -12,6 +12,7 @@
 // restatement oracle/rcnn_ref.py ("parity unpinned" w.r.t. the reference).
 #include <string.h>
 
+#include <stdlib.h>
 #include "rcnn_internal.h"
 
 namespace peanut {
@@ -20,6 +21,33 @@ namespace {
 // ---- uint8 BGR [B,H,W,3] -> bilinear resize -> round to 8-bit -> (x - mean) / std -> NHWC [B,Hp,Wp,16] ----
 // (zero in the padded border and in channels 3..15).  One thread per output pixel.
 struct Norm3 { float mean[3], inv_std[3]; };
+
+// one pixel of the network input: bilinear resize of the uint8 frame (rounded back to uint8, as the resized image is
+// uint8 again), then (x - mean) / std; zeros in the padding up to the size-divisible canvas
+__device__ __forceinline__ float4 rcnn_input_pixel(const uint8_t* __restrict__ img, long long b, int y, int x, int H, int W, int nh,
+                                                   int nw, const Norm3& nm) {
+  if (y >= nh || x >= nw) return make_float4(0.f, 0.f, 0.f, 0.f);
+  // F.interpolate(bilinear, align_corners=False): src = (dst + 0.5) * in/out - 0.5, clamped at 0
+  const float sy = fmaxf(((float)y + 0.5f) * ((float)H / (float)nh) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)x + 0.5f) * ((float)W / (float)nw) - 0.5f, 0.f);
+  int y0 = (int)sy, x0 = (int)sx;
+  if (y0 > H - 1) y0 = H - 1;
+  if (x0 > W - 1) x0 = W - 1;
+  const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+  const uint8_t* p00 = img + ((b * H + y0) * W + x0) * 3;
+  const uint8_t* p01 = img + ((b * H + y0) * W + x1) * 3;
+  const uint8_t* p10 = img + ((b * H + y1) * W + x0) * 3;
+  const uint8_t* p11 = img + ((b * H + y1) * W + x1) * 3;
+  float c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float f = hy * (hx * (float)p00[k] + lx * (float)p01[k]) + ly * (hx * (float)p10[k] + lx * (float)p11[k]);
+    const float u8 = fminf(fmaxf(floorf(f + 0.5f), 0.f), 255.f);
+    c[k] = (u8 - nm.mean[k]) * nm.inv_std[k];
+  }
+  return make_float4(c[0], c[1], c[2], 0.f);
+}
 
 __global__ __launch_bounds__(256) void rcnn_preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
                                                               int H, int W, int nh, int nw, int Hp, int Wp, Norm3 nm,
@@ -30,33 +58,28 @@ __global__ __launch_bounds__(256) void rcnn_preprocess_kernel(const uint8_t* __r
     const long long t = i / Wp;
     const int y = (int)(t % Hp);
     const long long b = t / Hp;
-    float4 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y < nh && x < nw) {
-      // F.interpolate(bilinear, align_corners=False): src = (dst + 0.5) * in/out - 0.5, clamped at 0
-      const float sy = fmaxf(((float)y + 0.5f) * ((float)H / (float)nh) - 0.5f, 0.f);
-      const float sx = fmaxf(((float)x + 0.5f) * ((float)W / (float)nw) - 0.5f, 0.f);
-      int y0 = (int)sy, x0 = (int)sx;
-      if (y0 > H - 1) y0 = H - 1;
-      if (x0 > W - 1) x0 = W - 1;
-      const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
-      const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-      const uint8_t* p00 = img + ((b * H + y0) * W + x0) * 3;
-      const uint8_t* p01 = img + ((b * H + y0) * W + x1) * 3;
-      const uint8_t* p10 = img + ((b * H + y1) * W + x0) * 3;
-      const uint8_t* p11 = img + ((b * H + y1) * W + x1) * 3;
-      float c[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float f = hy * (hx * (float)p00[k] + lx * (float)p01[k]) + ly * (hx * (float)p10[k] + lx * (float)p11[k]);
-        const float u8 = fminf(fmaxf(floorf(f + 0.5f), 0.f), 255.f);   // the resized image is uint8 again
-        c[k] = (u8 - nm.mean[k]) * nm.inv_std[k];
-      }
-      v[0] = make_float4(c[0], c[1], c[2], 0.f);
-    }
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* o = reinterpret_cast<float4*>(out + (size_t)i * 16);
-    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    o[0] = rcnn_input_pixel(img, b, y, x, H, W, nh, nw, nm); o[1] = z; o[2] = z; o[3] = z;
+  }
+}
+
+// The same image in 2x2 space-to-depth form: out [B, Hp/2, Wp/2, 16], channel (dy*2 + dx)*4 + c = channel c of pixel
+// (2Y + dy, 2X + dx) (c = 3: zero).  The 7x7 stride-2 stem conv over 3 channels becomes a 4x4 stride-1 conv over these
+// 16 (add_stem_s2d): 16 taps x 16 channels instead of 49 taps x 16 zero-padded channels in the implicit GEMM.
+__global__ __launch_bounds__(256) void rcnn_preprocess_s2d_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
+                                                                  int H, int W, int nh, int nw, int Hp, int Wp, Norm3 nm,
+                                                                  long long total) {
+  const int H2 = Hp >> 1, W2 = Wp >> 1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3);                   // (dy, dx) of this thread: four threads per output pixel
+    const long long pix = i >> 2;
+    const int X = (int)(pix % W2);
+    const long long t = pix / W2;
+    const int Y = (int)(t % H2);
+    const long long b = t / H2;
+    reinterpret_cast<float4*>(out + (size_t)pix * 16)[q] = rcnn_input_pixel(img, b, 2 * Y + (q >> 1), 2 * X + (q & 1), H, W, nh, nw, nm);
   }
 }
 
@@ -139,6 +162,36 @@ int add_rconv(peanut_rcnn* h, const TensorMap& tm, const std::string& name, int 
   return 0;
 }
 
+// BasicStem's 7x7 stride-2 pad-3 conv over 3 channels restated on the 2x2 space-to-depth image (rcnn_preprocess_s2d_kernel):
+// output (oy, ox) reads input rows 2 oy + ky - 3; in blocks of two rows that is block oy + by - 2, row dy inside it, with
+// ky = 2 by + dy - 1 (by = 0..3) -- a 4x4 stride-1 pad-2 conv whose taps outside 0 <= ky <= 6 are zero.  Same products,
+// summed in another order.
+int add_stem_s2d(peanut_rcnn* h, const TensorMap& tm, const std::string& name, int cout, ConvLayer** out) {
+  int rc = 0;
+  const int64_t wshape[4] = {cout, 3, 7, 7};
+  const peanut_tensor* w = tm.get(name + ".weight", 4, wshape, &rc);
+  if (!w) return rc;
+  std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+  if ((rc = bn_fold_eps(tm, name + ".norm", cout, h->cfg.bn_eps, scale.data(), shift.data()))) return rc;
+  std::vector<float> w2((size_t)cout * 16 * 4 * 4, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int c = 0; c < 3; ++c)
+      for (int by = 0; by < 4; ++by)
+        for (int dy = 0; dy < 2; ++dy)
+          for (int bx = 0; bx < 4; ++bx)
+            for (int dx = 0; dx < 2; ++dx) {
+              const int ky = 2 * by + dy - 1, kx = 2 * bx + dx - 1;
+              if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+              w2[(((size_t)o * 16 + (dy * 2 + dx) * 4 + c) * 4 + by) * 4 + bx] = w->data[(((size_t)o * 3 + c) * 7 + ky) * 7 + kx];
+            }
+  auto L = std::make_unique<ConvLayer>();
+  L->name = name;
+  if ((rc = upload_conv(*L, w2.data(), scale.data(), shift.data(), cout, 16, 16, 4, 4, 1, 2, 1, 1, h->cfg.precision))) return rc;
+  *out = L.get();
+  h->convs.push_back(std::move(L));
+  return 0;
+}
+
 void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
   // detectron2 ResizeShortestEdge.get_output_shape
   const double size = (double)c.min_size;
@@ -191,11 +244,13 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   auto rel = [&](const Act& t) { ar.release(t.off, t.bytes); };
   pl->splitk.bytes = kSplitKScratchFloats * sizeof(float);
   pl->splitk.off = ar.alloc(pl->splitk.bytes);
-  Act x = make_act(ar, B, pl->Hp, pl->Wp, 16);
+  // BasicStem, on the space-to-depth image when there is such a form of it (Hp, Wp are multiples of 32)
+  const ConvLayer* stem = h->stem_s2d ? h->stem_s2d : h->stem;
+  Act x = h->stem_s2d ? make_act(ar, B, pl->Hp / 2, pl->Wp / 2, 16) : make_act(ar, B, pl->Hp, pl->Wp, 16);
   { ROp op; op.kind = R_PREPROCESS; op.name = "preprocess"; op.kernel = "rcnn_preprocess"; op.out = x; pl->ops.push_back(op); }
-  // BasicStem
-  Act s = conv_out_act(ar, h->stem, x);
-  push_rconv(*pl, ar, h->stem, x, nullptr, s);
+  Act s = make_act(ar, B, conv_out_dim(pl->Hp, 7, 2, 3, 1), conv_out_dim(pl->Wp, 7, 2, 3, 1), h->stem->d.cout);
+  push_rconv(*pl, ar, stem, x, nullptr, s);
+  pl->ops.back().flops = conv_flops(h->stem, s);   // nominal: the 7x7 form
   rel(x);
   Act cur = make_act(ar, B, conv_out_dim(s.H, 3, 2, 1, 1), conv_out_dim(s.W, 3, 2, 1, 1), s.C);
   { ROp op; op.kind = R_MAXPOOL; op.name = "stem.maxpool"; op.kernel = "maxpool"; op.in = s; op.out = cur; pl->ops.push_back(op); }
@@ -292,6 +347,8 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
     if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
   int rc;
   if ((rc = add_rconv(h.get(), tm, "backbone.bottom_up.stem.conv1", 3, 16, cfg->stem_out, 7, 2, 3, true, 1, &h->stem))) return rc;
+  static const bool stem_s2d = [] { const char* e = getenv("PEANUT_RCNN_STEM_S2D"); return !(e && e[0] == '0'); }();
+  if (stem_s2d && (rc = add_stem_s2d(h.get(), tm, "backbone.bottom_up.stem.conv1", cfg->stem_out, &h->stem_s2d))) return rc;
   const int nblocks[3][4] = {{3, 4, 6, 3}, {3, 4, 23, 3}, {3, 8, 36, 3}};
   const int* nb = nblocks[cfg->depth == 50 ? 0 : (cfg->depth == 101 ? 1 : 2)];
   int cin = cfg->stem_out, bott = cfg->res2_out / 4, cout = cfg->res2_out;
@@ -369,9 +426,13 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
       case R_PREPROCESS: {
         Norm3 nm;
         for (int k = 0; k < 3; ++k) { nm.mean[k] = h->cfg.pixel_mean[k]; nm.inv_std[k] = 1.0f / h->cfg.pixel_std[k]; }
-        const long long total = (long long)B * pl->Hp * pl->Wp;
-        hipLaunchKernelGGL(rcnn_preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, s, img_bgr, P(op.out), H, W, pl->nh,
-                           pl->nw, pl->Hp, pl->Wp, nm, total);
+        const long long total = (long long)B * pl->Hp * pl->Wp;   // one thread per input pixel in either layout
+        if (h->stem_s2d)
+          hipLaunchKernelGGL(rcnn_preprocess_s2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, img_bgr, P(op.out), H, W, pl->nh,
+                             pl->nw, pl->Hp, pl->Wp, nm, total);
+        else
+          hipLaunchKernelGGL(rcnn_preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, s, img_bgr, P(op.out), H, W, pl->nh,
+                             pl->nw, pl->Hp, pl->Wp, nm, total);
         break;
       }
       case R_CONV: {

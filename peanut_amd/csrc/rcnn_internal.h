@@ -34,6 +34,7 @@ struct peanut_rcnn {
   peanut_rcnn_cfg cfg{};
   std::vector<std::unique_ptr<peanut::ConvLayer>> convs;
   peanut::ConvLayer* stem = nullptr;
+  peanut::ConvLayer* stem_s2d = nullptr;   // the same conv on the 2x2 space-to-depth input (rcnn_api.hip), when applicable
   struct Block { peanut::ConvLayer *shortcut, *c1, *c2, *c3; };
   std::vector<std::vector<Block>> stages;
   peanut::ConvLayer *lateral[4] = {nullptr}, *output[4] = {nullptr};   // levels 2..5
