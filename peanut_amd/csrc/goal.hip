@@ -9,7 +9,8 @@
 // mirrored operation by operation, in double) is solved by relaxation, arranged so that every stage provably ends:
 //
 //   * tiles: the map is cut into 32x32 tiles; a workgroup stages a tile plus a 2-cell halo in LDS and sweeps it
-//     (Jacobi, two barriers per sweep, 4 cells per lane) until nothing in the tile changes; a tile that changed wakes
+//     (Jacobi, two barriers per sweep, 4 cells per lane, re-evaluating only cells whose stencil saw a change in the
+//     previous sweep) until nothing in the tile changes; a tile that changed wakes
 //     its four neighbours for the next round (the stencil is axis-aligned: no diagonal dependency); rounds are plain
 //     launches over the tile grid in which sleeping tiles exit at once; the host reads one counter every few rounds;
 //   * stage A, first order: u <- min(u, update(u)) from +inf.  Monotone, hence convergent, to the unique first-order
@@ -128,16 +129,24 @@ __device__ __forceinline__ double update_cell(const AxisTerm& y, const AxisTerm&
 }
 
 // SECOND = false: stage A (first order, monotone).  SECOND = true: stage B (second order on the graph given by ord).
+// Jacobi sweeps of the tile in LDS.  A cell is only re-evaluated when one of the cells its stencil reads changed in the
+// previous sweep (the update is a pure function of those and of its own value, so skipping it changes nothing): once
+// the tile is loaded, the work follows the front -- a band a few cells wide -- instead of all 1024 cells.  Lanes are
+// laid out as 8 x 8 blocks (wave w, pass k -> block 4w + k), so that a band in any direction leaves most wave passes
+// with no lane to evaluate.  `active_clear` (the flags of the round after next) is wiped here, one byte per tile,
+// which saves a fill launch per round.
 template <bool SECOND>
 __global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dist, const double* __restrict__ ord,
                                                         const unsigned char* __restrict__ state, int H, int W, int tiles_x, int tiles_y,
                                                         const unsigned char* __restrict__ active_in, unsigned char* __restrict__ active_out,
-                                                        unsigned int* __restrict__ changed_tiles) {
+                                                        unsigned char* __restrict__ active_clear, unsigned int* __restrict__ changed_tiles) {
   const int tile = blockIdx.x;
+  if (threadIdx.x == 0) active_clear[tile] = 0;
   if (!active_in[tile]) return;
   __shared__ double d[LT][LT + 1];
   __shared__ double o[SECOND ? LT : 1][LT + 1];
   __shared__ unsigned char st[LT][LT + 4];
+  __shared__ unsigned char chg[2][LT][LT + 4];      // cells that changed in the previous / in this sweep (halo: never)
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int r0 = ty * TILE - HALO, c0 = tx * TILE - HALO;
   for (int i = threadIdx.x; i < LT * LT; i += 256) {
@@ -147,20 +156,32 @@ __global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dis
     d[ly][lx] = in ? dist[(size_t)r * W + c] : INFINITY;
     if (SECOND) o[ly][lx] = in ? ord[(size_t)r * W + c] : INFINITY;
     st[ly][lx] = in ? state[(size_t)r * W + c] : ST_MASKED;
+    chg[0][ly][lx] = 0;
+    chg[1][ly][lx] = 0;
   }
   __syncthreads();
-  const int lx = HALO + (threadIdx.x & 31), lyb = HALO + (threadIdx.x >> 5);   // cells (lyb + 8k, lx), k = 0..3
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bly = HALO + (lane >> 3), blx = HALO + (lane & 7);      // cell of pass k: block 4 * wave + k of the 4 x 4 blocks
   bool ever = false;
   int sweeps = 0;
   for (; sweeps < MAX_SWEEPS; ++sweeps) {
+    const int cur = sweeps & 1;
     double nv[4];
+    bool chk[4];
     bool ch = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ly = lyb + 8 * k;
+      const int blk = 4 * wave + k;
+      const int ly = bly + 8 * (blk >> 2), lx = blx + 8 * (blk & 3);
       const double old = d[ly][lx];
       nv[k] = old;
-      if (st[ly][lx] == ST_FREE) {
+      chk[k] = false;
+      bool need = sweeps == 0;        // a tile wakes because a neighbour changed its halo: everything once
+      if (!need) {
+        need = chg[cur][ly - 1][lx] | chg[cur][ly + 1][lx] | chg[cur][ly][lx - 1] | chg[cur][ly][lx + 1];
+        if (SECOND) need |= chg[cur][ly - 2][lx] | chg[cur][ly + 2][lx] | chg[cur][ly][lx - 2] | chg[cur][ly][lx + 2];
+      }
+      if (need && st[ly][lx] == ST_FREE) {
         double u;
         if (SECOND) {
           // a neighbour feeds the cell only if it precedes it in `ord`; the second one only if it precedes the first
@@ -179,20 +200,27 @@ __global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dis
           u = fmin(u, old);
         }
         nv[k] = u;
-        ch |= (u != old);
+        chk[k] = u != old;
+        ch |= chk[k];
       }
     }
     const int any = __syncthreads_or(ch);
     if (!any) break;
     ever = true;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d[lyb + 8 * k][lx] = nv[k];
+    for (int k = 0; k < 4; ++k) {
+      const int blk = 4 * wave + k;
+      const int ly = bly + 8 * (blk >> 2), lx = blx + 8 * (blk & 3);
+      d[ly][lx] = nv[k];
+      chg[cur ^ 1][ly][lx] = chk[k];
+    }
     __syncthreads();
   }
   if (!ever) return;      // (uniform: `ever` derives from __syncthreads_or)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int ly = lyb + 8 * k, r = r0 + ly, c = c0 + lx;
+    const int blk = 4 * wave + k;
+    const int ly = bly + 8 * (blk >> 2), lx = blx + 8 * (blk & 3), r = r0 + ly, c = c0 + lx;
     if (r < H && c < W) dist[(size_t)r * W + c] = d[ly][lx];
   }
   if (threadIdx.x == 0) {
@@ -322,12 +350,13 @@ int run_stage(peanut_goal* g, int* cur, int* rounds_used, unsigned long long* to
   for (int round = 0; round < max_rounds; round += ROUNDS_PER_CHECK) {
     PEANUT_HIP_CHECK(hipMemsetAsync(counters, 0, ROUNDS_PER_CHECK * sizeof(unsigned int), s));
     for (int k = 0; k < ROUNDS_PER_CHECK; ++k) {
+      // three flag arrays in rotation: read, written (clean since the round before last), wiped for the next round
       unsigned char* in = act + (size_t)(*cur) * nt;
-      unsigned char* out = act + (size_t)(*cur ^ 1) * nt;
-      PEANUT_HIP_CHECK(hipMemsetAsync(out, 0, nt, s));
+      unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
+      unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
       hipLaunchKernelGGL(fmm_round_kernel<SECOND>, dim3(nt), dim3(256), 0, s, (double*)g->dist.p, (const double*)g->order.p,
-                         (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, counters + k);
-      *cur ^= 1;
+                         (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
+      *cur = (*cur + 1) % 3;
     }
     PEANUT_HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, s));
     PEANUT_HIP_CHECK(hipStreamSynchronize(s));
@@ -340,9 +369,9 @@ int run_stage(peanut_goal* g, int* cur, int* rounds_used, unsigned long long* to
 
 int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* seed_mask, int seed_r, int seed_c, hipStream_t s) {
   const int H = g->H, W = g->W, n = H * W, nt = g->tiles_x * g->tiles_y;
-  unsigned char* act = (unsigned char*)g->active.p;     // two flag arrays, ping-pong
-  unsigned char* seed_tiles = act + 2 * (size_t)nt;     // third array: the tiles that hold seeds
-  PEANUT_HIP_CHECK(hipMemsetAsync(act, 0, 3 * (size_t)nt, s));
+  unsigned char* act = (unsigned char*)g->active.p;     // three flag arrays in rotation (run_stage)
+  unsigned char* seed_tiles = act + 3 * (size_t)nt;     // fourth array: the tiles that hold seeds
+  PEANUT_HIP_CHECK(hipMemsetAsync(act, 0, 4 * (size_t)nt, s));
   hipLaunchKernelGGL(fmm_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, trav, seed_mask, seed_r, seed_c, H, W,
                      (unsigned char*)g->state.p, (double*)g->dist.p, seed_tiles, g->tiles_x);
   int cur = 0, rounds = 0;
@@ -356,7 +385,7 @@ int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* 
     PEANUT_HIP_CHECK(hipMemcpyAsync(g->order.p, g->dist.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (pass == 0) {      // from the seeds again
       hipLaunchKernelGGL(fmm_restart_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned char*)g->state.p, n, (double*)g->dist.p);
-      PEANUT_HIP_CHECK(hipMemsetAsync(act, 0, 2 * (size_t)nt, s));
+      PEANUT_HIP_CHECK(hipMemsetAsync(act, 0, 3 * (size_t)nt, s));
       cur = 0;
       PEANUT_HIP_CHECK(hipMemcpyAsync(act, seed_tiles, nt, hipMemcpyDeviceToDevice, s));
     } else {              // warm start: every tile re-examines its cells under the new ordering
@@ -385,7 +414,7 @@ int peanut_goal_create(peanut_goal_t** out, int full_h, int full_w, int col_rad)
   const size_t n = (size_t)full_h * full_w;
   int rc;
   if ((rc = g->trav.ensure(n)) || (rc = g->state.ensure(n)) || (rc = g->dist.ensure(n * sizeof(double))) ||
-      (rc = g->order.ensure(n * sizeof(double))) || (rc = g->active.ensure(3 * (size_t)g->tiles_x * g->tiles_y)) || (rc = g->counters.ensure(ROUNDS_PER_CHECK * sizeof(unsigned int))) ||
+      (rc = g->order.ensure(n * sizeof(double))) || (rc = g->active.ensure(4 * (size_t)g->tiles_x * g->tiles_y)) || (rc = g->counters.ensure(ROUNDS_PER_CHECK * sizeof(unsigned int))) ||
       (rc = g->maxbits.ensure(sizeof(unsigned long long))) || (rc = g->wt_new.ensure(n * sizeof(double))) ||
       (rc = g->wt_last.ensure(n * sizeof(double))) || (rc = g->value.ensure(n * sizeof(double))) || (rc = g->sum.ensure(sizeof(double))) ||
       (rc = g->partial.ensure(1024 * sizeof(ArgMax))) || (rc = g->out_idx.ensure(2 * sizeof(int))) || (rc = g->out_val.ensure(2 * sizeof(double))))

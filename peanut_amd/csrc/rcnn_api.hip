@@ -301,12 +301,13 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   }
   rel(prev);
   p[4] = make_act(ar, B, (p[3].H - 1) / 2 + 1, (p[3].W - 1) / 2 + 1, p[3].C);
-  { ROp op; op.kind = R_SUBSAMPLE; op.name = "p6"; op.kernel = "subsample2"; op.in = p[3]; op.out = p[4]; op.ext_slot = 4; pl->ops.push_back(op); }
+  { ROp op; op.kind = R_SUBSAMPLE; op.name = "p6"; op.kernel = "subsample2"; op.in = p[3]; op.out = p[4]; op.ext_slot = 4; op.in_ext_slot = 3; pl->ops.push_back(op); }
   // RPN head on p2..p6
   for (int lvl = 0; lvl < 5; ++lvl) {
     pl->lvl_h[lvl] = p[lvl].H; pl->lvl_w[lvl] = p[lvl].W;
     Act t = conv_out_act(ar, h->rpn_conv, p[lvl]);
     push_rconv(*pl, ar, h->rpn_conv, p[lvl], nullptr, t);
+    pl->ops.back().in_ext_slot = lvl;
     Act o = conv_out_act(ar, h->rpn_obj, t);
     push_rconv(*pl, ar, h->rpn_obj, t, nullptr, o, 5 + lvl);
     Act dl = conv_out_act(ar, h->rpn_delta, t);
@@ -421,6 +422,9 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
     if (slot < 10) return objectness ? objectness[slot - 5] : nullptr;
     return deltas ? deltas[slot - 10] : nullptr;
   };
+  // outputs the caller asked for are written in place (and read from there by the ops that consume them)
+  auto OUT = [&](const ROp& op) -> float* { float* e = ext(op.ext_slot); return e ? e : P(op.out); };
+  auto IN = [&](const ROp& op) -> float* { float* e = ext(op.in_ext_slot); return e ? e : P(op.in); };
   for (const auto& op : pl->ops) {
     switch (op.kind) {
       case R_PREPROCESS: {
@@ -437,9 +441,9 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
       }
       case R_CONV: {
         ConvArgs a{};
-        a.x = P(op.in);
+        a.x = IN(op);
         a.res = op.has_res ? P(op.res) : nullptr;
-        a.y = P(op.out);
+        a.y = OUT(op);
         a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = op.out.H; a.Wo = op.out.W;
         a.ws = P(pl->splitk); a.ws_floats = kSplitKScratchFloats;
         if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, s))) return rc;
@@ -457,13 +461,11 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
       }
       case R_SUBSAMPLE: {
         const long long total = (long long)op.out.B * op.out.H * op.out.W * (op.out.C / 4);
-        hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, P(op.in), P(op.out), op.in.H, op.in.W,
+        hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, IN(op), OUT(op), op.in.H, op.in.W,
                            op.in.C, op.out.H, op.out.W, total);
         break;
       }
     }
-    if (float* dst = ext(op.ext_slot))
-      PEANUT_HIP_CHECK(hipMemcpyAsync(dst, P(op.out), op.out.bytes, hipMemcpyDeviceToDevice, s));
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_rcnn_forward_front: ") + hipGetErrorString(e));

@@ -17,6 +17,7 @@ struct ROp {
   double flops = 0;
   float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
   int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
+  int in_ext_slot = -1;       // the input is the caller-owned output of that slot (read there when the caller gave a buffer)
 };
 
 struct RPlan {
