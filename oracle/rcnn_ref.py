@@ -277,14 +277,80 @@ def roi_align(feat: torch.Tensor, rois: torch.Tensor, scale: float, P: int, samp
 import numpy as np  # noqa: E402  (used by roi_align's fp32 coordinate arithmetic)
 
 
-def roi_pool(pyr: Dict[str, torch.Tensor], rois: torch.Tensor, P: int) -> torch.Tensor:
+def roi_align_vec(feat: torch.Tensor, rois: torch.Tensor, scale: float, P: int, sampling_ratio=0, aligned=True, chunk=64):
+    """The same ROIAlign, vectorised over rois / bins / channels -- the arithmetic of ``roi_align`` above operation by
+    operation (fp32 coordinates, weights formed in double and rounded to fp32, the four corner terms added left to right,
+    samples accumulated in (iy, ix) order, one division by the sample count), so the two agree to the bit
+    (tests/test_oracles_cpu.py); rois are grouped by their sampling grid (gh, gw).  For inputs the loop form cannot
+    finish in reasonable time (1000 proposals per image)."""
+    N, C = rois.shape[0], feat.shape[1]
+    H, W = feat.shape[2:]
+    out = torch.zeros((N, C, P, P))
+    if N == 0:
+        return out
+    f32 = torch.float32
+    r = rois.to(f32)
+    sc, off, Pf = torch.tensor(scale, dtype=f32), torch.tensor(0.5 if aligned else 0.0, dtype=f32), torch.tensor(float(P), dtype=f32)
+    sw, sh, ew, eh = r[:, 1] * sc - off, r[:, 2] * sc - off, r[:, 3] * sc - off, r[:, 4] * sc - off
+    rw, rh = ew - sw, eh - sh
+    if not aligned:
+        rw, rh = rw.clamp(min=1.0), rh.clamp(min=1.0)
+    bh, bw = rh / Pf, rw / Pf
+    gh = torch.ceil(rh / Pf).to(torch.int64) if sampling_ratio <= 0 else torch.full((N,), sampling_ratio, dtype=torch.int64)
+    gw = torch.ceil(rw / Pf).to(torch.int64) if sampling_ratio <= 0 else torch.full((N,), sampling_ratio, dtype=torch.int64)
+    bidx = r[:, 0].to(torch.int64)
+    flat = feat.permute(0, 2, 3, 1).reshape(feat.shape[0] * H * W, C)         # [B*H*W, C]
+    pidx = torch.arange(P, dtype=f32)
+
+    def axis(start, binsz, g, i, size):
+        """coordinate of sample i of every bin along one axis -> (valid, low index, high index, l (double), h (double))"""
+        gf = torch.tensor(float(g), dtype=f32)
+        c = start[:, None] + pidx[None, :] * binsz[:, None] + (torch.tensor(i + 0.5, dtype=f32) * binsz / gf)[:, None]   # [n, P] fp32
+        valid = ~((c < -1.0) | (c > size))
+        c = c.clamp(min=0.0)
+        lo = c.to(torch.int64)                                  # int(y) of a non-negative float
+        top = lo >= size - 1
+        lo = torch.where(top, torch.full_like(lo, size - 1), lo)
+        hi = torch.where(top, lo, lo + 1)
+        cd = torch.where(top, lo.to(torch.float64), c.to(torch.float64))
+        l = cd - lo.to(torch.float64)
+        return valid, lo, hi, l, 1.0 - l
+
+    keys = gh * 100000 + gw
+    for key in torch.unique(keys).tolist():
+        sel_all = torch.nonzero(keys == key).flatten()
+        g_h, g_w = int(key // 100000), int(key % 100000)
+        count = max(g_h * g_w, 1)
+        for c0 in range(0, len(sel_all), chunk):
+            sel = sel_all[c0:c0 + chunk]
+            n = len(sel)
+            base = (bidx[sel] * (H * W))[:, None, None]
+            acc = torch.zeros((n, P, P, C))
+            for iy in range(g_h):
+                vy, yl, yh, ly, hy = axis(sh[sel], bh[sel], g_h, iy, H)
+                for ix in range(g_w):
+                    vx, xl, xh, lx, hx = axis(sw[sel], bw[sel], g_w, ix, W)
+                    valid = (vy[:, :, None] & vx[:, None, :])[..., None]          # [n, P, P, 1]
+
+                    def corner(yi, xi, wy, wx):
+                        v = flat[(base + yi[:, :, None] * W + xi[:, None, :]).reshape(-1)].view(n, P, P, C)
+                        wgt = (wy[:, :, None] * wx[:, None, :]).to(f32)[..., None]  # double product, then fp32
+                        return wgt * v
+                    val = corner(yl, xl, hy, hx) + corner(yl, xh, hy, lx) + corner(yh, xl, ly, hx) + corner(yh, xh, ly, lx)
+                    acc = acc + torch.where(valid, val, torch.zeros(()))
+            out[sel] = (acc / count).permute(0, 3, 1, 2)
+    return out
+
+
+def roi_pool(pyr: Dict[str, torch.Tensor], rois: torch.Tensor, P: int, vectorised: bool = False) -> torch.Tensor:
     """ROIPooler over p2..p5 (scales 1/4..1/32), ROIAlignV2, sampling_ratio 0."""
     lv = assign_levels(rois[:, 1:])
     out = torch.zeros((rois.shape[0], pyr["p2"].shape[1], P, P))
+    fn = roi_align_vec if vectorised else roi_align
     for l, k in enumerate(("p2", "p3", "p4", "p5")):
         inds = torch.nonzero(lv == l).flatten()
         if len(inds):
-            out[inds] = roi_align(pyr[k], rois[inds], 1.0 / (4 * 2 ** l), P, 0, True)
+            out[inds] = fn(pyr[k], rois[inds], 1.0 / (4 * 2 ** l), P, 0, True)
     return out
 
 
@@ -340,9 +406,10 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw, thr: float) -> tor
     return paste_values(masks, boxes, hw) >= thr
 
 
-def inference(sd, img_bgr_u8: torch.Tensor, cfg: RcnnCfg):
+def inference(sd, img_bgr_u8: torch.Tensor, cfg: RcnnCfg, vectorised: bool = False):
     """GeneralizedRCNN.inference + detector_postprocess for a batch; list of dicts (pred_boxes, scores,
-    pred_classes, pred_masks bool [n,H,W]) at the ORIGINAL image resolution."""
+    pred_classes, pred_masks bool [n,H,W]) at the ORIGINAL image resolution.  ``vectorised``: ROIAlign through
+    ``roi_align_vec`` (same values; needed at the full 1000 proposals per image)."""
     B, H, W, _ = img_bgr_u8.shape
     nh, nw = resized_hw(H, W, cfg)
     pyr, obj, deltas = forward_front(sd, img_bgr_u8, cfg)
@@ -352,11 +419,11 @@ def inference(sd, img_bgr_u8: torch.Tensor, cfg: RcnnCfg):
         for n in range(B):
             pb = props[n][0]
             rois = torch.cat([torch.full((len(pb), 1), float(n)), pb], 1)
-            scores, dl = box_head(sd, roi_pool(pyr, rois, cfg.box_pooler_resolution))
+            scores, dl = box_head(sd, roi_pool(pyr, rois, cfg.box_pooler_resolution, vectorised))
             boxes = apply_deltas(dl, pb, cfg.roi_bbox_weights)
             b, s, c = fast_rcnn_inference_single_image(boxes, F.softmax(scores, dim=-1), (nh, nw), cfg)
             rois = torch.cat([torch.full((len(b), 1), float(n)), b], 1)
-            logits = mask_head(sd, roi_pool(pyr, rois, cfg.mask_pooler_resolution), cfg)
+            logits = mask_head(sd, roi_pool(pyr, rois, cfg.mask_pooler_resolution, vectorised), cfg)
             probs = logits[torch.arange(len(b)), c].sigmoid() if len(b) else logits[:, 0]
             sx, sy = W / nw, H / nh
             ob = b * torch.tensor([sx, sy, sx, sy])

@@ -125,3 +125,20 @@ def test_nms_iou_matches_published_known_answers():
     scores = torch.tensor([0.6370, 0.7569, 0.3966])
     keep = rcnn_ref.batched_nms(boxes, scores, torch.zeros(3, dtype=torch.int64), 0.2)
     assert keep.tolist() == [1]
+
+
+def test_vectorised_roi_align_equals_the_loop_form():
+    """oracle/rcnn_ref.roi_align_vec (used where 1000 proposals per image make the loop form impractical) against
+    roi_align -- itself pinned on detectron2's known answers above -- on boxes inside, across and outside the map,
+    sub-pixel boxes, both alignment conventions, adaptive and fixed sampling: equal to the bit."""
+    import torch
+    from oracle import rcnn_ref
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn((2, 8, 25, 34), generator=g)
+    rois = torch.tensor([[0, 1.2, 3.4, 60.7, 55.1], [1, -5.0, -3.0, 20.0, 30.0], [0, 100.0, 80.0, 140.0, 100.5], [1, 10, 10, 10.5, 10.2],
+                         [0, 0, 0, 135.9, 99.9], [1, 130, 90, 150, 120], [0, 33.3, 7.7, 34.1, 90.0]])
+    for scale, P, sr, aligned in ((0.25, 7, 0, True), (0.25, 14, 0, True), (0.125, 7, 2, False), (0.25, 4, 0, False), (1.0, 3, 0, True)):
+        assert torch.equal(rcnn_ref.roi_align(feat, rois, scale, P, sr, aligned), rcnn_ref.roi_align_vec(feat, rois, scale, P, sr, aligned, chunk=3))
+    pyr = {k: torch.randn((2, 4, 64 >> i, 80 >> i), generator=g) for i, k in enumerate(("p2", "p3", "p4", "p5"))}
+    r = torch.tensor([[0, 4.0, 4.0, 40.0, 60.0], [1, 0.0, 0.0, 300.0, 250.0], [0, 10.0, 20.0, 130.0, 140.0], [1, 50.0, 50.0, 52.0, 51.0]])
+    assert torch.equal(rcnn_ref.roi_pool(pyr, r, 7), rcnn_ref.roi_pool(pyr, r, 7, vectorised=True))

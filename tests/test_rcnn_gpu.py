@@ -375,3 +375,66 @@ def test_semantic_entry_equals_inference_plus_accumulation(small_net):
         assert torch.equal(got, want)
         assert float(got[..., n_cats].abs().max()) == 0.0
     assert float(net.semantic(img, n_cats, 0.0, 0.0, None).sum()) > 0
+
+
+def test_r101_batch16_full_proposals_against_the_vectorised_oracle():
+    """The configuration BASELINE.json quotes for stage 1 -- R-101-FPN, sixteen 480x640 frames, 1000 pre- / post-NMS
+    proposals per level / image, 100 detections -- through ONE peanut_rcnn_inference call against the restatement with
+    its vectorised ROIAlign (bit-equal to the loop form, tests/test_oracles_cpu.py): the same detections -- every one
+    of the oracle's matched one to one by a detection of the same class with score within 1e-4 and box within 0.05 px,
+    ranks differing only between detections whose scores are that close (fp32 summation order decides such ties) --
+    and pasted masks IoU >= 0.98 per image."""
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import MaskRCNN
+    from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+    cfg = RcnnCfg(score_thresh_test=0.5)
+    assert cfg.depth == 101 and cfg.rpn_pre_nms_topk == 1000 and cfg.rpn_post_nms_topk == 1000 and cfg.detections_per_image == 100
+    sd = make_seeded_rcnn_state_dict(cfg, seed=5)
+    g = torch.Generator().manual_seed(17)
+    img = torch.randint(0, 256, (16, 480, 640, 3), generator=g, dtype=torch.uint8)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))     # the oracle is thousands of small ops: a 256-thread pool only adds latency
+    try:
+        with torch.no_grad():
+            ref = rcnn_ref.inference(sd, img, cfg, vectorised=True)
+    finally:
+        torch.set_num_threads(threads)
+    net = MaskRCNN(cfg, sd)
+    got = net.inference(img.cuda())
+    assert len(got) == len(ref) == 16
+    n_total, n_moved, worst_box, worst_score, worst_iou = 0, 0, 0.0, 0.0, 1.0
+    for gi, ri in zip(got, ref):
+        assert len(ri["proposals"]) == 1000
+        n = len(ri["scores"])
+        assert len(gi["scores"]) == n > 0
+        gs, gb, gc = gi["scores"].cpu(), gi["pred_boxes"].cpu(), gi["pred_classes"].cpu()
+        rs, rb, rc = ri["scores"], ri["pred_boxes"], ri["pred_classes"]
+        ok = (gc[None, :] == rc[:, None]) & ((gs[None, :] - rs[:, None]).abs() <= 1e-4) & \
+             ((gb[None, :, :] - rb[:, None, :]).abs().amax(2) <= 5e-2)                      # [ref i, got j]
+        perm = torch.full((n,), -1, dtype=torch.int64)
+        taken = torch.zeros(n, dtype=torch.bool)
+        for i in range(n):
+            cand = torch.nonzero(ok[i] & ~taken).flatten()
+            assert len(cand) > 0, f"oracle detection {i} (class {int(rc[i])}, score {float(rs[i]):.6f}) has no counterpart"
+            j = int(cand[(cand - i).abs().argmin()])
+            perm[i] = j
+            taken[j] = True
+        moved = torch.nonzero(perm != torch.arange(n)).flatten()
+        for i in moved.tolist():     # a rank can only differ inside a run of near-equal scores
+            lo, hi = min(i, int(perm[i])), max(i, int(perm[i]))
+            assert float(rs[lo] - rs[hi]) <= 2e-4
+        n_moved += len(moved)
+        worst_score = max(worst_score, (gs[perm] - rs).abs().max().item())
+        worst_box = max(worst_box, (gb[perm] - rb).abs().max().item())
+        gm, rm = gi["pred_masks"].cpu()[perm], ri["pred_masks"]
+        inter, union = (gm & rm).sum().item(), (gm | rm).sum().item()
+        worst_iou = min(worst_iou, inter / max(union, 1))
+        n_total += n
+    print(f"R-101 B=16: {n_total} detections ({n_moved} at another rank inside a score tie), max |score diff| {worst_score:.2e}, "
+          f"max |box diff| {worst_box:.2e} px, min mask IoU {worst_iou:.4f}")
+    assert worst_score <= 1e-4 and worst_box <= 5e-2 and worst_iou >= 0.98 and n_moved <= n_total // 20
+    # the fused semantic entry on the same batch: what inference + accumulation give
+    from peanut_amd.segmentation import accumulate_instances
+    sem = net.semantic(img.cuda(), cfg.num_classes, 0.5, 0.5, None)
+    for b in (0, 7, 15):
+        assert torch.equal(sem[b], accumulate_instances(got[b]["pred_masks"], got[b]["pred_classes"], got[b]["scores"], cfg.num_classes, 0.5, 0.5, None))
