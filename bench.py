@@ -363,11 +363,26 @@ def main():
     # logging-only collective: collate the predicted maps of the last step (outside the timed steps; timed on its own)
     gather_ms = None
     if world > 1 or args.config == 5:
-        pdist.allgather_maps(out)                      # warm-up (communicator set-up)
+        gather = pdist.allgather_maps                  # peanut_allgather_maps (the library's RCCL entry point)
+        gather_path = "peanut_allgather_maps (RCCL)"
+        try:
+            gather(out)                                # warm-up (communicator set-up, collective)
+        except Exception as e:                         # reporting only: never lose the bench line over the logging collective
+            import torch.distributed as tdist
+
+            def gather(t, _e=e):
+                full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                if world > 1:
+                    tdist.all_gather_into_tensor(full, t.contiguous())
+                else:
+                    full.copy_(t)
+                return full
+            gather_path = f"torch.distributed all_gather_into_tensor (library path failed: {e})"
+            gather(out)
         torch.cuda.synchronize()
         pdist.barrier()
         tg = time.perf_counter()
-        allmaps = pdist.allgather_maps(out)
+        allmaps = gather(out)
         torch.cuda.synchronize()
         gather_ms = pdist.max_over_ranks((time.perf_counter() - tg) * 1e3, device=dev)
         assert allmaps.shape[0] == world * B
@@ -423,6 +438,7 @@ def main():
         if gather_ms is not None:
             line["allgather_maps_ms"] = round(gather_ms, 3)
             line["allgather_maps_bytes_per_rank"] = int(out.numel() * 4)
+            line["allgather_maps_path"] = gather_path
         print(json.dumps(line), flush=True)
     pdist.barrier()
     if torch.distributed.is_initialized():
