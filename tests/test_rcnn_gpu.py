@@ -438,3 +438,18 @@ def test_r101_batch16_full_proposals_against_the_vectorised_oracle():
     sem = net.semantic(img.cuda(), cfg.num_classes, 0.5, 0.5, None)
     for b in (0, 7, 15):
         assert torch.equal(sem[b], accumulate_instances(got[b]["pred_masks"], got[b]["pred_classes"], got[b]["scores"], cfg.num_classes, 0.5, 0.5, None))
+
+
+def test_no_detections_gives_an_empty_result_and_a_zero_semantic_map(small_net):
+    """Score threshold above every class score: no detection survives; inference returns empty instance lists and the
+    semantic entry an all-zero map (the reference's loop body never runs, segmentation.py:46-60)."""
+    from peanut_amd.rcnn import MaskRCNN
+    s = small_net
+    cfg = _small_cfg(score_thresh_test=0.9999)
+    net = MaskRCNN(cfg, s["sd"])
+    img = s["img"].cuda()
+    res = net.inference(img)
+    assert [len(r["scores"]) for r in res] == [0, 0]
+    assert all(r["pred_masks"].shape == (0, img.shape[1], img.shape[2]) for r in res)
+    sem = net.semantic(img, cfg.num_classes, 0.5, 0.5, None)
+    assert sem.shape == (2, img.shape[1], img.shape[2], cfg.num_classes + 1) and float(sem.abs().max()) == 0.0
