@@ -236,6 +236,13 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], i
 int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
                               float* const* objectness, float* const* deltas, void* stream);
 
+/* The detector's input transform alone (DefaultPredictor.__call__: ResizeShortestEdge.get_transform(img).apply_image,
+ * i.e. PIL.Image.resize(BILINEAR) for uint8 frames -- Pillow's two-pass fixed-point resample, restated bit for bit --
+ * then GeneralizedRCNN.preprocess_image: (x - PIXEL_MEAN) / PIXEL_STD, zero padding to the size-divisible canvas).
+ * img_bgr: device uint8 [B,H,W,3]; out_nchw: device float [B,3,Hp,Wp] (Hp, Wp from peanut_rcnn_plan).  The front end
+ * computes the same pixels internally (in the layout its stem wants); this export exists for bisecting and parity. */
+int peanut_rcnn_preprocess(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* out_nchw, void* stream);
+
 /* The whole detector: what `DefaultPredictor(img)["instances"]` yields (nav/agent/utils/segmentation.py:45) --
  * GeneralizedRCNN.inference + detector_postprocess as configured by mask_rcnn_R_101_cat9.yaml -- for a batch of frames.
  * Needs a handle created with the roi_heads.* tensors in the state dict (box_head.fc1/fc2, box_predictor.cls_score /

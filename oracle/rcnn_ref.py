@@ -17,22 +17,72 @@ PIL's fixed-point BILINEAR filter; here it is float bilinear (half-pixel centres
 Only tests/, smoke() and bench baselines may import this module."""
 from __future__ import annotations
 
+import math
 from typing import Dict, List
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from peanut_amd.rcnn_weights import RcnnCfg, padded_hw, resized_hw
 
 
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """Pillow ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` (src/libImaging/Resample.c) for the bilinear filter:
+    per output index the first source index, the tap count and the fixed-point weights (22 fractional bits)."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ik = np.zeros((out_size, ksize), np.int64)
+    bounds = np.zeros((out_size, 2), np.int64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = []
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w.append(1.0 - a if a < 1.0 else 0.0)
+        ww = sum(w)         # left to right, as the C loop adds them
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            ik[xx, x] = int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return ik, bounds
+
+
+def _pil_resample_axis(img: np.ndarray, out_size: int, axis: int) -> np.ndarray:
+    ik, b = pil_bilinear_coeffs(img.shape[axis], out_size)
+    x = np.moveaxis(img, axis, 0).astype(np.int64)
+    acc = np.full((out_size,) + x.shape[1:], 1 << (_PIL_PRECISION_BITS - 1), np.int64)
+    for t in range(ik.shape[1]):                                              # taps; rows past a bound carry weight 0
+        src = np.minimum(b[:, 0] + t, x.shape[0] - 1)
+        acc += x[src] * ik[:, t].reshape((-1,) + (1,) * (x.ndim - 1))
+    return np.moveaxis(np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8), 0, axis)
+
+
+def pil_resize_bilinear_u8(img: np.ndarray, nh: int, nw: int) -> np.ndarray:
+    """``PIL.Image.fromarray(img).resize((nw, nh), Image.BILINEAR)`` restated (what detectron2's ResizeTransform
+    applies to uint8 images): Pillow's two-pass ImagingResample -- horizontal, then vertical over the uint8 result of
+    the first pass, fixed-point coefficients, round half up, clip.  uint8 [H,W,C] -> uint8 [nh,nw,C].  Equal to
+    Pillow's own output (tests/test_oracles_cpu.py, tests/golden/pil_resize_golden.npz)."""
+    t = _pil_resample_axis(img, nw, 1) if nw != img.shape[1] else img
+    return _pil_resample_axis(t, nh, 0) if nh != img.shape[0] else t
+
+
 def preprocess(img_bgr_u8: torch.Tensor, cfg: RcnnCfg) -> torch.Tensor:
-    """uint8 [B,H,W,3] BGR -> float32 [B,3,Hp,Wp]: resize (yaml :28-30), (x - PIXEL_MEAN) / PIXEL_STD
-    (:82-89), zero-pad to a multiple of 32 (ImageList.from_tensors with the FPN's size_divisibility)."""
+    """uint8 [B,H,W,3] BGR -> float32 [B,3,Hp,Wp]: resize (yaml :28-30; PIL bilinear as ResizeShortestEdge applies it),
+    (x - PIXEL_MEAN) / PIXEL_STD (:82-89), zero-pad to a multiple of 32 (ImageList.from_tensors with the FPN's
+    size_divisibility)."""
     b, h, w, _ = img_bgr_u8.shape
     nh, nw = resized_hw(h, w, cfg)
-    x = img_bgr_u8.permute(0, 3, 1, 2).float()
-    x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)
-    x = torch.floor(x + 0.5).clamp(0, 255)                                    # back to uint8 values (PIL output)
+    x = torch.stack([torch.from_numpy(pil_resize_bilinear_u8(im.numpy(), nh, nw)) for im in img_bgr_u8])
+    x = x.permute(0, 3, 1, 2).float()
     mean = torch.tensor(cfg.pixel_mean).view(1, 3, 1, 1)
     std = torch.tensor(cfg.pixel_std).view(1, 3, 1, 1)
     x = (x - mean) / std

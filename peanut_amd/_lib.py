@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 6     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 7     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -93,6 +93,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_int * 10), C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "peanut_rcnn_forward_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P),
                                             C.POINTER(_P), _P]),
+    "peanut_rcnn_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_rcnn_inference": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "peanut_rcnn_semantic": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int32), _P,
                                        C.POINTER(C.c_int), _P, _P, _P, _P, _P]),

@@ -502,7 +502,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
 extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
-int peanut_abi_version(void) { return 6; }
+int peanut_abi_version(void) { return 7; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {

@@ -12,6 +12,7 @@
 // restatement oracle/rcnn_ref.py ("parity unpinned" w.r.t. the reference).
 #include <string.h>
 
+#include <math.h>
 #include <stdlib.h>
 #include "rcnn_internal.h"
 
@@ -22,36 +23,79 @@ namespace {
 // (zero in the padded border and in channels 3..15).  One thread per output pixel.
 struct Norm3 { float mean[3], inv_std[3]; };
 
-// one pixel of the network input: bilinear resize of the uint8 frame (rounded back to uint8, as the resized image is
-// uint8 again), then (x - mean) / std; zeros in the padding up to the size-divisible canvas
+// one pixel of the network input: the frame resized as detectron2's ResizeShortestEdge does it for uint8 images --
+// PIL.Image.resize(BILINEAR), i.e. Pillow's ImagingResample (src/libImaging/Resample.c, 8 bits per channel):
+// a horizontal pass, then a vertical pass over its uint8 result, each a convolution with fixed-point coefficients
+// (22 fractional bits, rounded half up, clipped to 0..255).  Both passes are evaluated here for one output pixel:
+// the <= ksy rows of the intermediate image it needs are recomputed on the fly (integer arithmetic: exact).  Then
+// (x - mean) / std; zeros in the padding up to the size-divisible canvas.  Tables: see resize_tables.
+struct ResizeTab { const int* x; const int* y; int ksx, ksy; };
+__device__ __forceinline__ int clip8_fixed(int acc) {
+  const int v = acc >> 22;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
 __device__ __forceinline__ float4 rcnn_input_pixel(const uint8_t* __restrict__ img, long long b, int y, int x, int H, int W, int nh,
-                                                   int nw, const Norm3& nm) {
+                                                   int nw, const Norm3& nm, const ResizeTab& rz) {
   if (y >= nh || x >= nw) return make_float4(0.f, 0.f, 0.f, 0.f);
-  // F.interpolate(bilinear, align_corners=False): src = (dst + 0.5) * in/out - 0.5, clamped at 0
-  const float sy = fmaxf(((float)y + 0.5f) * ((float)H / (float)nh) - 0.5f, 0.f);
-  const float sx = fmaxf(((float)x + 0.5f) * ((float)W / (float)nw) - 0.5f, 0.f);
-  int y0 = (int)sy, x0 = (int)sx;
-  if (y0 > H - 1) y0 = H - 1;
-  if (x0 > W - 1) x0 = W - 1;
-  const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
-  const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-  const uint8_t* p00 = img + ((b * H + y0) * W + x0) * 3;
-  const uint8_t* p01 = img + ((b * H + y0) * W + x1) * 3;
-  const uint8_t* p10 = img + ((b * H + y1) * W + x0) * 3;
-  const uint8_t* p11 = img + ((b * H + y1) * W + x1) * 3;
+  const int* tx = rz.x + (size_t)x * (2 + rz.ksx);
+  const int* ty = rz.y + (size_t)y * (2 + rz.ksy);
+  const int x0 = tx[0], nx = tx[1], y0 = ty[0], ny = ty[1];
+  int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+  for (int j = 0; j < ny; ++j) {
+    const uint8_t* row = img + ((b * H + (y0 + j)) * W + x0) * 3;
+    int h[3] = {1 << 21, 1 << 21, 1 << 21};
+    for (int i = 0; i < nx; ++i) {
+      const int k = tx[2 + i];
+      h[0] += (int)row[i * 3 + 0] * k; h[1] += (int)row[i * 3 + 1] * k; h[2] += (int)row[i * 3 + 2] * k;
+    }
+    const int k = ty[2 + j];
+    acc[0] += clip8_fixed(h[0]) * k; acc[1] += clip8_fixed(h[1]) * k; acc[2] += clip8_fixed(h[2]) * k;
+  }
   float c[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float f = hy * (hx * (float)p00[k] + lx * (float)p01[k]) + ly * (hx * (float)p10[k] + lx * (float)p11[k]);
-    const float u8 = fminf(fmaxf(floorf(f + 0.5f), 0.f), 255.f);
-    c[k] = (u8 - nm.mean[k]) * nm.inv_std[k];
-  }
+  for (int k = 0; k < 3; ++k) c[k] = ((float)clip8_fixed(acc[k]) - nm.mean[k]) * nm.inv_std[k];
   return make_float4(c[0], c[1], c[2], 0.f);
+}
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1, stretched by the scale when
+// shrinking), in double like the C original: row i of the table = {first source index, taps, ks weights}.
+static std::vector<int> resize_tables(int in_size, int out_size, int* ks_out) {
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const int ks = (int)ceil(support) * 2 + 1;
+  std::vector<int> tab((size_t)out_size * (2 + ks), 0);
+  std::vector<double> kk(ks);
+  const double ss = 1.0 / filterscale;
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double a = (x + xmin - center + 0.5) * ss;
+      if (a < 0.0) a = -a;
+      const double w = a < 1.0 ? 1.0 - a : 0.0;
+      kk[x] = w;
+      ww += w;
+    }
+    int* row = tab.data() + (size_t)xx * (2 + ks);
+    row[0] = xmin; row[1] = xmax;
+    for (int x = 0; x < xmax; ++x) {
+      const double v = ww != 0.0 ? kk[x] / ww : kk[x];
+      row[2 + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << 22)) : (int)(0.5 + v * (double)(1 << 22));
+    }
+  }
+  *ks_out = ks;
+  return tab;
 }
 
 __global__ __launch_bounds__(256) void rcnn_preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
                                                               int H, int W, int nh, int nw, int Hp, int Wp, Norm3 nm,
-                                                              long long total) {
+                                                              ResizeTab rz, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int x = (int)(i % Wp);
@@ -60,7 +104,23 @@ __global__ __launch_bounds__(256) void rcnn_preprocess_kernel(const uint8_t* __r
     const long long b = t / Hp;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* o = reinterpret_cast<float4*>(out + (size_t)i * 16);
-    o[0] = rcnn_input_pixel(img, b, y, x, H, W, nh, nw, nm); o[1] = z; o[2] = z; o[3] = z;
+    o[0] = rcnn_input_pixel(img, b, y, x, H, W, nh, nw, nm, rz); o[1] = z; o[2] = z; o[3] = z;
+  }
+}
+
+// operator-level export (peanut_rcnn_preprocess): the same pixels as plain NCHW [B,3,Hp,Wp], for bisecting / parity
+__global__ __launch_bounds__(256) void rcnn_preprocess_nchw_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
+                                                                   int H, int W, int nh, int nw, int Hp, int Wp, Norm3 nm,
+                                                                   ResizeTab rz, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long long t = i / Wp;
+    const int y = (int)(t % Hp);
+    const long long b = t / Hp;
+    const float4 v = rcnn_input_pixel(img, b, y, x, H, W, nh, nw, nm, rz);
+    float* o = out + ((size_t)b * 3 * Hp + y) * Wp + x;
+    o[0] = v.x; o[(size_t)Hp * Wp] = v.y; o[(size_t)2 * Hp * Wp] = v.z;
   }
 }
 
@@ -69,7 +129,7 @@ __global__ __launch_bounds__(256) void rcnn_preprocess_kernel(const uint8_t* __r
 // 16 (add_stem_s2d): 16 taps x 16 channels instead of 49 taps x 16 zero-padded channels in the implicit GEMM.
 __global__ __launch_bounds__(256) void rcnn_preprocess_s2d_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
                                                                   int H, int W, int nh, int nw, int Hp, int Wp, Norm3 nm,
-                                                                  long long total) {
+                                                                  ResizeTab rz, long long total) {
   const int H2 = Hp >> 1, W2 = Wp >> 1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -79,7 +139,7 @@ __global__ __launch_bounds__(256) void rcnn_preprocess_s2d_kernel(const uint8_t*
     const long long t = pix / W2;
     const int Y = (int)(t % H2);
     const long long b = t / H2;
-    reinterpret_cast<float4*>(out + (size_t)pix * 16)[q] = rcnn_input_pixel(img, b, 2 * Y + (q >> 1), 2 * X + (q & 1), H, W, nh, nw, nm);
+    reinterpret_cast<float4*>(out + (size_t)pix * 16)[q] = rcnn_input_pixel(img, b, 2 * Y + (q >> 1), 2 * X + (q & 1), H, W, nh, nw, nm, rz);
   }
 }
 
@@ -326,7 +386,17 @@ RPlan* get_rplan(peanut_rcnn* h, int B, int H, int W) {
   if (B <= 0 || H < 32 || W < 32) { set_error("rcnn: need B >= 1 and H, W >= 32"); return nullptr; }
   const std::string key = std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W);
   auto it = h->plans.find(key);
-  if (it == h->plans.end()) it = h->plans.emplace(key, build_rplan(h, B, H, W)).first;
+  if (it == h->plans.end()) {
+    auto pl = build_rplan(h, B, H, W);
+    const std::vector<int> tx = resize_tables(W, pl->nw, &pl->ksx), ty = resize_tables(H, pl->nh, &pl->ksy);
+    if (pl->rz_x.ensure(tx.size() * sizeof(int)) || pl->rz_y.ensure(ty.size() * sizeof(int)) ||
+        hipMemcpy(pl->rz_x.p, tx.data(), tx.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pl->rz_y.p, ty.data(), ty.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("rcnn: resize table upload failed");
+      return nullptr;
+    }
+    it = h->plans.emplace(key, std::move(pl)).first;
+  }
   return it->second.get();
 }
 
@@ -431,12 +501,13 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
         Norm3 nm;
         for (int k = 0; k < 3; ++k) { nm.mean[k] = h->cfg.pixel_mean[k]; nm.inv_std[k] = 1.0f / h->cfg.pixel_std[k]; }
         const long long total = (long long)B * pl->Hp * pl->Wp;   // one thread per input pixel in either layout
+        const ResizeTab rz{(const int*)pl->rz_x.p, (const int*)pl->rz_y.p, pl->ksx, pl->ksy};
         if (h->stem_s2d)
           hipLaunchKernelGGL(rcnn_preprocess_s2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, img_bgr, P(op.out), H, W, pl->nh,
-                             pl->nw, pl->Hp, pl->Wp, nm, total);
+                             pl->nw, pl->Hp, pl->Wp, nm, rz, total);
         else
           hipLaunchKernelGGL(rcnn_preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, s, img_bgr, P(op.out), H, W, pl->nh,
-                             pl->nw, pl->Hp, pl->Wp, nm, total);
+                             pl->nw, pl->Hp, pl->Wp, nm, rz, total);
         break;
       }
       case R_CONV: {
@@ -470,6 +541,20 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_rcnn_forward_front: ") + hipGetErrorString(e));
   return 0;
+}
+
+int peanut_rcnn_preprocess(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* out_nchw, void* stream) {
+  if (!h || !img_bgr || !out_nchw) return fail(PEANUT_EINVAL, "peanut_rcnn_preprocess: null argument");
+  RPlan* pl = get_rplan(h, B, H, W);
+  if (!pl) return PEANUT_EINVAL;
+  Norm3 nm;
+  for (int k = 0; k < 3; ++k) { nm.mean[k] = h->cfg.pixel_mean[k]; nm.inv_std[k] = 1.0f / h->cfg.pixel_std[k]; }
+  const long long total = (long long)B * pl->Hp * pl->Wp;
+  const ResizeTab rz{(const int*)pl->rz_x.p, (const int*)pl->rz_y.p, pl->ksx, pl->ksy};
+  hipLaunchKernelGGL(rcnn_preprocess_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img_bgr, out_nchw, H, W, pl->nh,
+                     pl->nw, pl->Hp, pl->Wp, nm, rz, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_rcnn_preprocess: ") + hipGetErrorString(e));
 }
 
 }  // extern "C"

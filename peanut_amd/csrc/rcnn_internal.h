@@ -26,6 +26,10 @@ struct RPlan {
   size_t bytes = 0;
   std::vector<ROp> ops;
   int lvl_h[5] = {0}, lvl_w[5] = {0};
+  // fixed-point coefficients of the resize (rcnn_api.hip: resize_tables): per output column / row the first source
+  // index, the tap count and `ks` int32 weights
+  DevBuf rz_x, rz_y;
+  int ksx = 0, ksy = 0;
 };
 
 

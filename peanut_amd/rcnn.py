@@ -392,6 +392,18 @@ class MaskRCNN(MaskRCNNFront):
             start += n
         return out
 
+    def preprocess(self, img_bgr: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] (device) -> float32 [B,3,Hp,Wp]: PIL-bilinear resize, normalisation, padding (``peanut_rcnn_preprocess``)."""
+        assert img_bgr.is_cuda and img_bgr.dtype == torch.uint8 and img_bgr.dim() == 4 and img_bgr.shape[3] == 3
+        img_bgr = img_bgr.contiguous()
+        B, H, W, _ = img_bgr.shape
+        Hp, Wp = self.plan(B, H, W)["padded"]
+        out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=img_bgr.device)
+        with torch.cuda.device(img_bgr.device):
+            rc = self._lib.peanut_rcnn_preprocess(self._h, img_bgr.data_ptr(), B, H, W, out.data_ptr(), _lib.current_stream_ptr(img_bgr.device))
+        _lib.check(rc, "peanut_rcnn_preprocess")
+        return out
+
     def semantic(self, img_bgr: torch.Tensor, n_cats: int, sem_pred_prob_thr: float, goal_thr: float, goal_cats=None):
         """``SemanticPredMaskRCNN.get_prediction`` for a batch (segmentation.py:41-62): img_bgr uint8 [B,H,W,3] (device)
         -> float32 [B,H,W,n_cats+1] per-category sums of the gated instance masks, in ONE ``peanut_rcnn_semantic`` call

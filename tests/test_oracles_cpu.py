@@ -142,3 +142,27 @@ def test_vectorised_roi_align_equals_the_loop_form():
     pyr = {k: torch.randn((2, 4, 64 >> i, 80 >> i), generator=g) for i, k in enumerate(("p2", "p3", "p4", "p5"))}
     r = torch.tensor([[0, 4.0, 4.0, 40.0, 60.0], [1, 0.0, 0.0, 300.0, 250.0], [0, 10.0, 20.0, 130.0, 140.0], [1, 50.0, 50.0, 52.0, 51.0]])
     assert torch.equal(rcnn_ref.roi_pool(pyr, r, 7), rcnn_ref.roi_pool(pyr, r, 7, vectorised=True))
+
+
+def test_pil_resize_restatement_is_pinned_on_pillow(golden_dir):
+    """detectron2 resizes uint8 frames with PIL (ResizeTransform.apply_image -> Image.resize(BILINEAR)); Pillow is not
+    part of the reference checkout, so oracle/rcnn_ref.pil_resize_bilinear_u8 restates its published two-pass fixed-point
+    algorithm.  Pinned on outputs of Pillow itself: the committed vectors (oracle/gen_golden_resize.py) and, where Pillow
+    is importable, a live comparison at the agent's geometry (480x640 -> 800x1067) and a downscale."""
+    import numpy as np
+    from oracle import rcnn_ref
+    z = np.load(os.path.join(golden_dir, "pil_resize_golden.npz"))
+    i = 0
+    while f"in{i}" in z:
+        want = z[f"out{i}"]
+        assert np.array_equal(rcnn_ref.pil_resize_bilinear_u8(z[f"in{i}"], want.shape[0], want.shape[1]), want), i
+        i += 1
+    assert i >= 5
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.RandomState(7)
+    for (h, w, nh, nw) in ((480, 640, 800, 1067), (600, 900, 400, 600)):
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(rcnn_ref.pil_resize_bilinear_u8(img, nh, nw), np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR)))

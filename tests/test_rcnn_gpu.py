@@ -1,8 +1,10 @@
 """Mask R-CNN front end (preprocess + R-101-FPN + RPN head) on HIP vs the torch restatement of
 detectron2's published modules (oracle/rcnn_ref.py).  PARITY UNPINNED w.r.t. the reference: detectron2 is
-absent from the reference checkout, so this pins the HIP path to the restatement only.
+absent from the reference checkout, so this pins the HIP path to the restatement only (its input transform, PIL's
+resize, is pinned on Pillow itself).
 Tolerance: fp32 MFMA vs ATen CPU differ by summation order only; activations here are O(10), asserted
 max-abs <= 2e-3 * (1 + max|ref|) over 104 stacked convs (measured ~1e-5 relative)."""
+import numpy as np
 import pytest
 import torch
 
@@ -453,3 +455,30 @@ def test_no_detections_gives_an_empty_result_and_a_zero_semantic_map(small_net):
     assert all(r["pred_masks"].shape == (0, img.shape[1], img.shape[2]) for r in res)
     sem = net.semantic(img, cfg.num_classes, 0.5, 0.5, None)
     assert sem.shape == (2, img.shape[1], img.shape[2], cfg.num_classes + 1) and float(sem.abs().max()) == 0.0
+
+
+def test_input_transform_equals_pillow_resize_bit_for_bit(golden_dir):
+    """peanut_rcnn_preprocess (the pixels the front end feeds its stem) against the oracle's restatement of Pillow's
+    resize -- itself pinned on Pillow's own outputs (tests/test_oracles_cpu.py) -- at the agent's geometry (480x640 ->
+    800x1067, upscaling), a downscaled frame and a tall one: every pixel equal (integer resampling, std = 1)."""
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import MaskRCNN
+    from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+    cfg = RcnnCfg(depth=50)
+    net = MaskRCNN(cfg, make_seeded_rcnn_state_dict(cfg, seed=1))
+    g = torch.Generator().manual_seed(23)
+    for shape in ((2, 480, 640), (1, 1000, 1400), (1, 300, 120)):
+        img = torch.randint(0, 256, shape + (3,), generator=g, dtype=torch.uint8)
+        want = rcnn_ref.preprocess(img, cfg)
+        got = net.preprocess(img.cuda()).cpu()
+        assert got.shape == want.shape
+        assert torch.equal(got, want), shape
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    img = torch.randint(0, 256, (1, 480, 640, 3), generator=g, dtype=torch.uint8)
+    nh, nw = net.plan(1, 480, 640)["resized"]
+    pil = torch.from_numpy(np.asarray(Image.fromarray(img[0].numpy()).resize((nw, nh), Image.BILINEAR)).copy())
+    mean = torch.tensor(cfg.pixel_mean).view(3, 1, 1)
+    assert torch.equal(net.preprocess(img.cuda()).cpu()[0, :, :nh, :nw], pil.permute(2, 0, 1).float() - mean)
