@@ -9,7 +9,7 @@
 // mirrored operation by operation, in double) is solved by relaxation, arranged so that every stage provably ends:
 //
 //   * tiles: the map is cut into 32x32 tiles; a workgroup stages a tile plus a 2-cell halo in LDS and sweeps it
-//     (Jacobi, two barriers per sweep, 4 cells per lane, re-evaluating only cells whose stencil saw a change in the
+//     (Jacobi, two barriers per sweep, one cell per lane, re-evaluating only cells whose stencil saw a change in the
 //     previous sweep) until nothing in the tile changes; a tile that changed wakes
 //     its four neighbours for the next round (the stencil is axis-aligned: no diagonal dependency); rounds are plain
 //     launches over the tile grid in which sleeping tiles exit at once; the host reads one counter every few rounds;
@@ -36,6 +36,7 @@
 // overrides -> traversible map (:382-386), exp(-d / temperature) weights with the "stuck: keep the last weights"
 // rule (:395-399), value = target_pred * weights and its first-occurrence argmax (:401-413).
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -128,18 +129,60 @@ __device__ __forceinline__ double update_cell(const AxisTerm& y, const AxisTerm&
   return u1;
 }
 
+// The same update with the quadratic solved RELATIVE to the smaller upwind value, in single precision: the unknown
+// is u - base with base = min(v1_y, v1_x), every input a difference of neighbouring values (O(1) cells), so float
+// carries ~1e-7 cell per update where the double form needs its 15 digits only to cancel the common offset (~10^2..10^3
+// cells) out of b^2 - 4ac.  A fraction of the double instruction count (v_sqrt_f32 instead of a double square-root
+// sequence); the result is added back onto `base` in double.
+struct AxisPick { double v1, v2; };      // nearest upwind value and the one behind it (INFINITY: none)
+__device__ __forceinline__ AxisPick axis_pick(double m1, double m2, double p1, double p2) {
+  AxisPick t{INFINITY, INFINITY};
+  if (m1 < t.v1) { t.v1 = m1; t.v2 = (m2 < t.v1) ? m2 : INFINITY; }      // j = -1 first; j = +1 only when strictly closer
+  if (p1 < t.v1) { t.v1 = p1; t.v2 = (p2 < t.v1) ? p2 : INFINITY; }
+  return t;
+}
+__device__ __forceinline__ double update_cell_local(const AxisPick& y, const AxisPick& x) {
+  const bool hy = y.v1 < INFINITY, hx = x.v1 < INFINITY;
+  if (!hy && !hx) return INFINITY;
+  const bool y_first = hy && (!hx || y.v1 <= x.v1);
+  const AxisPick& s = y_first ? y : x;
+  const AxisPick& o = y_first ? x : y;
+  const double base = s.v1;
+  const bool s2 = s.v2 < INFINITY;
+  const float as = s2 ? 2.25f : 1.0f;
+  const float ts = s2 ? (float)(s.v1 - s.v2) * (1.0f / 3.0f) : 0.0f;      // (4 v1 - v2) / 3 - base
+  float r = ts + (s2 ? (2.0f / 3.0f) : 1.0f);                             // one-axis root: t + 1 / sqrt(a)
+  if (o.v1 < INFINITY) {
+    const float ov = (float)(o.v1 - base);
+    if (ov < r) {
+      const bool o2 = o.v2 < INFINITY;
+      const float ao = o2 ? 2.25f : 1.0f;
+      const float to = o2 ? ov + (float)(o.v1 - o.v2) * (1.0f / 3.0f) : ov;
+      const float A = as + ao, B = as * ts + ao * to, C = as * ts * ts + ao * to * to - 1.0f;
+      const float det = B * B - A * C;
+      if (det >= 0.0f) {
+        const float u2 = (B + sqrtf(det)) / A;
+        if (u2 > ov) r = u2;
+      }
+    }
+  }
+  return base + (double)r;
+}
+
 // SECOND = false: stage A (first order, monotone).  SECOND = true: stage B (second order on the graph given by ord).
-// Jacobi sweeps of the tile in LDS.  A cell is only re-evaluated when one of the cells its stencil reads changed in the
-// previous sweep (the update is a pure function of those and of its own value, so skipping it changes nothing): once
-// the tile is loaded, the work follows the front -- a band a few cells wide -- instead of all 1024 cells.  Lanes are
-// laid out as 8 x 8 blocks (wave w, pass k -> block 4w + k), so that a band in any direction leaves most wave passes
-// with no lane to evaluate.  `active_clear` (the flags of the round after next) is wiped here, one byte per tile,
-// which saves a fill launch per round.
-template <bool SECOND>
-__global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dist, const double* __restrict__ ord,
-                                                        const unsigned char* __restrict__ state, int H, int W, int tiles_x, int tiles_y,
-                                                        const unsigned char* __restrict__ active_in, unsigned char* __restrict__ active_out,
-                                                        unsigned char* __restrict__ active_clear, unsigned int* __restrict__ changed_tiles) {
+// Jacobi sweeps of the tile in LDS, one cell per lane.  A cell is only re-evaluated when one of the cells its stencil
+// reads changed in the previous sweep (the update is a pure function of those and of its own value, so skipping it
+// changes nothing): once the tile is loaded, the work follows the front -- a band a few cells wide -- instead of all
+// 1024 cells, and with one 8 x 8 block per wave most waves skip a sweep altogether.  Only a ring of tiles is awake in
+// a round (<= 64 of 900 on the agent's map), so a round costs the LATENCY of one tile: sweeps x time per sweep; hence
+// one evaluation per lane (1024 lanes) rather than four, the feed predicates hoisted out of the sweeps, and the
+// quadratic solved in single precision relative to the smaller upwind value (update_cell_local).  `active_clear`
+// (the flags of the round after next) is wiped here, one byte per tile, which saves a fill launch per round.
+template <bool SECOND, bool LOCAL32>
+__global__ __launch_bounds__(1024) void fmm_round_kernel(double* __restrict__ dist, const double* __restrict__ ord,
+                                                         const unsigned char* __restrict__ state, int H, int W, int tiles_x, int tiles_y,
+                                                         const unsigned char* __restrict__ active_in, unsigned char* __restrict__ active_out,
+                                                         unsigned char* __restrict__ active_clear, unsigned int* __restrict__ changed_tiles) {
   const int tile = blockIdx.x;
   if (threadIdx.x == 0) active_clear[tile] = 0;
   if (!active_in[tile]) return;
@@ -149,7 +192,7 @@ __global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dis
   __shared__ unsigned char chg[2][LT][LT + 4];      // cells that changed in the previous / in this sweep (halo: never)
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int r0 = ty * TILE - HALO, c0 = tx * TILE - HALO;
-  for (int i = threadIdx.x; i < LT * LT; i += 256) {
+  for (int i = threadIdx.x; i < LT * LT; i += 1024) {
     const int ly = i / LT, lx = i - ly * LT;
     const int r = r0 + ly, c = c0 + lx;
     const bool in = r >= 0 && r < H && c >= 0 && c < W;
@@ -160,67 +203,66 @@ __global__ __launch_bounds__(256) void fmm_round_kernel(double* __restrict__ dis
     chg[1][ly][lx] = 0;
   }
   __syncthreads();
+  // one cell per lane, one 8 x 8 block per wave (16 waves): a wave none of whose cells saw a change around it skips
+  // the sweep as a whole, so the sweep costs one evaluation on the waves the front passes through and nothing elsewhere
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bly = HALO + (lane >> 3), blx = HALO + (lane & 7);      // cell of pass k: block 4 * wave + k of the 4 x 4 blocks
+  const int ly = HALO + 8 * (wave >> 2) + (lane >> 3), lx = HALO + 8 * (wave & 3) + (lane & 7);
+  // which neighbours may feed the cell: fixed for the round (state and `ord` do not change), so worked out once --
+  // bit 0..3: y-1, y+1, x-1, x+1 precede the cell; bit 4..7: y-2, y+2, x-2, x+2 precede those; bit 8: the cell is
+  // free.  Stage A: every neighbour may feed, second neighbours never.
+  unsigned feed = st[ly][lx] == ST_FREE ? 0x100u : 0u;
+  if (SECOND) {
+    const double oi = o[ly][lx];
+    const double oym = o[ly - 1][lx], oyp = o[ly + 1][lx], oxm = o[ly][lx - 1], oxp = o[ly][lx + 1];
+    feed |= (oym < oi ? 1u : 0u) | (oyp < oi ? 2u : 0u) | (oxm < oi ? 4u : 0u) | (oxp < oi ? 8u : 0u);
+    feed |= (o[ly - 2][lx] < oym ? 16u : 0u) | (o[ly + 2][lx] < oyp ? 32u : 0u) | (o[ly][lx - 2] < oxm ? 64u : 0u) |
+            (o[ly][lx + 2] < oxp ? 128u : 0u);
+  } else {
+    feed |= 0xfu;
+  }
   bool ever = false;
   int sweeps = 0;
   for (; sweeps < MAX_SWEEPS; ++sweeps) {
     const int cur = sweeps & 1;
-    double nv[4];
-    bool chk[4];
-    bool ch = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int blk = 4 * wave + k;
-      const int ly = bly + 8 * (blk >> 2), lx = blx + 8 * (blk & 3);
-      const double old = d[ly][lx];
-      nv[k] = old;
-      chk[k] = false;
-      bool need = sweeps == 0;        // a tile wakes because a neighbour changed its halo: everything once
-      if (!need) {
-        need = chg[cur][ly - 1][lx] | chg[cur][ly + 1][lx] | chg[cur][ly][lx - 1] | chg[cur][ly][lx + 1];
-        if (SECOND) need |= chg[cur][ly - 2][lx] | chg[cur][ly + 2][lx] | chg[cur][ly][lx - 2] | chg[cur][ly][lx + 2];
-      }
-      if (need && st[ly][lx] == ST_FREE) {
-        double u;
-        if (SECOND) {
-          // a neighbour feeds the cell only if it precedes it in `ord`; the second one only if it precedes the first
-          const double oi = o[ly][lx];
-          const double oym = o[ly - 1][lx], oyp = o[ly + 1][lx], oxm = o[ly][lx - 1], oxp = o[ly][lx + 1];
-          const double ym1 = oym < oi ? d[ly - 1][lx] : INFINITY, ym2 = o[ly - 2][lx] < oym ? d[ly - 2][lx] : INFINITY;
-          const double yp1 = oyp < oi ? d[ly + 1][lx] : INFINITY, yp2 = o[ly + 2][lx] < oyp ? d[ly + 2][lx] : INFINITY;
-          const double xm1 = oxm < oi ? d[ly][lx - 1] : INFINITY, xm2 = o[ly][lx - 2] < oxm ? d[ly][lx - 2] : INFINITY;
-          const double xp1 = oxp < oi ? d[ly][lx + 1] : INFINITY, xp2 = o[ly][lx + 2] < oxp ? d[ly][lx + 2] : INFINITY;
-          u = update_cell(axis_term(ym1, ym2, yp1, yp2), axis_term(xm1, xm2, xp1, xp2));
-          // changes below 1e-12 relative are rounding, not information
-          if (old < INFINITY && fabs(u - old) <= 1e-12 * fmax(1.0, old)) u = old;
-        } else {
-          u = update_cell(axis_term(d[ly - 1][lx], INFINITY, d[ly + 1][lx], INFINITY),
-                          axis_term(d[ly][lx - 1], INFINITY, d[ly][lx + 1], INFINITY));
-          u = fmin(u, old);
-        }
-        nv[k] = u;
-        chk[k] = u != old;
-        ch |= chk[k];
-      }
+    const double old = d[ly][lx];
+    double nv = old;
+    bool need = sweeps == 0;        // a tile wakes because a neighbour changed its halo: everything once
+    if (!need) {
+      need = chg[cur][ly - 1][lx] | chg[cur][ly + 1][lx] | chg[cur][ly][lx - 1] | chg[cur][ly][lx + 1];
+      if (SECOND) need |= chg[cur][ly - 2][lx] | chg[cur][ly + 2][lx] | chg[cur][ly][lx - 2] | chg[cur][ly][lx + 2];
     }
-    const int any = __syncthreads_or(ch);
+    if (need && (feed & 0x100u)) {
+      // a neighbour feeds the cell only if it precedes it in `ord`; the second one only if it precedes the first
+      const double ym1 = (feed & 1u) ? d[ly - 1][lx] : INFINITY, yp1 = (feed & 2u) ? d[ly + 1][lx] : INFINITY;
+      const double xm1 = (feed & 4u) ? d[ly][lx - 1] : INFINITY, xp1 = (feed & 8u) ? d[ly][lx + 1] : INFINITY;
+      double ym2 = INFINITY, yp2 = INFINITY, xm2 = INFINITY, xp2 = INFINITY;
+      if (SECOND) {
+        ym2 = (feed & 16u) ? d[ly - 2][lx] : INFINITY; yp2 = (feed & 32u) ? d[ly + 2][lx] : INFINITY;
+        xm2 = (feed & 64u) ? d[ly][lx - 2] : INFINITY; xp2 = (feed & 128u) ? d[ly][lx + 2] : INFINITY;
+      }
+      double u;
+      if (LOCAL32) u = update_cell_local(axis_pick(ym1, ym2, yp1, yp2), axis_pick(xm1, xm2, xp1, xp2));
+      else u = update_cell(axis_term(ym1, ym2, yp1, yp2), axis_term(xm1, xm2, xp1, xp2));
+      if (SECOND) {
+        // changes at the rounding level of the update (1e-12 relative in double; 1e-6 cell with the single-precision
+        // local solve) are noise, not information
+        if (old < INFINITY && fabs(u - old) <= (LOCAL32 ? 1e-6 : 1e-12 * fmax(1.0, old))) u = old;
+      } else {
+        u = fmin(u, old);
+      }
+      nv = u;
+    }
+    const bool chd = nv != old;
+    const int any = __syncthreads_or(chd);
     if (!any) break;
     ever = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int blk = 4 * wave + k;
-      const int ly = bly + 8 * (blk >> 2), lx = blx + 8 * (blk & 3);
-      d[ly][lx] = nv[k];
-      chg[cur ^ 1][ly][lx] = chk[k];
-    }
+    d[ly][lx] = nv;
+    chg[cur ^ 1][ly][lx] = chd;
     __syncthreads();
   }
   if (!ever) return;      // (uniform: `ever` derives from __syncthreads_or)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int blk = 4 * wave + k;
-    const int ly = bly + 8 * (blk >> 2), lx = blx + 8 * (blk & 3), r = r0 + ly, c = c0 + lx;
+  {
+    const int r = r0 + ly, c = c0 + lx;
     if (r < H && c < W) dist[(size_t)r * W + c] = d[ly][lx];
   }
   if (threadIdx.x == 0) {
@@ -354,8 +396,13 @@ int run_stage(peanut_goal* g, int* cur, int* rounds_used, unsigned long long* to
       unsigned char* in = act + (size_t)(*cur) * nt;
       unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
       unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
-      hipLaunchKernelGGL(fmm_round_kernel<SECOND>, dim3(nt), dim3(256), 0, s, (double*)g->dist.p, (const double*)g->order.p,
-                         (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
+      static const bool local32 = [] { const char* e = getenv("PEANUT_FMM_LOCAL32"); return !(e && e[0] == '0'); }();
+      if (local32)
+        hipLaunchKernelGGL((fmm_round_kernel<SECOND, true>), dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p,
+                           (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
+      else
+        hipLaunchKernelGGL((fmm_round_kernel<SECOND, false>), dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p,
+                           (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
       *cur = (*cur + 1) % 3;
     }
     PEANUT_HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, s));
