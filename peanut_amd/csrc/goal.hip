@@ -38,6 +38,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "net_common.h"
@@ -49,7 +50,7 @@ namespace {
 
 constexpr int TILE = 32, HALO = 2, LT = TILE + 2 * HALO;   // 36
 constexpr int MAX_SWEEPS = 96;                             // per round and tile (a front crosses a tile in <= 64)
-constexpr int ROUNDS_PER_CHECK = 8;
+constexpr int ROUNDS_PER_CHECK = 8, MAX_ROUNDS_PER_CHECK = 96;
 constexpr int MAX_ORDER_PASSES = 6;     // measured distance to the heap-ordered march: 3 passes 0.39 / 0.70 cell (maze / cluttered map), 4 passes 0.14 / 0.47, fixed point (5-6) 0.14 / 0.03
 
 enum : unsigned char { ST_MASKED = 0, ST_FREE = 1, ST_SEED = 2 };
@@ -376,22 +377,29 @@ struct peanut_goal {
   bool have_last = false;
   int last_lw = 0, last_lh = 0;
   int last_rounds = 0, last_passes = 0;
+  int round_hint[1 + 8] = {0};     // rounds each stage needed in the previous solve (run_stage)
 };
 
 namespace {
 
 // rounds of one stage until a round changes nothing; *total = tiles changed over the whole stage
 template <bool SECOND>
-int run_stage(peanut_goal* g, int* cur, int* rounds_used, unsigned long long* total, hipStream_t s) {
+int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned long long* total, hipStream_t s) {
   const int H = g->H, W = g->W, nt = g->tiles_x * g->tiles_y;
   unsigned char* act = (unsigned char*)g->active.p;
   unsigned int* counters = (unsigned int*)g->counters.p;
   const int max_rounds = 32 * (g->tiles_x + g->tiles_y) + 64;    // generous bound on the front's path, in tiles
-  unsigned int host[ROUNDS_PER_CHECK];
+  unsigned int host[MAX_ROUNDS_PER_CHECK];
   *total = 0;
-  for (int round = 0; round < max_rounds; round += ROUNDS_PER_CHECK) {
-    PEANUT_HIP_CHECK(hipMemsetAsync(counters, 0, ROUNDS_PER_CHECK * sizeof(unsigned int), s));
-    for (int k = 0; k < ROUNDS_PER_CHECK; ++k) {
+  // The host reads the per-round "tiles changed" counters once per batch of rounds.  The first batch of a stage is as
+  // long as that stage needed in the previous solve on this handle (+2: consecutive solves of an episode see almost
+  // the same map), so that a stage normally costs ONE host synchronisation; rounds after the field has settled wake no
+  // tile and cost a few microseconds each.
+  int batch = std::min(std::max(g->round_hint[stage] + 2, 4), MAX_ROUNDS_PER_CHECK);
+  int needed = 0;
+  for (int round = 0; round < max_rounds; round += batch, batch = ROUNDS_PER_CHECK) {
+    PEANUT_HIP_CHECK(hipMemsetAsync(counters, 0, batch * sizeof(unsigned int), s));
+    for (int k = 0; k < batch; ++k) {
       // three flag arrays in rotation: read, written (clean since the round before last), wiped for the next round
       unsigned char* in = act + (size_t)(*cur) * nt;
       unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
@@ -405,11 +413,17 @@ int run_stage(peanut_goal* g, int* cur, int* rounds_used, unsigned long long* to
                            (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
       *cur = (*cur + 1) % 3;
     }
-    PEANUT_HIP_CHECK(hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, s));
+    PEANUT_HIP_CHECK(hipMemcpyAsync(host, counters, batch * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     PEANUT_HIP_CHECK(hipStreamSynchronize(s));
-    *rounds_used += ROUNDS_PER_CHECK;
-    for (int k = 0; k < ROUNDS_PER_CHECK; ++k) *total += host[k];
-    if (host[ROUNDS_PER_CHECK - 1] == 0) return 0;
+    *rounds_used += batch;
+    for (int k = 0; k < batch; ++k) {
+      *total += host[k];
+      if (host[k]) needed = round + k + 1;
+    }
+    if (host[batch - 1] == 0) {
+      g->round_hint[stage] = needed;
+      return 0;
+    }
   }
   return fail(PEANUT_EHIP, "fmm: a relaxation stage did not settle within its round budget");
 }
@@ -425,7 +439,7 @@ int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* 
   unsigned long long changed = 0;
   // stage A: first-order field
   PEANUT_HIP_CHECK(hipMemcpyAsync(act, seed_tiles, nt, hipMemcpyDeviceToDevice, s));
-  if (int rc = run_stage<false>(g, &cur, &rounds, &changed, s)) return rc;
+  if (int rc = run_stage<false>(g, 0, &cur, &rounds, &changed, s)) return rc;
   // stage B: second order on the graph ordered by the previous field, until a pass changes nothing
   g->last_passes = 0;
   for (int pass = 0; pass < MAX_ORDER_PASSES; ++pass) {
@@ -438,7 +452,7 @@ int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* 
     } else {              // warm start: every tile re-examines its cells under the new ordering
       PEANUT_HIP_CHECK(hipMemsetAsync(act + (size_t)cur * nt, 1, nt, s));
     }
-    if (int rc = run_stage<true>(g, &cur, &rounds, &changed, s)) return rc;
+    if (int rc = run_stage<true>(g, 1 + pass, &cur, &rounds, &changed, s)) return rc;
     g->last_passes = pass + 1;
     if (pass > 0 && changed == 0) break;
   }
@@ -461,7 +475,7 @@ int peanut_goal_create(peanut_goal_t** out, int full_h, int full_w, int col_rad)
   const size_t n = (size_t)full_h * full_w;
   int rc;
   if ((rc = g->trav.ensure(n)) || (rc = g->state.ensure(n)) || (rc = g->dist.ensure(n * sizeof(double))) ||
-      (rc = g->order.ensure(n * sizeof(double))) || (rc = g->active.ensure(4 * (size_t)g->tiles_x * g->tiles_y)) || (rc = g->counters.ensure(ROUNDS_PER_CHECK * sizeof(unsigned int))) ||
+      (rc = g->order.ensure(n * sizeof(double))) || (rc = g->active.ensure(4 * (size_t)g->tiles_x * g->tiles_y)) || (rc = g->counters.ensure(MAX_ROUNDS_PER_CHECK * sizeof(unsigned int))) ||
       (rc = g->maxbits.ensure(sizeof(unsigned long long))) || (rc = g->wt_new.ensure(n * sizeof(double))) ||
       (rc = g->wt_last.ensure(n * sizeof(double))) || (rc = g->value.ensure(n * sizeof(double))) || (rc = g->sum.ensure(sizeof(double))) ||
       (rc = g->partial.ensure(1024 * sizeof(ArgMax))) || (rc = g->out_idx.ensure(2 * sizeof(int))) || (rc = g->out_val.ensure(2 * sizeof(double))))
