@@ -426,7 +426,7 @@ def main():
                        "parallelism": f"dp{world} (map shards, no data-path collective)"},
             "gflop_per_map_nominal": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
             "whole_forward_tflops_nominal": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
-            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 256 input channels as Winograd "
+            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 128 input channels (>= 256 in the emulated modes) as Winograd "
                           "F(4x4,3x3) with fp32 transforms; pyramid half of the PSP bottleneck folded through linearity "
                           "(nominal GFLOP/map counts the reference's 61 direct convs, so nominal TFLOP/s can exceed the MFMA peak)",
             "roofline": roof, "cpu_baseline": cpu,

@@ -1,6 +1,7 @@
 // Pieces shared by the network planners (pred_api.hip: PSPNet; rcnn_api.hip: Mask R-CNN front end):
 // device buffers, conv layers resident on the device, the workspace arena, state-dict lookup.
 #pragma once
+#include <stdlib.h>
 #include <math.h>
 
 #include <stdint.h>
@@ -145,7 +146,11 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
 
 // Adds the Winograd form to an uploaded stride-1 3x3 layer (keeps the direct form for the two-source path).
 inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int pad, int dil, int precision) {
-  return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= 256 && cin_pad % 32 == 0 && cout % 4 == 0 &&
+  // measured (profiles/r2s): from 128 input channels on in fp32 (+1.2 % on the headline, +1.8 % on the detector;
+  // 64 adds 0.1 %), from 256 on in the split / emulated modes (their transforms move 6-byte S values: 128 loses 1 %)
+  static const int env_min = [] { const char* e = getenv("PEANUT_WINO_MIN_CIN"); return e ? atoi(e) : 0; }();
+  const int min_cin = env_min ? env_min : (precision == PEANUT_PREC_FP32 ? 128 : 256);
+  return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 &&
          cout >= 64 && precision != PEANUT_PREC_FP16X3;   // fp16x3: the 1/24-scaled weight tails would underflow
 }
 
