@@ -49,6 +49,7 @@ struct ConvArgs {
   size_t ws_floats;
   int mt_per_group;        // grouped GEMM: 128-row m-tile mt reads weight block mt / mt_per_group (0 = single block)
   size_t w_group_stride;   // floats between weight blocks (bytes for S-packed weights)
+  int ss_group_stride;     // floats between the scale (and shift) blocks of the weight groups (0: one block for all)
   // S-format operands (see gemm_sx.hip): A read from xs instead of x; optional S copy of the output
   const unsigned short* xs;
   int xs_rows;
@@ -102,17 +103,18 @@ int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W
 int launch_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 // adaptive average pooling of [B,H,W,C] into all pyramid bins: out [B,nbins_total,C]
 int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, const int* scales, int nscales,
-                    hipStream_t s);
+                    hipStream_t s, int scale_rows = 0);
 // two-pass form (reads x once); scratch = ppm_pool_scratch_floats(...) floats (0 -> falls back to the above)
 size_t ppm_pool_scratch_floats(int B, int H, int C, const int* scales, int nscales);
+// scale_rows: row stride between the scales of `out` (0 = packed; a uniform stride lets ONE grouped GEMM take all scales)
 int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, int W, int C, const int* scales,
-                     int nscales, hipStream_t s);
+                     int nscales, hipStream_t s, int scale_rows = 0);
 // bilinear (align_corners=False) upsample of the pooled pyramid + channel concat: out [B,H,W,nscales*Cp]
 int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int W, int Cp, const int* scales,
                                int nscales, int align_corners, hipStream_t s);
 // pyramid half of the 3x3 bottleneck conv evaluated from the folded tables Q (see pspnet_aux.hip)
 int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
-                         int align_corners, hipStream_t s);
+                         int align_corners, hipStream_t s, int scale_rows = 0);
 // bilinear resize of NHWC logits [B,h,w,K] to NCHW [B,K,H,W], optional sigmoid
 int launch_upsample_logits(const float* lo, float* out, int B, int h, int w, int K, int H, int W,
                            int align_corners, int sigmoid, hipStream_t s);

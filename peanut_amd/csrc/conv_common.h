@@ -27,6 +27,7 @@ struct ConvKParams {
   // grouped GEMM (Winograd positions): m-tile mt uses the weight block (mt / mt_per_group); 0 = one block
   int mt_per_group;
   long long w_group_stride;   // floats between consecutive weight blocks
+  int ss_group_stride;        // floats between the groups' scale (and shift) blocks; 0 = shared
   // split-plane ("S") operands of the emulated-fp32 GEMM (gemm_sx.hip): every fp32 value as s_planes bf16 pieces
   // (x = hi + mid (+ lo), each piece the bf16 rounding of what is left), laid out
   // [16-channel chunk][plane][row][16 bf16] with the row count padded to a multiple of 128
@@ -142,8 +143,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
   constexpr int ROWS_PER_PASS = NT / NV;   // rows covered by the NT threads per pass
   const int c4 = (tid % NV) * 4, r0 = tid / NV;
   const int n = n0 + c4;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);   // scale/shift are padded to cout_pad
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+  const int ss_off = (p.mt_per_group && p.ss_group_stride) ? (wk.mt / p.mt_per_group) * p.ss_group_stride : 0;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n);   // scale/shift are padded to cout_pad
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);
   const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
 #pragma unroll
   for (int ep = 0; ep < EP; ++ep) {
@@ -280,8 +282,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
     if (m >= p.M) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(base + row * BN + c4);
     for (int s = 1; s < p.split_p; ++s) v += *reinterpret_cast<const f32x4*>(base + (size_t)s * (BM * BN) + row * BN + c4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    const int ss_off = (p.mt_per_group && p.ss_group_stride) ? (mt / p.mt_per_group) * p.ss_group_stride : 0;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);
     v = v * sc + sh;
     const size_t o = (size_t)m * p.cout + n;
     if (vec_ok) {

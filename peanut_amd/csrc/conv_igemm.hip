@@ -340,7 +340,7 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.nkt = (d.cin / d.bk) * p.ntaps;
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
-  p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride;
+  p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
   p.ys = a.ys; p.ys_rows = a.ys_rows; p.s_planes = d.s_planes; p.skip_f32 = a.skip_f32;
   if (p.ys && (d.cout % 16 || (d.s_planes != 2 && d.s_planes != 3))) return fail(-2, "launch_conv: S output needs cout % 16 == 0 and 2 or 3 planes");
   if (a.xs) {   // emulated-fp32 GEMM on pre-split operands

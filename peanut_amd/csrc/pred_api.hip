@@ -55,6 +55,10 @@ struct Op {
   // the side stream before this op
   int branch = 0;
   bool fork_before = false, join_before = false;
+  // grouped pointwise conv (the per-scale PSP convs in one launch): m-tiles per weight group; the PSP kernels then
+  // address scale s at row s * ppm_scale_rows
+  int group_mt = 0;
+  int ppm_scale_rows = 0;
 };
 
 struct Plan {
@@ -90,6 +94,9 @@ struct peanut_pred {
   ConvLayer* bottleneck = nullptr;     // unfolded form: 3x3 over cat([x, ppm...])
   ConvLayer* bottleneck_x = nullptr;   // folded form: 3x3 over x only ...
   std::vector<ConvLayer*> ppm_q;       // ... plus the per-scale tables Q_s = W_s (x) p_s (1x1 convs, cout = 9*hc)
+  // the per-scale 1x1 convs as ONE grouped GEMM each (weights / scale / shift of the scales back to back), used at small
+  // batch where four tiny launches + four reduces cost more than the padded rows (build_grouped)
+  std::unique_ptr<ConvLayer> ppm_grouped, ppmq_grouped;
   ConvLayer* conv_seg = nullptr;
   int feat_channels = 0;
   // runtime
@@ -150,6 +157,38 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
+}
+
+// One layer object whose weight / scale / shift buffers hold those of `parts` (identical shapes and tilings, fp32
+// path) back to back: a grouped GEMM then takes m-tile group g against block g (ConvArgs::mt_per_group,
+// w_group_stride, ss_group_stride).  Null when the parts do not qualify.
+std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, const std::string& name, int* rc) {
+  *rc = 0;
+  if (parts.size() < 2) return nullptr;
+  const ConvDesc& d0 = parts[0]->d;
+  for (const ConvLayer* L : parts)
+    if (L->d.mode != 0 || L->d.kh != 1 || L->d.kw != 1 || L->d.cin != d0.cin || L->d.cout != d0.cout || L->d.bn_tile != d0.bn_tile ||
+        L->d.bk != d0.bk || L->d.relu != d0.relu || L->w.bytes != parts[0]->w.bytes || L->ss.bytes != parts[0]->ss.bytes)
+      return nullptr;
+  auto G = std::make_unique<ConvLayer>();
+  G->name = name;
+  G->d = d0;
+  G->cin_real = parts[0]->cin_real;
+  const size_t wb = parts[0]->w.bytes, sb = (size_t)d0.cout_pad * sizeof(float), n = parts.size();
+  if ((*rc = G->w.ensure(wb * n)) || (*rc = G->ss.ensure(2 * sb * n))) return nullptr;
+  for (size_t i = 0; i < n; ++i) {
+    if (hipMemcpy((char*)G->w.p + i * wb, parts[i]->w.p, wb, hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy((char*)G->ss.p + i * sb, parts[i]->d.scale, sb, hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy((char*)G->ss.p + (n + i) * sb, parts[i]->d.shift, sb, hipMemcpyDeviceToDevice) != hipSuccess) {
+      *rc = fail(PEANUT_EHIP, name + ": grouping the per-scale layers failed");
+      return nullptr;
+    }
+  }
+  G->d.w_packed = (const float*)G->w.p;
+  G->d.scale = (const float*)G->ss.p;
+  G->d.shift = (const float*)G->ss.p + n * d0.cout_pad;
+  G->d.w_s = nullptr;
+  return G;
 }
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
@@ -321,11 +360,28 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   }
   std::vector<Act> side_bufs;   // released after the bottleneck when the branch overlaps it
   auto rel_side = [&](const Act& t) { if (overlap) side_bufs.push_back(t); else rel(t); };
-  int nbins = 0;
-  for (int i = 0; i < h->cfg.n_pool_scales; ++i) nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
-  Act pooled = make_act(ar, B, 1, nbins, x.C);
+  int nbins = 0, kmax = 0;
+  for (int i = 0; i < h->cfg.n_pool_scales; ++i) {
+    nbins += h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
+    kmax = std::max(kmax, h->cfg.pool_scales[i]);
+  }
+  // Small batches: the per-scale 1x1 convs (and the per-scale Q tables) as ONE grouped GEMM each -- every scale padded
+  // to the same `srows` rows (whole 128-row tiles), block s of the grouped weights for scale s.  Four launches + four
+  // split-K reduces of 15 + 6 us become one of each (batch 1: 170 -> 45 us for the eight convs); taken while the padded
+  // rows stay within 2x of what the separate launches would compute.  Not in debug (keep_all) plans, whose named
+  // tensors keep the packed layout.
+  int srows = 0;
+  if (h->ppm_grouped && h->ppmq_grouped && !h->keep_all) {
+    const int cand = (B * kmax * kmax + 127) / 128 * 128;
+    long long separate = 0;
+    for (int i = 0; i < h->cfg.n_pool_scales; ++i) separate += ((long long)B * h->cfg.pool_scales[i] * h->cfg.pool_scales[i] + 127) / 128 * 128;
+    static const int env = [] { const char* e = getenv("PEANUT_PPM_GROUPED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (env != 0 && ((long long)h->cfg.n_pool_scales * cand <= 2 * separate || env == 1)) srows = cand;
+  }
+  const int prow = srows ? h->cfg.n_pool_scales * srows : nbins * B;       // rows of pooled / table / q
+  Act pooled = make_act(ar, 1, 1, prow, x.C);
   {
-    Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.kernel = "ppm_pool"; op.in = x; op.out = pooled;
+    Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.kernel = "ppm_pool"; op.in = x; op.out = pooled; op.ppm_scale_rows = srows;
     const size_t sf = ppm_pool_scratch_floats(B, x.H, x.C, h->cfg.pool_scales, h->cfg.n_pool_scales);
     if (sf) {   // per-row partial sums of the two-pass pooling
       Act scr; scr.B = 1; scr.H = 1; scr.W = 1; scr.C = 0; scr.bytes = sf * sizeof(float); scr.off = ar.alloc(scr.bytes);
@@ -336,10 +392,18 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       pl->ops.push_back(op);
     }
   }
-  Act table = make_act(ar, B, 1, nbins, h->cfg.head_channels);
+  Act table = make_act(ar, 1, 1, prow, h->cfg.head_channels);
   // pooled/table are SCALE-MAJOR [scale][B][k*k][C] (pspnet_aux.hip: ppm_pool_kernel), so the 1x1 conv
   // of each scale (psp_head.py:39-46) runs on one contiguous [B*k*k, C] matrix.
-  {
+  auto push_grouped = [&](const ConvLayer* G, const Act& in, const Act& out) {
+    push_conv(*pl, G, in, nullptr, nullptr, out);
+    Op& op = pl->ops.back();
+    op.group_mt = srows / 128;
+    op.flops = 2.0 * (double)prow * G->d.cout * G->cin_real;      // executed (padded rows included)
+  };
+  if (srows) {
+    push_grouped(h->ppm_grouped.get(), pooled, table);
+  } else {
     size_t row0 = 0;
     for (int i = 0; i < h->cfg.n_pool_scales; ++i) {
       const int k = h->cfg.pool_scales[i];
@@ -355,25 +419,31 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   pl->named["ppm_table"] = table;
   rel_side(pooled);
   Act bt;
+  int term_scale_rows = 0;
   if (h->bottleneck_x) {
     // folded pyramid half (pspnet_aux.hip: ppm_conv_term_kernel): Q_s = table_s x W_s, then the 9-tap
     // bilinear evaluation R, then the 3x3 conv over x alone with R as its residual term
     const int hc = h->cfg.head_channels;
-    Act q = make_act(ar, B, 1, nbins, 9 * hc);
-    size_t row0 = 0;
-    for (int i = 0; i < h->cfg.n_pool_scales; ++i) {
-      const int k = h->cfg.pool_scales[i];
-      Act in = table, out = q;
-      in.off = table.off + row0 * (size_t)hc * sizeof(float);
-      in.H = 1; in.W = k * k; in.C = hc; in.B = B;
-      out.off = q.off + row0 * (size_t)(9 * hc) * sizeof(float);
-      out.H = 1; out.W = k * k; out.C = 9 * hc; out.B = B;
-      push_conv(*pl, h->ppm_q[i], in, nullptr, nullptr, out);
-      row0 += (size_t)B * k * k;
+    Act q = make_act(ar, 1, 1, prow, 9 * hc);
+    if (srows) {
+      push_grouped(h->ppmq_grouped.get(), table, q);
+      term_scale_rows = srows;
+    } else {
+      size_t row0 = 0;
+      for (int i = 0; i < h->cfg.n_pool_scales; ++i) {
+        const int k = h->cfg.pool_scales[i];
+        Act in = table, out = q;
+        in.off = table.off + row0 * (size_t)hc * sizeof(float);
+        in.H = 1; in.W = k * k; in.C = hc; in.B = B;
+        out.off = q.off + row0 * (size_t)(9 * hc) * sizeof(float);
+        out.H = 1; out.W = k * k; out.C = 9 * hc; out.B = B;
+        push_conv(*pl, h->ppm_q[i], in, nullptr, nullptr, out);
+        row0 += (size_t)B * k * k;
+      }
     }
     rel_side(table);
     Act r = make_act(ar, B, x.H, x.W, hc);
-    { Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; pl->ops.push_back(op); }
+    { Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; op.ppm_scale_rows = term_scale_rows; pl->ops.push_back(op); }
     rel_side(q);
     const size_t side_end = pl->ops.size();
     bt = make_act(ar, B, x.H, x.W, h->bottleneck_x->d.cout);
@@ -456,6 +526,11 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       if (op.in_s.valid) { a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad; }
       if (op.out_s.valid) { a.ys = (unsigned short*)(base + op.out_s.off); a.ys_rows = op.out_s.rows_pad; }
       a.skip_f32 = op.skip_f32;
+      if (op.group_mt) {     // per-scale PSP convs as one grouped GEMM over [scales * srows, C]
+        a.mt_per_group = op.group_mt;
+        a.w_group_stride = op.conv->w.bytes / sizeof(float) / (size_t)h->cfg.n_pool_scales;
+        a.ss_group_stride = op.conv->d.cout_pad;
+      }
       return launch_conv(op.conv->d, a, s);
     }
     case OP_WINO_IN:
@@ -485,13 +560,13 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:
       return launch_ppm_pool2(P(op.in), op.has_in2 ? P(op.in2) : nullptr, P(op.out), op.in.B, op.in.H, op.in.W, op.in.C,
-                              h->cfg.pool_scales, h->cfg.n_pool_scales, s);
+                              h->cfg.pool_scales, h->cfg.n_pool_scales, s, op.ppm_scale_rows);
     case OP_PPM_UP:
       return launch_ppm_upsample_concat(P(op.in), P(op.out), op.out.B, op.out.H, op.out.W, h->cfg.head_channels,
                                         h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s);
     case OP_PPM_TERM:
       return launch_ppm_conv_term(P(op.in), P(op.out), op.out.B, op.out.H, op.out.W, h->cfg.head_channels,
-                                  h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s);
+                                  h->cfg.pool_scales, h->cfg.n_pool_scales, h->cfg.align_corners, s, op.ppm_scale_rows);
     case OP_UPSAMPLE:
       return launch_upsample_logits(P(op.in), out_dev, op.in.B, op.in.H, op.in.W, op.in.C, pl.H, pl.W,
                                     h->cfg.align_corners, sigmoid, s);
@@ -598,6 +673,12 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
     }
   }
   if ((rc = add_conv(h.get(), tm, "decode_head.conv_seg", "", hc, hc, cfg->num_classes, 1, 1, 0, 1, 0, &h->conv_seg))) return rc;
+  if (cfg->fold_ppm) {
+    h->ppm_grouped = build_grouped(h->ppm, "decode_head.psp_modules.*.1.conv", &rc);
+    if (rc) return rc;
+    h->ppmq_grouped = build_grouped(h->ppm_q, "decode_head.bottleneck.conv[ppm*]", &rc);
+    if (rc) return rc;
+  }
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = h.release();
   return 0;

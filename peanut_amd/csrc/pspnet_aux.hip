@@ -101,17 +101,21 @@ int launch_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, in
 // scale s sees one contiguous [B*k_s^2, C] matrix.  One workgroup per (b, bin, 1024-channel slab): thread t owns 4 channels, loops the bin's pixels (coalesced 16-B
 // reads across the wave: 64 lanes x 16 B = one 1-KiB row segment per pixel).
 // Bin edges follow ATen's adaptive pooling: start = floor(i*n/k), end = ceil((i+1)*n/k).
-struct PpmScales { int s[8]; int n; };
+// rows: row stride between the scales of the pooled / table / Q tensors (0: packed, scale s starts at row B * sum_{j<s} k_j^2)
+struct PpmScales { int s[8]; int n; int rows; };
+__device__ __forceinline__ size_t ppm_row0(const PpmScales& sc, int s, int cells_before, int B) {
+  return sc.rows ? (size_t)s * sc.rows : (size_t)B * cells_before;
+}
 
 __global__ __launch_bounds__(256) void ppm_pool_kernel(const float* __restrict__ x, float* __restrict__ out, int H,
                                                        int W, int C, PpmScales sc, int nbins) {
   const int bin = blockIdx.x, b = blockIdx.y;
   const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
   if (c >= C) return;
-  int k = 0, local = bin, before = 0;
+  int k = 0, local = bin, before = 0, si = 0;
   for (int i = 0; i < sc.n; ++i) {
     const int kk = sc.s[i];
-    if (local < kk * kk) { k = kk; break; }
+    if (local < kk * kk) { k = kk; si = i; break; }
     local -= kk * kk;
     before += kk * kk;
   }
@@ -126,15 +130,16 @@ __global__ __launch_bounds__(256) void ppm_pool_kernel(const float* __restrict__
     }
   const float cnt = (float)((y1 - y0) * (x1 - x0));   // ATen: sum / count
   acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
-  const size_t row = (size_t)gridDim.y * before + (size_t)b * k * k + local;
+  const size_t row = ppm_row0(sc, si, before, gridDim.y) + (size_t)b * k * k + local;
   *reinterpret_cast<float4*>(out + row * C + c) = acc;
 }
 
 int launch_ppm_pool(const float* x, float* out, int B, int H, int W, int C, const int* scales, int nscales,
-                    hipStream_t s) {
+                    hipStream_t s, int scale_rows) {
   if (nscales > 8 || C % 4) return fail(-2, "ppm_pool: unsupported configuration");
   PpmScales sc;
   sc.n = nscales;
+  sc.rows = scale_rows;
   int nbins = 0;
   for (int i = 0; i < nscales; ++i) { sc.s[i] = scales[i]; nbins += scales[i] * scales[i]; }
   const dim3 grid(nbins, B, (C / 4 + 255) / 256);
@@ -201,10 +206,10 @@ __global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict
   const int bin = blockIdx.x, b = blockIdx.y;
   const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
   if (c >= C) return;
-  int k = 0, local = bin, before = 0, slot0 = 0;
+  int k = 0, local = bin, before = 0, slot0 = 0, si = 0;
   for (int i = 0; i < sc.n; ++i) {
     const int kk = sc.s[i];
-    if (local < kk * kk) { k = kk; break; }
+    if (local < kk * kk) { k = kk; si = i; break; }
     local -= kk * kk;
     before += kk * kk;
     slot0 += kk;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict
   }
   const float cnt = (float)((y1 - y0) * (x1 - x0));
   acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
-  const size_t row = (size_t)gridDim.y * before + (size_t)b * k * k + local;
+  const size_t row = ppm_row0(sc, si, before, gridDim.y) + (size_t)b * k * k + local;
   *reinterpret_cast<float4*>(out + row * C + c) = acc;
 }
 
@@ -231,11 +236,12 @@ size_t ppm_pool_scratch_floats(int B, int H, int C, const int* scales, int nscal
 }
 
 int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, int W, int C, const int* scales,
-                     int nscales, hipStream_t s) {
+                     int nscales, hipStream_t s, int scale_rows) {
   if (nscales > 8 || C % 4) return fail(-2, "ppm_pool: unsupported configuration");
   PpmScales sc;
   PpmSlots sl;
   sc.n = nscales;
+  sc.rows = scale_rows;
   sl.n = 0;
   int nbins = 0;
   for (int i = 0; i < nscales; ++i) {
@@ -243,13 +249,13 @@ int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, i
     sc.s[i] = k;
     nbins += k * k;
     for (int bx = 0; bx < k; ++bx) {
-      if (sl.n >= PPM_MAX_SLOTS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+      if (sl.n >= PPM_MAX_SLOTS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s, scale_rows);
       sl.x0[sl.n] = (short)((bx * W) / k);
       sl.x1[sl.n] = (short)(((bx + 1) * W + k - 1) / k);
       ++sl.n;
     }
   }
-  if (!scratch) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+  if (!scratch) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s, scale_rows);
   // segments between consecutive bin edges, each with the set of bin-columns (slots) that contain it
   PpmSegs sg;
   sg.n = 0;
@@ -264,7 +270,7 @@ int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, i
       for (int q = 0; q < sl.n; ++q)
         if (edges[i] >= sl.x0[q] && edges[i + 1] <= sl.x1[q]) m |= 1u << q;
       if (!m) continue;
-      if (sg.n >= 2 * PPM_MAX_SLOTS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s);
+      if (sg.n >= 2 * PPM_MAX_SLOTS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s, scale_rows);
       sg.x0[sg.n] = edges[i]; sg.x1[sg.n] = edges[i + 1]; sg.mask[sg.n] = m;
       ++sg.n;
     }
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void ppm_upsample_concat_kernel(const float* _
     float ly, lx;
     bilinear_src(yy, k, H, align_corners, &y0, &y1, &ly);
     bilinear_src(xx, k, W, align_corners, &x0, &x1, &lx);
-    const float* tb = table + ((size_t)B * base + (size_t)b * k * k) * Cp + g * 4;
+    const float* tb = table + (ppm_row0(sc, s, base, B) + (size_t)b * k * k) * Cp + g * 4;
     const float4 v00 = *reinterpret_cast<const float4*>(tb + (size_t)(y0 * k + x0) * Cp);
     const float4 v01 = *reinterpret_cast<const float4*>(tb + (size_t)(y0 * k + x1) * Cp);
     const float4 v10 = *reinterpret_cast<const float4*>(tb + (size_t)(y1 * k + x0) * Cp);
@@ -340,6 +346,7 @@ int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int
   if (nscales > 8 || Cp % 4) return fail(-2, "ppm_upsample: unsupported configuration");
   PpmScales sc;
   sc.n = nscales;
+  sc.rows = 0;
   for (int i = 0; i < nscales; ++i) sc.s[i] = scales[i];
   const long long total = (long long)B * H * W * nscales * (Cp / 4);
   hipLaunchKernelGGL(ppm_upsample_concat_kernel, dim3(grid_for(total)), dim3(256), 0, s, table, out, H, W, Cp, sc,
@@ -349,7 +356,7 @@ int launch_ppm_upsample_concat(const float* table, float* out, int B, int H, int
 }
 
 int launch_ppm_conv_term_l2(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
-                            int align_corners, hipStream_t s);
+                            int align_corners, hipStream_t s, int scale_rows);
 
 // ---- pyramid half of the PSP bottleneck conv, folded through linearity ----
 // The reference convolves cat([x, up(p_1), up(p_2), up(p_3), up(p_6)]) with a 3x3 kernel
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(256) void ppm_conv_term_kernel(const float* __restr
     int base = 0;
     for (int s = 0; s < sc.n; ++s) {
       const int k = sc.s[s];
-      const float* qs = Q + ((size_t)B * base + (size_t)b * k * k) * (9 * C) + g * 4;
+      const float* qs = Q + (ppm_row0(sc, s, base, B) + (size_t)b * k * k) * (9 * C) + g * 4;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const int py = yy + dy - 1;
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void ppm_conv_term_lds_kernel(const float* __r
     int base = 0;
     for (int s = 0; s < sc.n; ++s) {
       const int k = sc.s[s], cells = k * k;
-      const float* src = Q + ((size_t)B * base + (size_t)b * cells) * (9 * C) + c0;
+      const float* src = Q + (ppm_row0(sc, s, base, B) + (size_t)b * cells) * (9 * C) + c0;
       for (int i = threadIdx.x; i < cells * 9 * (CH / 4); i += blockDim.x) {
         const int v4 = i % (CH / 4), rt = i / (CH / 4);        // rt = cell*9 + tap
         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)rt * C + v4 * 4);
@@ -512,10 +519,11 @@ __global__ __launch_bounds__(256) void ppm_conv_term_lds_kernel(const float* __r
 }
 
 int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
-                         int align_corners, hipStream_t s) {
+                         int align_corners, hipStream_t s, int scale_rows) {
   if (nscales <= 8 && C % 32 == 0) {
     PpmScales sc;
     sc.n = nscales;
+    sc.rows = scale_rows;
     int nbins = 0;
     for (int i = 0; i < nscales; ++i) { sc.s[i] = scales[i]; nbins += scales[i] * scales[i]; }
     const int L = (H > W ? H : W) + 2;
@@ -539,14 +547,15 @@ int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, c
       return e == hipSuccess ? 0 : fail(-3, std::string("ppm_conv_term_lds: ") + hipGetErrorString(e));
     }
   }
-  return launch_ppm_conv_term_l2(Q, R, B, H, W, C, scales, nscales, align_corners, s);
+  return launch_ppm_conv_term_l2(Q, R, B, H, W, C, scales, nscales, align_corners, s, scale_rows);
 }
 
 int launch_ppm_conv_term_l2(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
-                            int align_corners, hipStream_t s) {
+                            int align_corners, hipStream_t s, int scale_rows) {
   if (nscales > 8 || C % 4) return fail(-2, "ppm_conv_term: unsupported configuration");
   PpmScales sc;
   sc.n = nscales;
+  sc.rows = scale_rows;
   for (int i = 0; i < nscales; ++i) sc.s[i] = scales[i];
   const long long total = (long long)B * H * W * (C / 4);
   hipLaunchKernelGGL(ppm_conv_term_kernel, dim3(grid_for(total)), dim3(256), 0, s, Q, R, H, W, C, sc, B,
