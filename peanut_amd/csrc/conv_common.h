@@ -28,6 +28,8 @@ struct ConvKParams {
   int mt_per_group;
   long long w_group_stride;   // floats between consecutive weight blocks
   int ss_group_stride;        // floats between the groups' scale (and shift) blocks; 0 = shared
+  int mtiles;                 // m-tiles of the launch (decode_work's n-chunked tile order)
+  int nchunk;                 // n-tiles per chunk of that order; 0 = plain order (n fastest over all n-tiles)
   // split-plane ("S") operands of the emulated-fp32 GEMM (gemm_sx.hip): every fp32 value as s_planes bf16 pieces
   // (x = hi + mid (+ lo), each piece the bf16 rounding of what is left), laid out
   // [16-channel chunk][plane][row][16 bf16] with the row count padded to a multiple of 128
@@ -99,6 +101,31 @@ int launch_gemm_sx(const ConvKParams& p, int bn_tile, int planes, float* ws, siz
 //    the XCD runs (they are shorter than full tiles, so lumping them on one XCD would unbalance it).
 struct Work { int mt, nt, kt0, kt1, item; };   // item >= 0: split part -> partial tile #item
 
+// tile -> (mt, nt).  Plain order: n fastest.  With more than `nchunk` n-tiles the n range is cut into chunks that are
+// walked one after the other (all m-tiles of chunk 0, then chunk 1, ...): the 64 workgroups resident on an XCD then
+// cover 8 m-tiles x 8 n-tiles instead of 4 x 16, i.e. 16 instead of 20 operand panels per round through its L2.
+__device__ __forceinline__ void tile_to_mn(const ConvKParams& p, int tile, int* mt_out, int* nt_out) {
+  int mt, nt;
+  if (p.nchunk > 0 && p.ntiles > p.nchunk) {
+    const int full = p.ntiles / p.nchunk, rem = p.ntiles - full * p.nchunk;
+    const int per_chunk = p.mtiles * p.nchunk;
+    if (tile < full * per_chunk) {
+      const int c = tile / per_chunk, r = tile - c * per_chunk;
+      mt = r / p.nchunk;
+      nt = c * p.nchunk + (r - mt * p.nchunk);
+    } else {
+      const int r = tile - full * per_chunk;
+      mt = r / rem;
+      nt = full * p.nchunk + (r - mt * rem);
+    }
+  } else {
+    mt = tile / p.ntiles;
+    nt = tile - mt * p.ntiles;
+  }
+  *mt_out = mt;
+  *nt_out = nt;
+}
+
 __device__ __forceinline__ Work decode_work(const ConvKParams& p) {
   const int G = gridDim.x, bid = blockIdx.x;
   const int q = G >> 3, r = G & 7, xcd = bid & 7, local = bid >> 3;
@@ -120,8 +147,7 @@ __device__ __forceinline__ Work decode_work(const ConvKParams& p) {
     w.kt0 = 0;
     w.kt1 = p.nkt;
   }
-  w.mt = tile / p.ntiles;
-  w.nt = tile - w.mt * p.ntiles;
+  tile_to_mn(p, tile, &w.mt, &w.nt);
   return w;
 }
 
@@ -271,7 +297,8 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKParams p) {
   const int j = blockIdx.x;                    // tail tile
   const int tile = p.n_full + j;
-  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  int mt, nt;
+  tile_to_mn(p, tile, &mt, &nt);
   const int m0 = mt * BM, n0 = nt * BN;
   constexpr int NV = BN / 4, SLAB = 16;
   const float* base = p.partial + (size_t)j * p.split_p * (BM * BN);
@@ -328,6 +355,9 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   p.n_sp = t * sp;
   p.n_full = T - t;
   p.partial = ws;
+  static const int nchunk = [] { const char* e = getenv("PEANUT_NCHUNK"); return e ? atoi(e) : 8; }();
+  p.mtiles = mtiles;
+  p.nchunk = nchunk;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(NT), 0, stream, p);
   if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
