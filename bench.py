@@ -139,6 +139,7 @@ def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 40.0):
 
 # bench kernel family -> substring of the rocprofv3 kernel name
 FAMILY_KERNEL = {
+    "conv_pw_glds_256x128": "conv_pw_glds256_kernel",
     "conv_pw_glds_128x128": "conv_pw_glds_kernel<128, 2, 2>",
     "conv_pw_glds_128x64": "conv_pw_glds_kernel<64, 2, 2>",
     "conv_pw_glds_128x32": "conv_pw_glds_kernel<32, 4, 1>",

@@ -73,6 +73,9 @@ void pack_conv_weights_split(const float* w_oihw, int cout, int cin_real, int ci
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
 // true unless PEANUT_PW_GLDS=0: fp32 1x1 convs / grouped GEMMs run on the LDS-DMA kernel of conv_pw.hip
 bool conv_pw_enabled();
+// conv_pw.hip: whether a pointwise layer / grouped GEMM runs on the 256 x 128 three-stage kernel
+bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
+int conv_pw_256_min_k();
 
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
 // tiles per sub-grid (th x tw), tile count and its padding to whole `gran`-row GEMM tiles (128; 256 when the position

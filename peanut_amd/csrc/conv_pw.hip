@@ -164,6 +164,134 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
   conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, smem, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 128 tiles, 8 waves (wave tile 64 x 64 as above), THREE stages of 48 KiB = 144 of the CU's 160 KiB, one
+// workgroup per CU.  Same fragment reads, same swizzle, same MFMA order per wave as the 128 x 128 kernel; what changes:
+// a k-tile is requested two iterations before it is read (the two-stage kernel has half an iteration of cover: 0.85 us
+// at full matrix-core rate, less than a loaded HBM round trip), the operand bytes per FLOP drop by a quarter (6 instead
+// of 8 LDS-DMA instructions per wave and k-tile) and one barrier serves eight waves.  For the large pointwise layers
+// (see conv_pw_uses_256).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams p) {
+  constexpr int BM = 256, BN = 128, BK = 32, WM = 4, WN = 2, NT = 512, STAGES = 3;
+  constexpr int TM = BM / WM, TN = BN / WN;      // 64 x 64
+  constexpr int MI = TM / 32, NI = TN / 32;      // 2 x 2
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;   // 48 KiB
+  constexpr int A_INSTR = BM / 64, B_INSTR = BN / 64;   // 1 KiB (8-row) DMA pieces per wave and k-tile: 4 + 2
+  constexpr int CS = BN + 4;
+  constexpr int SMEM_FLOATS = (STAGES * STAGE > BM * CS) ? STAGES * STAGE : BM * CS;
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const Work wk = decode_work(p);
+  const int mt = wk.mt, nt = wk.nt, nk = wk.kt1 - wk.kt0;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 3, lp = lane & 7;
+
+  const float* a_src[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int r = (wave * A_INSTR + j) * 8 + lr;
+    const int m = m0 + r;
+    const int mc = m < p.M ? m : p.M - 1;
+    const int b = mc / p.HoWo;
+    const int rem = mc - b * p.HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const size_t pix = (size_t)b * p.H * p.W + (size_t)oy * p.stride * p.W + (size_t)ox * p.stride;
+    const int c = lp ^ ((r >> 1) & 7);
+    a_src[j] = p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4;
+  }
+  const float* b_src[B_INSTR];
+  {
+    const float* wtile = p.w + (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride : 0) +
+                         ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      const int r = (wave * B_INSTR + j) * 8 + lr;
+      const int c = lp ^ ((r >> 1) & 7);
+      b_src[j] = wtile + r * BK + c * 4;
+    }
+  }
+#define PW256_DMA_TILE(stage)                                                                                    \
+  {                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                                        \
+      __builtin_amdgcn_global_load_lds((gptr_t)a_src[j], (lptr_t)((stage) + (wave * A_INSTR + j) * 256), 16, 0, 0); \
+      a_src[j] += BK;                                                                                            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j) {                                                        \
+      __builtin_amdgcn_global_load_lds((gptr_t)b_src[j], (lptr_t)((stage) + A_FLOATS + (wave * B_INSTR + j) * 256), 16, 0, 0); \
+      b_src[j] += BN * BK;                                                                                       \
+    }                                                                                                            \
+  }
+#define PW256_BARRIER()                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("" ::: "memory");
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  const int swz = (li >> 1) & 7;
+  int sw[BK / 8];
+#pragma unroll
+  for (int ks = 0; ks < BK / 8; ++ks) sw[ks] = ((ks * 2 + hi) ^ swz) * 4;
+  const int a_row = (wm * TM + li) * BK;
+  const int b_row = A_FLOATS + (wn * TN + li) * BK;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int t = 0; t < MI; ++t)
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  // prologue: two k-tiles in flight
+  PW256_DMA_TILE(smem);
+  if (nk > 1) {
+    PW256_DMA_TILE(smem + STAGE);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // all but the newest tile (6 DMA instructions per wave and tile)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  PW256_BARRIER();
+  // one barrier per k-tile; the fragment reads of a k-tile are not carried across it (measured: splitting them in
+  // halves around a mid-iteration barrier as the two-stage kernel does is 2 % SLOWER here -- with two waves per SIMD
+  // the other wave's MFMAs already cover them, and the extra scheduling fences cost more)
+  int o_cur = 0, o_mid = STAGE, o_fill = 2 * STAGE;
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* const cur = smem + o_cur;
+    const bool more = kt + 2 < nk;
+    if (more) PW256_DMA_TILE(smem + o_fill);
+    f32x4 af[BK / 8][MI], bf[BK / 8][NI];
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+#pragma unroll
+      for (int t = 0; t < MI; ++t) af[j][t] = *reinterpret_cast<const f32x4*>(cur + a_row + t * 32 * BK + sw[j]);
+#pragma unroll
+      for (int u = 0; u < NI; ++u) bf[j][u] = *reinterpret_cast<const f32x4*>(cur + b_row + u * 32 * BK + sw[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int t = 0; t < MI; ++t)
+#pragma unroll
+          for (int u = 0; u < NI; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+    // the next k-tile must have landed; the one just requested may stay in flight across the barrier
+    if (more) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    PW256_BARRIER();
+    { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+  }
+#undef PW256_DMA_TILE
+#undef PW256_BARRIER
+  conv_epilogue<BM, BN, WM, WN, 1, NT>(p, wk, acc, smem, m0, n0);
+}
+
 template <int BN, int WM, int WN>
 int launch_pw_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
   static int slots = 0;
@@ -182,8 +310,27 @@ bool conv_pw_enabled() {
   return on == 1;
 }
 
+// whether the 256 x 128 kernel takes a [M x cout] pointwise layer (mt_per_group: 128-row tiles per weight group, 0 = plain)
+// Measured per layer (profiles/r2t): +2-3 % on the K >= 1024 layers (layer3/4 conv1, layer4 downsample: 129 -> 133 TF/s),
+// -3 % on the K = 512 ones (short k-loops: with one workgroup per CU nobody computes under a tile's epilogue), level on
+// the K = 2048 Winograd GEMM of the bottleneck.  Grouped GEMMs need whole 256-row tiles per weight group.
+int conv_pw_256_min_k() {
+  static const int min_k = [] { const char* e = getenv("PEANUT_PW256_MINK"); return e ? atoi(e) : 1024; }();
+  return min_k;
+}
+bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin) {
+  return bn_tile == 128 && cin >= conv_pw_256_min_k() && mt_per_group % 2 == 0 && M * cout >= 256LL * 256 * 128;
+}
+
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
+  if (conv_pw_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1)) {
+    static int slots256 = 0;
+    ConvKParams q = p;
+    if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
+    return launch_with_tail_split<decltype(&conv_pw_glds256_kernel), 256, 128, 512>(&conv_pw_glds256_kernel, q, ws, ws_floats, stream,
+                                                                                     &slots256);
+  }
   if (bn_tile == 128) return launch_pw_t<128, 2, 2>(p, ws, ws_floats, stream);
   if (bn_tile == 64) return launch_pw_t<64, 2, 2>(p, ws, ws_floats, stream);
   if (bn_tile == 32) return launch_pw_t<32, 4, 1>(p, ws, ws_floats, stream);

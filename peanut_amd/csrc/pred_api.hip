@@ -198,7 +198,8 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_
     return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
   }
   if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && !two_source && d.cin % 32 == 0 && conv_pw_enabled())
-    return "conv_pw_glds_128x" + std::to_string(d.bn_tile);
+    return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
+                                                                         : "conv_pw_glds_128x" + std::to_string(d.bn_tile);
   return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
          std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
 }
@@ -224,7 +225,10 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     int th, tw;
     long long n_tiles, m_pad;
     const bool s_gemm = L->wino.w_s != nullptr;
-    const int gran = s_gemm ? 256 : 128;   // the S-format position GEMMs run on 256 x 256 tiles (gemm_sx.hip)
+    // row padding per Winograd position: whole 256-row tiles where the position GEMMs run on a 256-row kernel (the
+    // S-format one of gemm_sx.hip; the three-stage fp32 one of conv_pw.hip for K >= 1024), else 128
+    const bool pw256 = !s_gemm && L->wino.mode == 0 && L->wino.bn_tile == 128 && in.C >= conv_pw_256_min_k() && conv_pw_enabled();
+    const int gran = (s_gemm || pw256) ? 256 : 128;
     wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran);
     Act v;   // fp32 V (unused in the S form)
     SAct vs;
