@@ -227,7 +227,11 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     const bool s_gemm = L->wino.w_s != nullptr;
     // row padding per Winograd position: whole 256-row tiles where the position GEMMs run on a 256-row kernel (the
     // S-format one of gemm_sx.hip; the three-stage fp32 one of conv_pw.hip for K >= 1024), else 128
-    const bool pw256 = !s_gemm && L->wino.mode == 0 && L->wino.bn_tile == 128 && in.C >= conv_pw_256_min_k() && conv_pw_enabled();
+    bool pw256 = false;
+    if (!s_gemm && L->wino.mode == 0 && conv_pw_enabled()) {     // would the 256-row kernel take it with 256-row padding?
+      wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, 256);
+      pw256 = conv_pw_uses_256(L->wino.cout, 36 * m_pad, (int)(m_pad / 128), L->wino.bn_tile, in.C);
+    }
     const int gran = (s_gemm || pw256) ? 256 : 128;
     wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran);
     Act v;   // fp32 V (unused in the S form)
