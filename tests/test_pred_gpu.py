@@ -500,6 +500,21 @@ for precision in ("fp32", "bf16x6"):
         for _ in range(2):
             y = m.get_prediction_batch(x)
         out.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
+    # the same forwards replayed as hipGraphs (the fork / join of the two-stream head is captured with them)
+    m.model.use_graph(True)
+    side = torch.cuda.Stream()
+    for B, S in ((1, 240), (3, 176)):
+        g = torch.Generator().manual_seed(B * 1000 + S)
+        x = (torch.rand((B, cfg.in_channels, S, S), generator=g) > 0.7).float().cuda()
+        y = torch.empty((B, cfg.num_classes, S, S), device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                y.zero_()
+                m.get_prediction_batch(x, out=y)
+                side.synchronize()
+        out.append("g" + hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())
+    m.model.use_graph(False)
 print("HASHES " + " ".join(out))
 """
 
@@ -517,3 +532,7 @@ def test_two_stream_head_schedule_is_bit_identical():
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = [l for l in r.stdout.splitlines() if l.startswith("HASHES ")][-1]
     assert got["default"] == got["one_stream"]
+    h = got["default"].split()[1:]
+    # per precision: three plain forwards, then two graph replays of the first two of them
+    for k in (0, 5):
+        assert h[k + 3] == "g" + h[k] and h[k + 4] == "g" + h[k + 1], "graph replay differs from plain launches"
