@@ -30,6 +30,7 @@ struct ConvKParams {
   int ss_group_stride;        // floats between the groups' scale (and shift) blocks; 0 = shared
   int mtiles;                 // m-tiles of the launch (decode_work's n-chunked tile order)
   int nchunk;                 // n-tiles per chunk of that order; 0 = plain order (n fastest over all n-tiles)
+  int res_prefetch;           // epilogue: request the first rows of the residual before the accumulators go through LDS
   // split-plane ("S") operands of the emulated-fp32 GEMM (gemm_sx.hip): every fp32 value as s_planes bf16 pieces
   // (x = hi + mid (+ lo), each piece the bf16 rounding of what is left), laid out
   // [16-channel chunk][plane][row][16 bf16] with the row count padded to a multiple of 128
@@ -155,9 +156,32 @@ __device__ __forceinline__ Work decode_work(const ConvKParams& p) {
 // The accumulators go through LDS (EP row slabs) so that global traffic is whole rows: each thread then handles
 // 16-byte pieces (4 consecutive channels) -- a wave reads the residual and writes the output as contiguous row
 // segments instead of 64 scalar accesses per lane.  The caller's k-loop must have retired every LDS read (barrier).
+constexpr int kResPrefetchRows = 8;
+struct ResPrefetch { f32x4 v[kResPrefetchRows]; bool on; };
+
+// The first kResPrefetchRows residual rows a thread will add in conv_epilogue, requested early: a kernel may call this
+// before its last k-tile's MFMAs (the loads then travel under them), conv_epilogue itself does it before the
+// accumulators go through LDS otherwise.  Same thread -> (row, 4 channels) mapping as the epilogue's row loop.
+template <int BM, int BN, int EP, int NT>
+__device__ __forceinline__ ResPrefetch conv_res_prefetch(const ConvKParams& p, const Work& wk, int m0, int n0) {
+  constexpr int NV = BN / 4, ROWS_PER_PASS = NT / NV, ER = BM / EP;
+  const int tid = threadIdx.x;
+  const int c4 = (tid % NV) * 4, r0 = tid / NV, n = n0 + c4;
+  ResPrefetch r;
+  r.on = p.res_prefetch && p.res && wk.item < 0 && (p.cout & 3) == 0 && n < p.cout;
+  if (r.on) {
+#pragma unroll
+    for (int i = 0; i < kResPrefetchRows; ++i) {
+      const int row = r0 + i * ROWS_PER_PASS, m = m0 + row;
+      r.v[i] = (row < ER && m < p.M) ? *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.cout + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  return r;
+}
+
 template <int BM, int BN, int WM, int WN, int EP, int NT = 256, int MI = 0, int NI = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& wk, f32x16 (&acc)[MI][NI], float* smem,
-                                              int m0, int n0) {
+                                              int m0, int n0, const ResPrefetch* early = nullptr) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int CS = BN + 4, ER = BM / EP;
   static_assert(MI == TM / 32 && NI == TN / 32, "accumulator shape");
@@ -173,6 +197,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
   const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n);   // scale/shift are padded to cout_pad
   const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);
   const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
+  // the first PRE residual rows of this thread are requested early (conv_res_prefetch): their latency runs under the
+  // last MFMAs / the LDS stores and the barrier instead of at the head of the row loop
+  constexpr int PRE = kResPrefetchRows;
+  const ResPrefetch rp = early ? *early : conv_res_prefetch<BM, BN, EP, NT>(p, wk, m0, n0);
+  const f32x4 (&rpre)[PRE] = rp.v;
+  const bool pre = rp.on;
 #pragma unroll
   for (int ep = 0; ep < EP; ++ep) {
     if (EP == 1 || wm == ep) {
@@ -192,8 +222,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
       for (int row = r0; row < ER; row += ROWS_PER_PASS)
         *reinterpret_cast<f32x4*>(dst + row * BN + c4) = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
     } else {
+      int row_first = r0;
+      if (pre && ep == 0) {     // the rows whose residual is already on its way
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+          const int row = r0 + i * ROWS_PER_PASS, m = m0 + row;
+          if (row < ER && m < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
+            v = v * sc + sh;
+            v += rpre[i];
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const size_t o = (size_t)m * p.cout + n;
+            if (!p.skip_f32) *reinterpret_cast<f32x4*>(p.y + o) = v;
+            if (p.ys) *reinterpret_cast<f32x4*>(smem + row * CS + c4) = v;
+          }
+        }
+        row_first = r0 + PRE * ROWS_PER_PASS;
+      }
 #pragma unroll 4
-      for (int row = r0; row < ER; row += ROWS_PER_PASS) {
+      for (int row = row_first; row < ER; row += ROWS_PER_PASS) {
         const int m = m0 + ep * ER + row;
         if (m >= p.M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
@@ -358,6 +405,8 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   static const int nchunk = [] { const char* e = getenv("PEANUT_NCHUNK"); return e ? atoi(e) : 8; }();
   p.mtiles = mtiles;
   p.nchunk = nchunk;
+  static const int res_prefetch = [] { const char* e = getenv("PEANUT_RES_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
+  p.res_prefetch = res_prefetch;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(NT), 0, stream, p);
   if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();

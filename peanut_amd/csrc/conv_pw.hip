@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
     PEANUT_MFMA_HALF(afB, bfB);
     __builtin_amdgcn_sched_barrier(0);
   }
+  const ResPrefetch rp = conv_res_prefetch<BM, BN, EP, 256>(p, wk, m0, n0);   // under the last k-tile's MFMAs
   {   // last k-tile
     const float* const cur = smem + (kt & 1) * STAGE;
     PEANUT_LOAD_FRAGS(afB, bfB, cur, 1);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
 #undef PEANUT_DMA_TILE
 #undef PEANUT_DMA_LANDED_BARRIER
 
-  conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, smem, m0, n0);
+  conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, smem, m0, n0, &rp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
   static_assert(PER_WAVE <= 6, "SX_WAIT_ALL_BUT_LAST_TILE covers up to 6 pieces per wave");
+  ResPrefetch rp;
+  rp.on = false;
   // ---- prologue: STAGES - 1 k-tiles in flight ----
   SX_DMA_TILE(smem);
   if (STAGES == 3 && nk > 1) {
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
       const unsigned char* const cur = smem + o_cur;
       const bool more = kt + STAGES - 1 < nk;
       if (more) SX_DMA_TILE(smem + o_fill);
+      if (kt == nk - 1) rp = conv_res_prefetch<BM, BN, EP, 256>(p, wk, m0, n0);   // under the last k-tile's MFMAs
       bf16x8 af[NP][MI], bf[NP][NI];
       SX_READ_FRAGS(af, bf, cur);
       SX_MFMA(af, bf, 2);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_sx_kernel(const ConvKParams p) {
 #undef SX_WAIT_ALL_BUT_LAST_TILE
 #undef SX_BARRIER
 
-  conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0);
+  conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0, PIPE ? nullptr : &rp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -329,11 +332,14 @@ __global__ __launch_bounds__(512) void gemm_sx256_kernel(const ConvKParams p) {
   } else {
     SX_DMA_LANDED_BARRIER();
   }
+  ResPrefetch rp;
+  rp.on = false;
   int o_cur = 0, o_fill = 2 * STAGE, o_mid = STAGE;
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* const cur = smem + o_cur;
     const bool more = kt + 2 < nk;
     if (more) SX_DMA_TILE(smem + o_fill);
+    if (kt == nk - 1) rp = conv_res_prefetch<BM, BN, EP, NT>(p, wk, m0, n0);   // under the last k-tile's MFMAs
     bf16x8 af[NP][MI], bf[NP][NI];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_sx256_kernel(const ConvKParams p) {
 #undef SX_WAIT_ALL_BUT_LAST_TILE
 #undef SX_BARRIER
 
-  conv_epilogue<BM, BN, WM, WN, EP, NT>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0);
+  conv_epilogue<BM, BN, WM, WN, EP, NT>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0, &rp);
 }
 
 template <int NP>
