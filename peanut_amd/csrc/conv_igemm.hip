@@ -353,7 +353,7 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
     if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
     return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);
   }
-  if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c2 == 0 && p.c1 % 32 == 0 && conv_pw_enabled())
+  if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c1 % 32 == 0 && p.c2 % 32 == 0 && (p.c2 == 0 || p.stride == 1) && conv_pw_enabled())
     return launch_conv_pw(p, d.bn_tile, a.ws, a.ws_floats, stream);
   if (d.bk == 32) {
     if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, a.ws, a.ws_floats, stream);

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
 
   // ---- per-lane DMA source pointers (advanced by one k-tile per iteration) ----
   const float* a_src[A_INSTR];
+  const float* a_src2[A_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
     const int r = (wave * A_INSTR + j) * 8 + lr;
@@ -64,8 +65,12 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     const size_t pix = (size_t)b * p.H * p.W + (size_t)oy * p.stride * p.W + (size_t)ox * p.stride;
     const int c = lp ^ ((r >> 1) & 7);
-    a_src[j] = p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4;
+    // two sources (channels [0, c1) from x, [c1, c1 + c2) from x2, same pixels): the k-tiles of x first
+    const int k1 = p.c1 / BK;
+    a_src[j] = wk.kt0 < k1 ? p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4 : p.x2 + pix * p.c2 + (size_t)(wk.kt0 - k1) * BK + c * 4;
+    a_src2[j] = p.x2 + pix * p.c2 + c * 4;
   }
+  int to_switch = p.c2 ? p.c1 / BK - wk.kt0 : 0x7fffffff;     // k-tiles until the A source changes (<= 0: already on x2)
   const float* b_src[B_INSTR];
   {
     const float* wtile = p.w + (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride : 0) +
@@ -79,6 +84,9 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
   }
 #define PEANUT_DMA_TILE(stage)                                                                                   \
   {                                                                                                              \
+    if (to_switch-- == 0) {                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) a_src[j] = a_src2[j];                                  \
+    }                                                                                                            \
     _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                                        \
       __builtin_amdgcn_global_load_lds((gptr_t)a_src[j], (lptr_t)((stage) + (wave * A_INSTR + j) * 256), 16, 0, 0); \
       a_src[j] += BK;                                                                                            \
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   const int lr = lane >> 3, lp = lane & 7;
 
   const float* a_src[A_INSTR];
+  const float* a_src2[A_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
     const int r = (wave * A_INSTR + j) * 8 + lr;
@@ -202,8 +211,11 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     const size_t pix = (size_t)b * p.H * p.W + (size_t)oy * p.stride * p.W + (size_t)ox * p.stride;
     const int c = lp ^ ((r >> 1) & 7);
-    a_src[j] = p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4;
+    const int k1 = p.c1 / BK;
+    a_src[j] = wk.kt0 < k1 ? p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4 : p.x2 + pix * p.c2 + (size_t)(wk.kt0 - k1) * BK + c * 4;
+    a_src2[j] = p.x2 + pix * p.c2 + c * 4;
   }
+  int to_switch = p.c2 ? p.c1 / BK - wk.kt0 : 0x7fffffff;
   const float* b_src[B_INSTR];
   {
     const float* wtile = p.w + (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride : 0) +
@@ -217,6 +229,9 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   }
 #define PW256_DMA_TILE(stage)                                                                                    \
   {                                                                                                              \
+    if (to_switch-- == 0) {                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) a_src[j] = a_src2[j];                                  \
+    }                                                                                                            \
     _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                                        \
       __builtin_amdgcn_global_load_lds((gptr_t)a_src[j], (lptr_t)((stage) + (wave * A_INSTR + j) * 256), 16, 0, 0); \
       a_src[j] += BK;                                                                                            \

@@ -88,7 +88,7 @@ struct peanut_pred {
   std::vector<std::unique_ptr<ConvLayer>> convs;
   // structure
   ConvLayer* stem[3] = {nullptr, nullptr, nullptr};
-  struct Block { ConvLayer *c1, *c2, *c3, *down; };
+  struct Block { ConvLayer *c1, *c2, *c3, *down, *c3d; };   // c3d: conv3 and the stride-1 downsample as one two-source GEMM (add_fused_c3d)
   std::vector<std::vector<Block>> layers;
   std::vector<ConvLayer*> ppm;
   ConvLayer* bottleneck = nullptr;     // unfolded form: 3x3 over cat([x, ppm...])
@@ -159,6 +159,35 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   return 0;
 }
 
+// conv3 + BN3 and the block's stride-1 downsample conv + BN as ONE pointwise layer over the channel concatenation
+// [conv2 output | block input] (resnet.py:289-305: out = bn3(conv3(t2)) + bn_d(conv_d(x)), then ReLU): the BN scales are
+// folded into the weights (W' = alpha[n] * W[n][c]), the shifts add up.  One launch instead of two, and the identity
+// tensor (as large as the block output) is neither written nor read back.
+int add_fused_c3d(peanut_pred* h, const TensorMap& tm, const std::string& blk, int planes, int inplanes, int cout, ConvLayer** out) {
+  int rc = 0;
+  const int64_t w3s[4] = {cout, planes, 1, 1}, wds[4] = {cout, inplanes, 1, 1};
+  const peanut_tensor* w3 = tm.get(blk + ".conv3.weight", 4, w3s, &rc);
+  if (!w3) return rc;
+  const peanut_tensor* wd = tm.get(blk + ".downsample.0.weight", 4, wds, &rc);
+  if (!wd) return rc;
+  std::vector<float> s3(cout), b3(cout), sd(cout), bd(cout);
+  if ((rc = bn_fold(h, tm, blk + ".bn3", cout, s3.data(), b3.data()))) return rc;
+  if ((rc = bn_fold(h, tm, blk + ".downsample.1", cout, sd.data(), bd.data()))) return rc;
+  const int cin = planes + inplanes;
+  std::vector<float> w((size_t)cout * cin), shift(cout);
+  for (int n = 0; n < cout; ++n) {
+    for (int c = 0; c < planes; ++c) w[(size_t)n * cin + c] = s3[n] * w3->data[(size_t)n * planes + c];
+    for (int c = 0; c < inplanes; ++c) w[(size_t)n * cin + planes + c] = sd[n] * wd->data[(size_t)n * inplanes + c];
+    shift[n] = b3[n] + bd[n];
+  }
+  auto L = std::make_unique<ConvLayer>();
+  L->name = blk + ".conv3+downsample";
+  if ((rc = upload_conv(*L, w.data(), nullptr, shift.data(), cout, cin, cin, 1, 1, 1, 0, 1, 1, PEANUT_PREC_FP32))) return rc;
+  *out = L.get();
+  h->convs.push_back(std::move(L));
+  return 0;
+}
+
 // One layer object whose weight / scale / shift buffers hold those of `parts` (identical shapes and tilings, fp32
 // path) back to back: a grouped GEMM then takes m-tile group g against block g (ConvArgs::mt_per_group,
 // w_group_stride, ss_group_stride).  Null when the parts do not qualify.
@@ -197,7 +226,7 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_
     if (gemm_sx_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return d.s_planes == 3 ? "gemm_sx6_256x256" : "gemm_sx3_256x256";
     return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
   }
-  if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && !two_source && d.cin % 32 == 0 && conv_pw_enabled())
+  if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
     return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
                                                                          : "conv_pw_glds_128x" + std::to_string(d.bn_tile);
   return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
@@ -331,7 +360,8 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       rel(t1);
       Act idn = x;
       bool own_idn = false;
-      if (blk.down) {
+      const bool fused_c3d = blk.c3d != nullptr && !planes && !t2_s && !h->keep_all;   // debug plans keep the two separate layers
+      if (blk.down && !fused_c3d) {
         idn = make_act(ar, B, h2, w2, blk.down->d.cout);
         push_conv(*pl, blk.down, x, nullptr, nullptr, idn, nullptr, &xs);
         own_idn = true;
@@ -340,7 +370,8 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       SAct ys;
       const bool y_s = planes && !last_block && blk.c3->d.cout % 16 == 0;   // next block's conv1 (+ downsample) read it
       if (y_s) ys = make_sact(ar, (size_t)B * h2 * w2, blk.c3->d.cout, planes);
-      push_conv(*pl, blk.c3, t2, nullptr, &idn, y, nullptr, &t2s, y_s ? &ys : nullptr);  // BN3 + identity + ReLU fused (resnet.py:289-305)
+      if (fused_c3d) push_conv(*pl, blk.c3d, t2, &x, nullptr, y);     // [t2 | x] x [W3'; Wd'] + shifts, ReLU: conv3 and the downsample in one GEMM
+      else push_conv(*pl, blk.c3, t2, nullptr, &idn, y, nullptr, &t2s, y_s ? &ys : nullptr);  // BN3 + identity + ReLU fused (resnet.py:289-305)
       if (t2_s) ar.release(t2s.off, t2s.bytes); else rel(t2);
       if (own_idn) rel(idn);
       rel(x);
@@ -619,13 +650,17 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
     for (int bi = 0; bi < stage_blocks[li]; ++bi) {
       const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
       const int s = bi == 0 ? stride : 1, d = bi == 0 ? first_dil : dilation;
-      peanut_pred::Block b{nullptr, nullptr, nullptr, nullptr};
+      peanut_pred::Block b{nullptr, nullptr, nullptr, nullptr, nullptr};
       if ((rc = add_conv(h.get(), tm, p + ".conv1", p + ".bn1", inplanes, inplanes, planes, 1, 1, 0, 1, 1, &b.c1))) return rc;
       if ((rc = add_conv(h.get(), tm, p + ".conv2", p + ".bn2", planes, planes, planes, 3, s, d, d, 1, &b.c2))) return rc;
       // conv3: BN only; the block's final ReLU follows the residual add and is fused here
       if ((rc = add_conv(h.get(), tm, p + ".conv3", p + ".bn3", planes, planes, planes * 4, 1, 1, 0, 1, 1, &b.c3))) return rc;
       if (bi == 0 && (stride != 1 || inplanes != planes * 4)) {
         if ((rc = add_conv(h.get(), tm, p + ".downsample.0", p + ".downsample.1", inplanes, inplanes, planes * 4, 1, stride, 0, 1, 0, &b.down))) return rc;
+        static const bool fuse = [] { const char* e = getenv("PEANUT_FUSE_C3D"); return !(e && e[0] == '0'); }();
+        if (fuse && s == 1 && cfg->precision == PEANUT_PREC_FP32 && planes % 32 == 0 && inplanes % 32 == 0 && conv_pw_enabled() &&
+            (rc = add_fused_c3d(h.get(), tm, p, planes, inplanes, planes * 4, &b.c3d)))
+          return rc;
       }
       blocks.push_back(b);
       inplanes = planes * 4;
