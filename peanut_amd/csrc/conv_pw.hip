@@ -340,7 +340,7 @@ bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
 
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
-  if (conv_pw_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1)) {
+  if (conv_pw_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2)) {
     static int slots256 = 0;
     ConvKParams q = p;
     if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
