@@ -252,6 +252,34 @@ int add_stem_s2d(peanut_rcnn* h, const TensorMap& tm, const std::string& name, i
   return 0;
 }
 
+// conv3 + FrozenBN and the block's stride-1 shortcut conv + FrozenBN as one pointwise layer over [conv2 output | block
+// input] (detectron2 BottleneckBlock.forward: out = conv3(out) + shortcut(x), then ReLU): scales folded into the weights,
+// shifts added -- the same restatement as pred_api.hip: add_fused_c3d.
+int add_fused_c3s(peanut_rcnn* h, const TensorMap& tm, const std::string& blk, int bott, int cin, int cout, ConvLayer** out) {
+  int rc = 0;
+  const int64_t w3s[4] = {cout, bott, 1, 1}, wss[4] = {cout, cin, 1, 1};
+  const peanut_tensor* w3 = tm.get(blk + ".conv3.weight", 4, w3s, &rc);
+  if (!w3) return rc;
+  const peanut_tensor* ws = tm.get(blk + ".shortcut.weight", 4, wss, &rc);
+  if (!ws) return rc;
+  std::vector<float> s3(cout), b3(cout), ss(cout), bs(cout);
+  if ((rc = bn_fold_eps(tm, blk + ".conv3.norm", cout, h->cfg.bn_eps, s3.data(), b3.data()))) return rc;
+  if ((rc = bn_fold_eps(tm, blk + ".shortcut.norm", cout, h->cfg.bn_eps, ss.data(), bs.data()))) return rc;
+  const int k = bott + cin;
+  std::vector<float> w((size_t)cout * k), shift(cout);
+  for (int n = 0; n < cout; ++n) {
+    for (int c = 0; c < bott; ++c) w[(size_t)n * k + c] = s3[n] * w3->data[(size_t)n * bott + c];
+    for (int c = 0; c < cin; ++c) w[(size_t)n * k + bott + c] = ss[n] * ws->data[(size_t)n * cin + c];
+    shift[n] = b3[n] + bs[n];
+  }
+  auto L = std::make_unique<ConvLayer>();
+  L->name = blk + ".conv3+shortcut";
+  if ((rc = upload_conv(*L, w.data(), nullptr, shift.data(), cout, k, k, 1, 1, 1, 0, 1, 1, PEANUT_PREC_FP32))) return rc;
+  *out = L.get();
+  h->convs.push_back(std::move(L));
+  return 0;
+}
+
 void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
   // detectron2 ResizeShortestEdge.get_output_shape
   const double size = (double)c.min_size;
@@ -321,7 +349,7 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
     for (const auto& blk : h->stages[si]) {
       Act idn = cur;
       bool own = false;
-      if (blk.shortcut) {
+      if (blk.shortcut && !blk.c3s) {
         idn = conv_out_act(ar, blk.shortcut, cur);
         push_rconv(*pl, ar, blk.shortcut, cur, nullptr, idn);
         own = true;
@@ -332,7 +360,13 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
       push_rconv(*pl, ar, blk.c2, t1, nullptr, t2);
       rel(t1);
       Act y = conv_out_act(ar, blk.c3, t2);
-      push_rconv(*pl, ar, blk.c3, t2, &idn, y);        // + shortcut, ReLU fused
+      if (blk.c3s) {                                    // [t2 | x] x [W3'; Ws'] + shifts, ReLU: conv3 and the shortcut in one GEMM
+        push_rconv(*pl, ar, blk.c3s, t2, nullptr, y);
+        pl->ops.back().in2 = cur;
+        pl->ops.back().has_in2 = true;
+      } else {
+        push_rconv(*pl, ar, blk.c3, t2, &idn, y);      // + shortcut, ReLU fused
+      }
       rel(t2);
       if (own) rel(idn);
       // the block input dies here unless it is a stage output that the FPN laterals still need
@@ -376,7 +410,7 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   }
   size_t hw = pl->splitk.off + Arena::round_up(pl->splitk.bytes);
   for (const auto& op : pl->ops)
-    for (const Act* a : {&op.in, &op.res, &op.out, &op.wino_v, &op.wino_m})
+    for (const Act* a : {&op.in, &op.in2, &op.res, &op.out, &op.wino_v, &op.wino_m})
       if (a->bytes && a->off + Arena::round_up(a->bytes) > hw) hw = a->off + Arena::round_up(a->bytes);
   pl->bytes = hw;
   return pl;
@@ -429,11 +463,15 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
       const std::string p = "backbone.bottom_up.res" + std::to_string(si + 2) + "." + std::to_string(bi);
       const int s = (bi == 0 && si > 0) ? 2 : 1;
       const int s1 = cfg->stride_in_1x1 ? s : 1, s3 = cfg->stride_in_1x1 ? 1 : s;
-      peanut_rcnn::Block b{nullptr, nullptr, nullptr, nullptr};
+      peanut_rcnn::Block b{nullptr, nullptr, nullptr, nullptr, nullptr};
       if (cin != cout && (rc = add_rconv(h.get(), tm, p + ".shortcut", cin, cin, cout, 1, s, 0, true, 0, &b.shortcut))) return rc;
       if ((rc = add_rconv(h.get(), tm, p + ".conv1", cin, cin, bott, 1, s1, 0, true, 1, &b.c1))) return rc;
       if ((rc = add_rconv(h.get(), tm, p + ".conv2", bott, bott, bott, 3, s3, 1, true, 1, &b.c2))) return rc;
       if ((rc = add_rconv(h.get(), tm, p + ".conv3", bott, bott, cout, 1, 1, 0, true, 1, &b.c3))) return rc;   // ReLU after the add
+      static const bool fuse = [] { const char* e = getenv("PEANUT_FUSE_C3D"); return !(e && e[0] == '0'); }();
+      if (fuse && b.shortcut && s == 1 && cfg->precision == PEANUT_PREC_FP32 && bott % 32 == 0 && cin % 32 == 0 && conv_pw_enabled() &&
+          (rc = add_fused_c3s(h.get(), tm, p, bott, cin, cout, &b.c3s)))
+        return rc;
       blocks.push_back(b);
       cin = cout;
     }
@@ -516,6 +554,7 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
         a.res = op.has_res ? P(op.res) : nullptr;
         a.y = OUT(op);
         a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = op.out.H; a.Wo = op.out.W;
+        if (op.has_in2) { a.x2 = P(op.in2); a.c2 = op.in2.C; }
         a.ws = P(pl->splitk); a.ws_floats = kSplitKScratchFloats;
         if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, s))) return rc;
         break;

@@ -11,9 +11,9 @@ struct ROp {
   ROpKind kind;
   std::string name, kernel;
   const ConvLayer* conv = nullptr;
-  Act in, res, out;
+  Act in, in2, res, out;      // in2: second source of a two-source pointwise layer (channels [in.C, in.C + in2.C))
   Act wino_v, wino_m;         // scratch of the Winograd form (R_CONV of a layer that carries one)
-  bool has_res = false, has_wino = false;
+  bool has_res = false, has_wino = false, has_in2 = false;
   double flops = 0;
   float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
   int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
@@ -40,7 +40,7 @@ struct peanut_rcnn {
   std::vector<std::unique_ptr<peanut::ConvLayer>> convs;
   peanut::ConvLayer* stem = nullptr;
   peanut::ConvLayer* stem_s2d = nullptr;   // the same conv on the 2x2 space-to-depth input (rcnn_api.hip), when applicable
-  struct Block { peanut::ConvLayer *shortcut, *c1, *c2, *c3; };
+  struct Block { peanut::ConvLayer *shortcut, *c1, *c2, *c3, *c3s; };   // c3s: conv3 + stride-1 shortcut as one two-source GEMM
   std::vector<std::vector<Block>> stages;
   peanut::ConvLayer *lateral[4] = {nullptr}, *output[4] = {nullptr};   // levels 2..5
   peanut::ConvLayer *rpn_conv = nullptr, *rpn_obj = nullptr, *rpn_delta = nullptr;
