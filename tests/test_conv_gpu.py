@@ -68,6 +68,30 @@ def test_conv_two_source_concat():
     assert err < 5e-5, err
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, c1, c2, cout): 1x1 over [x | x2] -- the fused conv3 + downsample layers (pred_api.hip: add_fused_c3d)
+    (2, 30, 30, 64, 64, 256),        # layer1.0 shape class: 128 x 64 tiles, K = 128
+    (1, 23, 17, 256, 512, 1024),     # ragged M, 128 x 128 tiles; few tiles, so split-K parts start on either side of the switch
+    (4, 64, 64, 512, 1024, 256),     # M * cout large, K = 1536: the 256 x 128 three-stage kernel
+    (1, 9, 9, 32, 2048, 128),        # the switch after the first k-tile, long second source
+], ids=lambda c: "x".join(map(str, c)))
+def test_pointwise_two_source_matches_torch(case):
+    """LDS-DMA pointwise kernels reading their A k-tiles from two tensors (csrc/conv_pw.hip: the source pointer switches at
+    k-tile c1 / 32) against a plain conv over the concatenation, with residual-free epilogue, scale / shift and ReLU."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, c1, c2, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) * scale[None, :, None, None] + shift[None, :, None, None])
+    conv = FusedConv(w, scale, shift, relu=True)
+    y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+    err = (y - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
 def test_conv_transpose_detecting():
     """Asymmetric one-hot probes: catches swapped rows/cols in the accumulator write-back."""
     from peanut_amd.ops import FusedConv
