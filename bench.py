@@ -44,10 +44,13 @@ from peanut_amd.weights import PredCfg, conv_flops_per_map, make_seeded_state_di
 
 # MI355X_MICROARCH.md: fp32 MFMA 157.3 TF (v_mfma_f32_32x32x2_f32); dense bf16/f16 MFMA 2.5 PF, of which a
 # split-product mode can deliver at most one third as fp32-equivalent FLOPs (3 MFMAs per product).
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6,
+               "bf16x6rs": 2500.0 / 6, "bf16x3rs": 2500.0 / 3}
 DTYPE = {"fp32": "f32", "bf16x3": "f32 (bf16x3 split products, f32 accumulate)",
          "fp16x3": "f32 (fp16x3 split products, f32 accumulate)",
-         "bf16x6": "f32 (emulated: 3 bf16 pieces per value, 6 MFMA products per fp32 product, f32 accumulate)"}
+         "bf16x6": "f32 (emulated: 3 bf16 pieces per value, 6 MFMA products per fp32 product, f32 accumulate)",
+         "bf16x6rs": "f32 (emulated: 3 bf16 pieces per value split in registers, 6 MFMA products per fp32 product, f32 accumulate)",
+         "bf16x3rs": "f32 (2 bf16 pieces per value split in registers, 3 MFMA products per fp32 product, f32 accumulate)"}
 MODE_NOTES = {
     "bf16x3": "opt-in split-precision mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; "
               "1.0e-4 max-abs on the logits vs the reference golden vectors (bound 1e-3); not the headline value",

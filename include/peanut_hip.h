@@ -27,6 +27,9 @@ extern "C" {
 #define PEANUT_EWEIGHTS (-4) /* missing or mis-shaped tensor in the state dict */
 
 const char* peanut_last_error(void);
+/* kernel family the calling thread's most recent conv / GEMM launch selected, e.g. "conv_pw_glds_256x128" (for tests
+ * and profiles: lets a parity test assert which kernel produced the result it checked) */
+const char* peanut_last_conv_kernel(void);
 /* library / ABI version and the arch it was compiled for ("gfx950") */
 int peanut_abi_version(void);
 const char* peanut_build_arch(void);
@@ -75,6 +78,12 @@ typedef struct peanut_pred_cfg {
  * 1x1 convs and the Winograd GEMMs use it (csrc/gemm_sx.hip, operands pre-split by their producers); the other
  * layers stay on the fp32 MFMA kernel. */
 #define PEANUT_PREC_BF16X6 3
+/* BF16X6_RS / BF16X3_RS ("register split", csrc/gemm_rs.hip): the same six (three) piece products, but activations
+ * stay fp32 in HBM and LDS -- the forward's tensors, transforms and fusions are exactly the fp32 mode's -- and are
+ * split into their bf16 pieces in registers after the fragment read; only the weights are pre-split.  Also available
+ * at the operator level (peanut_conv_create). */
+#define PEANUT_PREC_BF16X6_RS 4
+#define PEANUT_PREC_BF16X3_RS 5
 
 /* One entry of an mmcv/PyTorch state dict (HOST memory, fp32, contiguous, OIHW for convs). */
 typedef struct peanut_tensor {
@@ -326,7 +335,8 @@ int peanut_seg_accumulate(const uint8_t* masks, const int32_t* classes, const fl
 typedef struct peanut_conv peanut_conv_t;
 /* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
  * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
- * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X3 / FP16X3; the split modes need
+ * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X3 / FP16X3 / BF16X6_RS / BF16X3_RS (in the RS modes the
+ * pointwise layers and the Winograd position GEMMs run on the bf16 matrix cores, every other layer in fp32); the split modes need
  * cin_pad % 32 == 0 and the call FAILS with PEANUT_EINVAL otherwise (no silent change of arithmetic);
  * peanut_conv_precision() returns the PEANUT_PREC_* mode the layer actually runs in.  conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
  * >= 256 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */

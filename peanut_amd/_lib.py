@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 7     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 8     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -67,6 +67,7 @@ class TensorC(C.Structure):
 _P = C.c_void_p
 SIGNATURES = {
     "peanut_last_error": (C.c_char_p, []),
+    "peanut_last_conv_kernel": (C.c_char_p, []),
     "peanut_abi_version": (C.c_int, []),
     "peanut_build_arch": (C.c_char_p, []),
     "peanut_pred_create": (C.c_int, [C.POINTER(_P), C.POINTER(PredCfgC), C.POINTER(TensorC), C.c_int]),
@@ -130,7 +131,7 @@ SIGNATURES = {
 
 
 CONV_ALGOS = {"auto": 0, "direct": 1}   # PEANUT_ALGO_*
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x3": 2, "bf16x6": 3}   # PEANUT_PREC_* (bf16x6: prediction planner only)
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x3": 2, "bf16x6": 3, "bf16x6rs": 4, "bf16x3rs": 5}   # PEANUT_PREC_* (bf16x6: prediction planner only)
 
 
 def lib_path() -> str:

@@ -9,6 +9,9 @@ namespace peanut {
 // ---- error plumbing (thread-local message, negative codes; include/peanut_hip.h) ----
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+// the kernel family the calling thread's last conv launch picked (string with static storage; peanut_last_conv_kernel)
+void note_kernel(const char* family);
+const char* noted_kernel();
 
 #define PEANUT_HIP_CHECK(expr)                                                            \
   do {                                                                                    \
@@ -35,6 +38,7 @@ struct ConvDesc {
   const float* shift;      // device [cout_pad]
   const void* w_s;         // device: S-packed weights of a pointwise layer (gemm_sx.hip), or null
   int s_planes;            // bf16 pieces per value in w_s and in S activations: 2 (bf16x3) or 3 (bf16x6)
+  int rs;                  // 1: pointwise layer on gemm_rs.hip -- fp32 activations split in registers, weights from w_s
 };
 
 struct ConvArgs {
@@ -97,6 +101,9 @@ int launch_wino_output(const float* Mb, const float* scale, const float* shift, 
 bool gemm_sx_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
 size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
 void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
+// ---- emulated-fp32 GEMM with fp32 activations split in registers (gemm_rs.hip) ----
+bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
+const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_tile, int cin, int planes);
 // bytes of an S tensor of `rows` x `channels`
 inline size_t s_tensor_bytes(size_t rows, int channels, int planes) { return (rows + 127) / 128 * 128 * (size_t)channels * 2 * planes; }
 inline int s_rows_pad(size_t rows) { return (int)((rows + 127) / 128 * 128); }

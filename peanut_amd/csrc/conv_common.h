@@ -89,6 +89,8 @@ bool conv_pw_enabled();
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream);
 // gemm_sx.hip: pointwise layer / grouped GEMM on S-format operands (p.xs, p.w = S-packed weights, nkt = cin / 16)
 int launch_gemm_sx(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
+// gemm_rs.hip: pointwise layer / grouped GEMM, fp32 A (p.x, p.x2) split in registers, p.w = S-packed weights, nkt = cin / 16
+int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
 
 
 // Work decomposition of one launch.

@@ -324,7 +324,8 @@ static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream
 
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   if (a.c1 + a.c2 != d.cin) return fail(-2, "launch_conv: c1 + c2 != cin");
-  if (a.c1 % d.bk != 0 || (a.c2 % d.bk) != 0) return fail(-2, "launch_conv: channel split not a multiple of BK");
+  const int kgran = d.rs ? 16 : d.bk;     // k-tile of the kernel that will run
+  if (a.c1 % kgran != 0 || (a.c2 % kgran) != 0) return fail(-2, "launch_conv: channel split not a multiple of the k-tile");
   ConvKParams p{};
   p.x = a.x; p.x2 = a.x2 ? a.x2 : a.x; p.w = d.w_packed; p.scale = d.scale; p.shift = d.shift;
   p.res = a.res; p.y = a.y;
@@ -343,6 +344,12 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
   p.ys = a.ys; p.ys_rows = a.ys_rows; p.s_planes = d.s_planes; p.skip_f32 = a.skip_f32;
   if (p.ys && (d.cout % 16 || (d.s_planes != 2 && d.s_planes != 3))) return fail(-2, "launch_conv: S output needs cout % 16 == 0 and 2 or 3 planes");
+  if (d.rs) {   // emulated-fp32 GEMM, fp32 activations split in registers
+    if (!d.w_s || a.xs || a.ys) return fail(-2, "launch_conv: register-split layer needs S-packed weights and fp32 tensors");
+    p.w = static_cast<const float*>(d.w_s);
+    p.nkt = d.cin / 16;
+    return launch_gemm_rs(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
+  }
   if (a.xs) {   // emulated-fp32 GEMM on pre-split operands
     if (!d.w_s) return fail(-2, "launch_conv: layer has no S-packed weights");
     p.xs = a.xs; p.xs_rows = a.xs_rows; p.w = static_cast<const float*>(d.w_s);
@@ -351,10 +358,16 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   }
   if (d.mode != 0) {
     if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
+    note_kernel(d.mode == 2 ? "conv_igemm_fp16x3" : "conv_igemm_bf16x3");
     return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);
   }
   if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c1 % 32 == 0 && p.c2 % 32 == 0 && (p.c2 == 0 || p.stride == 1) && conv_pw_enabled())
     return launch_conv_pw(p, d.bn_tile, a.ws, a.ws_floats, stream);
+  {
+    static const char* const names[2][3] = {{"conv_igemm_128x128x32", "conv_igemm_128x64x32", "conv_igemm_128x32x32"},
+                                            {"conv_igemm_128x128x16", "conv_igemm_128x64x16", "conv_igemm_128x32x16"}};
+    note_kernel(names[d.bk == 32 ? 0 : 1][d.bn_tile == 128 ? 0 : (d.bn_tile == 64 ? 1 : 2)]);
+  }
   if (d.bk == 32) {
     if (d.bn_tile == 128) return launch_t<128, 128, 32, 2, 2>(p, a.ws, a.ws_floats, stream);
     if (d.bn_tile == 64) return launch_t<128, 64, 32, 2, 2>(p, a.ws, a.ws_floats, stream);

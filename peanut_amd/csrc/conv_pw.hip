@@ -344,9 +344,11 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
     static int slots256 = 0;
     ConvKParams q = p;
     if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
+    note_kernel("conv_pw_glds_256x128");
     return launch_with_tail_split<decltype(&conv_pw_glds256_kernel), 256, 128, 512>(&conv_pw_glds256_kernel, q, ws, ws_floats, stream,
                                                                                      &slots256);
   }
+  note_kernel(bn_tile == 128 ? "conv_pw_glds_128x128" : (bn_tile == 64 ? "conv_pw_glds_128x64" : "conv_pw_glds_128x32"));
   if (bn_tile == 128) return launch_pw_t<128, 2, 2>(p, ws, ws_floats, stream);
   if (bn_tile == 64) return launch_pw_t<64, 2, 2>(p, ws, ws_floats, stream);
   if (bn_tile == 32) return launch_pw_t<32, 4, 1>(p, ws, ws_floats, stream);

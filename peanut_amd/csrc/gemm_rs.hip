@@ -1,0 +1,331 @@
+// fp32 GEMM emulated on the bf16 matrix cores with fp32 activations: the A operand stays fp32 in HBM and in LDS and is
+// split into bf16 pieces IN REGISTERS, after the fragment read ("RS" = register split); only the weights are pre-split.
+//
+// Why (round 3): gemm_sx.hip keeps activations as pre-split bf16 pieces ("S" format, 6 bytes per value, written by the
+// producer next to the fp32 tensor).  Its k-loop is nothing but LDS-DMA + fragment reads + MFMAs, but the forward then
+// moves 81.6 GB per batch-32 step against 58.9 GB in fp32 mode, and its expanding 1x1 convs (fp32 output + S copy +
+// residual: 14-15.5 bytes per output element) are HBM-bound as a pipeline.  Here the data flow is EXACTLY the fp32
+// mode's (same tensors, same Winograd transforms, same fused conv3 + downsample layers, same epilogue); what changes
+// is the inner product: a k-tile of 16 channels of A travels global -> LDS as fp32 by LDS-DMA (64-byte rows, like
+// conv_pw.hip), a lane reads its 8 consecutive k of a row (two ds_read_b128) and peels off the bf16 pieces
+//     p0 = bf16(x), r = x - p0 (exact), p1 = bf16(r), r' = r - p1 (exact), p2 = bf16(r')      x = p0 + p1 + p2 exactly
+// with v_cvt_pk_bf16_f32 (round to nearest even, two values per instruction), a shift / mask to widen a piece again and
+// v_sub_f32: 5.5 VALU instructions per A element.  A wave tile of 64 (M) x 128 (N) splits 16 elements per lane and
+// k-tile (88 VALU) for 48 MFMAs (v_mfma_f32_32x32x16_bf16, 32 cycles each on its SIMD): ~2 VALU per MFMA, inside the
+// <= 5 issue slots a bf16 MFMA hides (MI355X_MICROARCH.md, cycle constants).  The split is repeated by the WN waves that
+// share an A row block -- which is why the wave tile is wide in N, not in M.
+//
+// Product terms as in gemm_sx.hip: NP = 3 -> hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (bf16x6, dropped terms
+// <= 2^-24 |ab|: fp32-class), NP = 2 -> hi*hi + hi*lo + lo*hi (bf16x3), smallest terms first, fp32 accumulation.
+//
+// LDS image of a stage: A [BM rows][16 floats], 16-byte chunk c of row r stored at chunk position c ^ ((r >> 2) & 3)
+// (applied to the DMA source address and to the ds_read_b128 address alike): the 16 lanes of a ds_read_b128 lane group
+// then hit 16 distinct 16-byte bank groups.  B: the S-packed weights of gemm_sx.hip, [plane][BN rows][16 bf16] per
+// k-tile (a 256-wide n-tile is two adjacent packed 128-row tiles), the two halves of a row swapped for rows with bit 3
+// set.  Three stages; a k-tile is requested two iterations before it is read (counted s_waitcnt vmcnt(N) + raw
+// s_barrier: a __syncthreads would drain the DMA queue).
+//
+// Replaces the same reference call sites as conv_pw.hip / gemm_sx.hip: resnet.py:267-307 (conv1 / conv3 / downsample),
+// the position GEMMs of the Winograd form of conv2 and of psp_head.py:86-93.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_common.h"
+
+namespace peanut {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// two fp32 -> two bf16 (round to nearest even) packed in one dword, first value in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// the bf16 pieces of 8 consecutive k of one row: x = v0 | v1 (fp32) -> pc[q] = piece q of the 8 values
+template <int NP>
+__device__ __forceinline__ void split_frag(const f32x4& v0, const f32x4& v1, bf16x8 (&pc)[NP]) {
+  u32x4 w[NP];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = i < 2 ? v0[2 * i] : v1[2 * i - 4], b = i < 2 ? v0[2 * i + 1] : v1[2 * i - 3];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const unsigned pk = cvt_pk_bf16(a, b);
+      w[q][i] = pk;
+      if (q + 1 < NP) {
+        a -= __uint_as_float(pk << 16);            // exact: the piece agrees with the value in its leading bits
+        b -= __uint_as_float(pk & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q) pc[q] = __builtin_bit_cast(bf16x8, w[q]);
+}
+
+template <int BM, int BN, int WM, int WN, int NP, bool STAG>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams p) {
+  constexpr int NT = 64 * WM * WN, NW = WM * WN, STAGES = 3;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = NP * BN * 32, STAGE = A_BYTES + B_BYTES;   // one k-tile = 16 channels
+  constexpr int BSUB = BN > 128 ? 128 : BN;            // rows of one packed weight tile
+  constexpr int BSUB_BYTES = NP * BSUB * 32;
+  constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024, PIECES = A_PIECES + B_PIECES;   // 1 KiB DMA pieces
+  constexpr int PER_WAVE = (PIECES + NW - 1) / NW;
+  constexpr bool EVEN = PIECES % NW == 0;
+  constexpr int CS = BN + 4;
+  constexpr int EP = (BM * CS * 4 > STAGES * STAGE) ? WM : 1;
+  constexpr int ER = BM / EP;
+  constexpr int SMEM_BYTES = (STAGES * STAGE > ER * CS * 4) ? STAGES * STAGE : ER * CS * 4;
+  static_assert(TM % 32 == 0 && TN % 32 == 0 && (NP == 2 || NP == 3) && PER_WAVE <= 6, "tile configuration");
+  static_assert(BN <= 128 || BN == 256, "a 256-wide n-tile is two packed 128-row weight tiles");
+  static_assert(!STAG || (NW == 8 && MI == 2), "the rotated schedule is for two waves per SIMD and two row blocks per wave");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x;
+  const Work wk = decode_work(p);
+  const int mt = wk.mt, nt = wk.nt, nk = wk.kt1 - wk.kt0;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- per-lane DMA sources.  Piece i < A_PIECES: rows 16 i .. 16 i + 15 of the A tile (lane l: row l / 4, chunk
+  //      position l % 4); the rest: 32 rows of a plane of the weight tile (lane l: row l / 2, half l % 2). ----
+  const unsigned char* src[PER_WAVE];
+  const unsigned char* src2[PER_WAVE];     // A pieces: the same place in the second source (k-tile 0 of x2)
+  unsigned step[PER_WAVE];
+  const int k1 = p.c1 / 16;                // k-tiles of the first source
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int piece = wave * PER_WAVE + j;
+    if (piece < A_PIECES) {
+      const int r = piece * 16 + (lane >> 2);
+      const int m = m0 + r;
+      const int mc = m < p.M ? m : p.M - 1;   // rows past the end compute a valid row and are dropped
+      const int b = mc / p.HoWo;
+      const int rem = mc - b * p.HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const size_t pix = (size_t)b * p.H * p.W + (size_t)oy * p.stride * p.W + (size_t)ox * p.stride;
+      const int c = (lane & 3) ^ ((r >> 2) & 3);
+      const unsigned char* s1 = reinterpret_cast<const unsigned char*>(p.x + pix * p.c1) + (size_t)wk.kt0 * 64 + c * 16;
+      const unsigned char* s2 = reinterpret_cast<const unsigned char*>(p.x2 + pix * p.c2) + c * 16;
+      src[j] = wk.kt0 < k1 ? s1 : s2 + (size_t)(wk.kt0 - k1) * 64;
+      src2[j] = s2;
+      step[j] = 64;
+    } else {
+      const int pb = piece - A_PIECES;
+      const int pbc = pb < B_PIECES ? pb : B_PIECES - 1;      // past the end (uneven split): clamp, never issued
+      const int q = pbc / (BN / 32), r = (pbc % (BN / 32)) * 32 + (lane >> 1);
+      const int sub = r / BSUB, rs = r % BSUB;
+      const int h = (lane & 1) ^ ((r >> 3) & 1);
+      const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) +
+                                   (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * (size_t)p.w_group_stride : 0) +
+                                   ((size_t)(nt * (BN / BSUB) + sub) * p.nkt + wk.kt0) * BSUB_BYTES;
+      src[j] = wtile + ((size_t)q * BSUB + rs) * 32 + h * 16;
+      src2[j] = src[j];
+      step[j] = BSUB_BYTES;
+    }
+  }
+  int to_switch = p.c2 ? k1 - wk.kt0 : 0x7fffffff;     // k-tiles until the A source changes (<= 0: already on x2)
+  // the source switch (fused conv3 + downsample layers: [t2 | x]) only concerns the A pieces
+#define RS_DMA_TILE(stage)                                                                                        \
+  {                                                                                                               \
+    if (to_switch-- == 0) {                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j)                                                        \
+        if (wave * PER_WAVE + j < A_PIECES) src[j] = src2[j];                                                     \
+    }                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < PER_WAVE; ++j) {                                                        \
+      const int piece = wave * PER_WAVE + j;                                                                      \
+      if (EVEN || piece < PIECES)                                                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t)src[j], (lptr_t)((stage) + piece * 1024), 16, 0, 0);            \
+      src[j] += step[j];                                                                                          \
+    }                                                                                                             \
+  }
+  const int my_pieces = (wave + 1) * PER_WAVE <= PIECES ? PER_WAVE : (PIECES - wave * PER_WAVE > 0 ? PIECES - wave * PER_WAVE : 0);
+#define RS_WAIT_ALL_BUT_LAST_TILE()                                                \
+  if constexpr (EVEN && PER_WAVE == 6) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }      \
+  else if constexpr (EVEN && PER_WAVE == 5) { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); } \
+  else if constexpr (EVEN && PER_WAVE == 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+  else if constexpr (EVEN && PER_WAVE == 3) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
+  else {                                                                           \
+    switch (my_pieces) {                                                           \
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;              \
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;              \
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;              \
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;              \
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;              \
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;              \
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;             \
+    }                                                                              \
+  }
+#define RS_BARRIER()                                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("" ::: "memory");
+#define RS_DMA_LANDED_BARRIER()                    \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+  RS_BARRIER()
+
+  // ---- MFMA fragment coordinates: lane (li, hi) takes k = 8 hi .. 8 hi + 7 of row li of each 32-row block ----
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  const int af = (li >> 2) & 3;                                    // chunk permutation of this lane's A rows
+  const int a_off0 = (wm * TM + li) * 64 + (((2 * hi) ^ af) * 16);
+  const int a_off1 = (wm * TM + li) * 64 + (((2 * hi + 1) ^ af) * 16);
+  const int b_row = A_BYTES + (wn * TN + li) * 32 + ((hi ^ ((li >> 3) & 1)) * 16);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int t = 0; t < MI; ++t)
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+#define RS_HEAD(cur)                                                                                              \
+  {                                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t) {                                                              \
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>((cur) + a_off0 + t * 32 * 64);                             \
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>((cur) + a_off1 + t * 32 * 64);                             \
+      split_frag<NP>(v0, v1, ap[t]);                                                                              \
+    }                                                                                                             \
+    _Pragma("unroll") for (int q = 0; q < NP; ++q)                                                                \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                              \
+        bf[q][u] = *reinterpret_cast<const bf16x8*>((cur) + q * (BN * 32) + b_row + u * 32 * 32);                 \
+  }
+#define RS_MFMA_ROWS(T0, T1)                                                                                      \
+  _Pragma("unroll") for (int t = (T0); t < (T1); ++t)                                                             \
+    _Pragma("unroll") for (int u = 0; u < NI; ++u) {                                                              \
+      if constexpr (NP == 3) {                                                                                    \
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][2], bf[0][u], acc[t][u], 0, 0, 0);              \
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[2][u], acc[t][u], 0, 0, 0);              \
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][1], bf[1][u], acc[t][u], 0, 0, 0);              \
+      }                                                                                                           \
+      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][1], bf[0][u], acc[t][u], 0, 0, 0);                \
+      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[1][u], acc[t][u], 0, 0, 0);                \
+      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[0][u], acc[t][u], 0, 0, 0);                \
+    }
+  // the next k-tile must have landed; the one just requested may stay in flight across the barrier
+#define RS_NEXT_TILE_BARRIER(more)                                  \
+  if (more) { RS_WAIT_ALL_BUT_LAST_TILE(); RS_BARRIER(); }          \
+  else { RS_DMA_LANDED_BARRIER(); }
+
+  RS_DMA_TILE(smem);
+  if (nk > 1) {
+    RS_DMA_TILE(smem + STAGE);
+    RS_WAIT_ALL_BUT_LAST_TILE();
+    RS_BARRIER();
+  } else {
+    RS_DMA_LANDED_BARRIER();
+  }
+  ResPrefetch rp;
+  rp.on = false;
+  int o_cur = 0, o_fill = 2 * STAGE, o_mid = STAGE;
+  bf16x8 ap[MI][NP], bf[NP][NI];
+  // Eight-wave workgroups put two waves on every SIMD (waves w and w + 4: MI355X_MICROARCH.md, LDS section).  One
+  // barrier per k-tile would start both on their split (VALU only) at the same moment, with the SIMD's matrix pipe idle,
+  // and then make them queue for it.  STAG: the second half of the waves runs its loop rotated by half a k-tile --
+  //     first half :  barrier | read + split kt | MFMAs rows 0 (kt) | MFMAs rows 1 (kt)          | barrier
+  //     second half:  barrier | MFMAs rows 1 (kt - 1, operands kept in registers) | read + split kt | MFMAs rows 0 (kt) | barrier
+  // so that on every SIMD one wave's split runs under the other wave's MFMAs.  Same LDS intervals for both halves
+  // (a stage is read between the barrier that publishes it and the next one), same number of barriers and DMA requests.
+  if (STAG && wave >= NW / 2) {
+    {   // k-tile 0: nothing pending from a previous tile
+      const bool more = 2 < nk;
+      if (more) RS_DMA_TILE(smem + o_fill);
+      RS_HEAD(smem + o_cur);
+      RS_MFMA_ROWS(0, MI / 2);
+      RS_NEXT_TILE_BARRIER(more);
+      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+    }
+    for (int kt = 1; kt < nk; ++kt) {
+      const unsigned char* const cur = smem + o_cur;
+      const bool more = kt + 2 < nk;
+      if (more) RS_DMA_TILE(smem + o_fill);
+      RS_MFMA_ROWS(MI / 2, MI);
+      __builtin_amdgcn_sched_barrier(0);      // the reads below must not be hoisted over the MFMAs: the old operands die first
+      RS_HEAD(cur);
+      RS_MFMA_ROWS(0, MI / 2);
+      RS_NEXT_TILE_BARRIER(more);
+      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+    }
+    RS_MFMA_ROWS(MI / 2, MI);
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* const cur = smem + o_cur;
+      const bool more = kt + 2 < nk;
+      if (more) RS_DMA_TILE(smem + o_fill);
+      // residual rows requested under the last k-tile's MFMAs -- not in the 244-register eight-wave kernels, where the 32
+      // registers of the prefetch spill; their epilogue requests them before the accumulators go through LDS
+      if (NW < 8 && kt == nk - 1) rp = conv_res_prefetch<BM, BN, EP, NT>(p, wk, m0, n0);
+      RS_HEAD(cur);
+      RS_MFMA_ROWS(0, MI);
+      RS_NEXT_TILE_BARRIER(more);
+      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+    }
+  }
+  if (STAG) { RS_BARRIER(); }     // the rotated half finishes after the loop's last barrier; the epilogue reuses the stages
+#undef RS_HEAD
+#undef RS_MFMA_ROWS
+#undef RS_NEXT_TILE_BARRIER
+#undef RS_DMA_TILE
+#undef RS_DMA_LANDED_BARRIER
+#undef RS_WAIT_ALL_BUT_LAST_TILE
+#undef RS_BARRIER
+
+  conv_epilogue<BM, BN, WM, WN, EP, NT>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0, NW < 8 ? &rp : nullptr);
+}
+
+template <int BM, int BN, int WM, int WN, int NP>
+int launch_rs_t(ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream) {
+  p.ntiles = (p.cout + BN - 1) / BN;             // n-tiles of THIS kernel (decode_work)
+  if (p.mt_per_group) p.mt_per_group /= BM / 128;   // BM-row tiles per weight group
+  if constexpr (WM * WN == 8) {
+    static const bool stag = [] { const char* e = getenv("PEANUT_RS_STAG"); return !(e && e[0] == '0'); }();
+    if (stag) {
+      static int slots_s = 0;
+      return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP, true>), BM, BN, 64 * WM * WN>(
+          &gemm_rs_kernel<BM, BN, WM, WN, NP, true>, p, ws, ws_floats, stream, &slots_s);
+    }
+  }
+  static int slots = 0;
+  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP, false>), BM, BN, 64 * WM * WN>(
+      &gemm_rs_kernel<BM, BN, WM, WN, NP, false>, p, ws, ws_floats, stream, &slots);
+}
+
+}  // namespace
+
+// 256 x 256 tiles (one workgroup per CU) where the shape fills the chip with them and K is long enough to amortise
+// a tile's epilogue, which nobody computes under with one workgroup per CU; else 128 x 128 (two per CU) / 128 x 64.
+bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin) {
+  static const int min_k = [] { const char* e = getenv("PEANUT_RS256_MINK"); return e ? atoi(e) : 512; }();
+  return cin >= min_k && bn_tile == 128 && cout % 256 == 0 && mt_per_group % 2 == 0 && M * cout >= 256LL * 256 * 256;
+}
+
+const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_tile, int cin, int planes) {
+  if (gemm_rs_uses_256(cout, M, mt_per_group, bn_tile, cin)) return planes == 3 ? "gemm_rs6_256x256" : "gemm_rs3_256x256";
+  if (bn_tile == 128) return planes == 3 ? "gemm_rs6_128x128" : "gemm_rs3_128x128";
+  return planes == 3 ? "gemm_rs6_128x64" : "gemm_rs3_128x64";
+}
+
+// p.x / p.x2: fp32 A (two sources allowed), p.w: S-packed weights (bn_tile rows per packed tile), p.nkt = cin / 16
+int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream) {
+  if (p.ntaps != 1 || p.pad != 0 || p.c1 % 16 || p.c2 % 16 || (p.c2 && p.stride != 1) || (bn_tile != 128 && bn_tile != 64) ||
+      (planes != 2 && planes != 3))
+    return fail(-2, "launch_gemm_rs: needs a pointwise layer with 16-channel granularity and 64- or 128-row weight tiles");
+  note_kernel(gemm_rs_kernel_name(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, planes));
+  if (gemm_rs_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2))
+    return planes == 3 ? launch_rs_t<256, 256, 4, 2, 3>(p, ws, ws_floats, stream) : launch_rs_t<256, 256, 4, 2, 2>(p, ws, ws_floats, stream);
+  if (bn_tile == 128)
+    return planes == 3 ? launch_rs_t<128, 128, 2, 2, 3>(p, ws, ws_floats, stream) : launch_rs_t<128, 128, 2, 2, 2>(p, ws, ws_floats, stream);
+  return planes == 3 ? launch_rs_t<128, 64, 2, 2, 3>(p, ws, ws_floats, stream) : launch_rs_t<128, 64, 2, 2, 2>(p, ws, ws_floats, stream);
+}
+
+}  // namespace peanut

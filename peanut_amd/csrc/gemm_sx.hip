@@ -450,8 +450,14 @@ int launch_gemm_sx(const ConvKParams& p, int bn_tile, int planes, float* ws, siz
     return fail(-2, "launch_gemm_sx: needs an S-format A operand of a pointwise layer");
   // 256 x 256 tiles when the shape allows: whole 256-wide n-tiles, whole 256-row tiles per Winograd position, enough
   // rows to fill the chip at one workgroup per CU (PEANUT_SX256=0 keeps the 128 x 128 kernel everywhere)
-  if (gemm_sx_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1))
+  if (gemm_sx_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1)) {
+    note_kernel(planes == 3 ? "gemm_sx6_256x256" : "gemm_sx3_256x256");
     return planes == 3 ? launch_sx256_t<3>(p, ws, ws_floats, stream) : launch_sx256_t<2>(p, ws, ws_floats, stream);
+  }
+  static const char* const names[2][3] = {{"gemm_sx3_128x128", "gemm_sx3_128x64", "gemm_sx3_128x32"},
+                                          {"gemm_sx6_128x128", "gemm_sx6_128x64", "gemm_sx6_128x32"}};
+  if ((planes == 2 || planes == 3) && (bn_tile == 128 || bn_tile == 64 || bn_tile == 32))
+    note_kernel(names[planes - 2][bn_tile == 128 ? 0 : (bn_tile == 64 ? 1 : 2)]);
   if (planes == 3) {
     if (bn_tile == 128) return launch_sx_t<128, 2, 2, 3>(p, ws, ws_floats, stream);
     if (bn_tile == 64) return launch_sx_t<64, 2, 2, 3>(p, ws, ws_floats, stream);

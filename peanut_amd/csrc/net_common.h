@@ -100,6 +100,15 @@ struct ConvLayer {
 
 // bf16 pieces per value of the S-format operands in a precision mode (0: the mode has none)
 inline int s_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : 0); }
+// bf16 pieces per value in the register-split modes (gemm_rs.hip; 0: not such a mode)
+inline int rs_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6_RS ? 3 : (precision == PEANUT_PREC_BF16X3_RS ? 2 : 0); }
+// n-tile of a pointwise layer's S-packed weights in the register-split modes (0: the layer stays on the fp32 kernel)
+inline int rs_bn_tile(int cin_pad, int cout, int kh, int kw, int pad) {
+  if (kh != 1 || kw != 1 || pad != 0 || cin_pad % 16 != 0 || cout < 64) return 0;
+  // 128 x 64 tiles (three workgroups per CU) for the short-K layers whose time is their epilogue's HBM traffic
+  static const int bn64_maxk = [] { const char* e = getenv("PEANUT_RS_BN64_MAXK"); return e ? atoi(e) : 128; }();
+  return (cout >= 128 && cin_pad > bn64_maxk) ? 128 : 64;
+}
 
 inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
                 int cin_pad, int kh, int kw, int stride, int pad, int dil, int relu, int precision) {
@@ -109,6 +118,7 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
   // the S-format GEMMs (emulated-fp32 modes) run 256 x 256 tiles built from 128-row packed weight tiles
   if (s_planes_of(precision) && kh == 1 && kw == 1 && pad == 0 && cout >= 128) d.bn_tile = 128;
+  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) d.bn_tile = rs_bn_tile(cin_pad, cout, kh, kw, pad);
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
   const bool split_mode = precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3;
   if (split_mode && cin_pad % 32 == 0) d.bk = 32;            // split kernels are BK = 32 only
@@ -134,7 +144,12 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.shift = (const float*)L.ss.p + d.cout_pad;
   d.s_planes = s_planes_of(precision);
   d.w_s = nullptr;
-  if (d.s_planes && kh == 1 && kw == 1 && pad == 0 && cin_pad % 16 == 0) {   // pointwise: may run on gemm_sx.hip
+  d.rs = 0;
+  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) {   // pointwise, register-split mode: gemm_rs.hip
+    d.rs = 1;
+    d.s_planes = rs_planes_of(precision);
+  }
+  if (d.s_planes && kh == 1 && kw == 1 && pad == 0 && cin_pad % 16 == 0) {   // pointwise: may run on gemm_sx.hip / gemm_rs.hip
     std::vector<unsigned char> ps(sx_packed_bytes(cin_pad, cout, d.bn_tile, d.s_planes));
     pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, ps.data());
     if ((rc = L.w_s.ensure(ps.size()))) return rc;
@@ -149,7 +164,7 @@ inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int
   // measured (profiles/r2s): from 128 input channels on in fp32 (+1.2 % on the headline, +1.8 % on the detector;
   // 64 adds 0.1 %), from 256 on in the split / emulated modes (their transforms move 6-byte S values: 128 loses 1 %)
   static const int env_min = [] { const char* e = getenv("PEANUT_WINO_MIN_CIN"); return e ? atoi(e) : 0; }();
-  const int min_cin = env_min ? env_min : (precision == PEANUT_PREC_FP32 ? 128 : 256);
+  const int min_cin = env_min ? env_min : ((precision == PEANUT_PREC_FP32 || rs_planes_of(precision)) ? 128 : 256);
   return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 &&
          cout >= 64 && precision != PEANUT_PREC_FP16X3;   // fp16x3: the 1/24-scaled weight tails would underflow
 }
@@ -159,10 +174,12 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   g.cin = cin_pad; g.cout = cout; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
   conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
   if (s_planes_of(precision) && cout >= 128) g.bn_tile = 128;   // see upload_conv
+  g.rs = 0;
+  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, 1, 1, 0)) { g.rs = 1; g.bn_tile = rs_bn_tile(cin_pad, cout, 1, 1, 0); }
   g.bk = 32;
   g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
   g.mode = (precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3) ? precision : 0;
-  g.s_planes = s_planes_of(precision);
+  g.s_planes = g.rs ? rs_planes_of(precision) : s_planes_of(precision);
   g.w_s = nullptr;
   const size_t gf = conv_packed_floats(cin_pad, cout, 1, 1, g.bn_tile);
   std::vector<float> U((size_t)36 * cout * cin);
@@ -198,11 +215,24 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   return 0;
 }
 
+// Row padding per Winograd position: whole 256-row tiles where the position GEMMs run on a 256-row kernel (the S-format
+// one of gemm_sx.hip; the three-stage fp32 one of conv_pw.hip for K >= 1024; the register-split one of gemm_rs.hip),
+// else 128
+inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
+  int th, tw;
+  long long n_tiles, m_pad;
+  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, 256);
+  const ConvDesc& g = L.wino;
+  if (g.rs) return gemm_rs_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;
+  if (g.w_s) return 256;
+  return (g.mode == 0 && conv_pw_enabled() && conv_pw_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
+}
+
 // floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]
 inline void wino_scratch_floats(const ConvLayer& L, int B, int H, int W, size_t* v, size_t* m) {
   int th, tw;
   long long n_tiles, m_pad;
-  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad);
+  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, wino_gran_for(L, B, H, W));
   *v = (size_t)36 * m_pad * L.d.cin;
   *m = (size_t)36 * m_pad * L.d.cout;
 }
@@ -213,16 +243,17 @@ inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_
   if (!(L.has_wino && !a.x2 && wino_v && wino_m)) return launch_conv(L.d, a, s);
   int th, tw, rc;
   long long n_tiles, m_pad;
-  wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad);
+  const int gran = wino_gran_for(L, a.B, a.H, a.W);
+  wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad, gran);
   if (36 * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
-  if ((rc = launch_wino_input(a.x, wino_v, nullptr, 0, a.B, a.H, a.W, L.d.cin, L.d.dil, s))) return rc;
+  if ((rc = launch_wino_input(a.x, wino_v, nullptr, 0, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran))) return rc;
   ConvArgs g{};
   g.x = wino_v; g.y = wino_m;
   g.B = 1; g.H = 1; g.W = (int)(36 * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
   g.ws = a.ws; g.ws_floats = a.ws_floats;
-  g.mt_per_group = (int)(m_pad / 128); g.w_group_stride = L.wino_group_floats;
+  g.mt_per_group = (int)(m_pad / 128); g.w_group_stride = L.wino.rs ? L.wino_group_bytes : L.wino_group_floats;
   if ((rc = launch_conv(L.wino, g, s))) return rc;
-  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, nullptr, 0, 0, 0, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s);
+  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, nullptr, 0, 0, 0, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s, gran);
 }
 
 // ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----

@@ -25,6 +25,9 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+static thread_local const char* g_kernel = "";
+void note_kernel(const char* family) { g_kernel = family; }
+const char* noted_kernel() { return g_kernel; }
 
 namespace {
 
@@ -182,7 +185,8 @@ int add_fused_c3d(peanut_pred* h, const TensorMap& tm, const std::string& blk, i
   }
   auto L = std::make_unique<ConvLayer>();
   L->name = blk + ".conv3+downsample";
-  if ((rc = upload_conv(*L, w.data(), nullptr, shift.data(), cout, cin, cin, 1, 1, 1, 0, 1, 1, PEANUT_PREC_FP32))) return rc;
+  if ((rc = upload_conv(*L, w.data(), nullptr, shift.data(), cout, cin, cin, 1, 1, 1, 0, 1, 1,
+                        rs_planes_of(h->cfg.precision) ? h->cfg.precision : PEANUT_PREC_FP32))) return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
@@ -217,11 +221,13 @@ std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, c
   G->d.scale = (const float*)G->ss.p;
   G->d.shift = (const float*)G->ss.p + n * d0.cout_pad;
   G->d.w_s = nullptr;
+  G->d.rs = 0;      // the grouped form runs the fp32 kernel on the parts' fp32-packed weights
   return G;
 }
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
 std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_input = false, long long M = 0, int mt_per_group = 0) {
+  if (d.rs) return gemm_rs_kernel_name(d.cout, M, mt_per_group, d.bn_tile, d.cin, d.s_planes);
   if (s_input) {
     if (gemm_sx_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return d.s_planes == 3 ? "gemm_sx6_256x256" : "gemm_sx3_256x256";
     return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
@@ -253,15 +259,9 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
     int th, tw;
     long long n_tiles, m_pad;
-    const bool s_gemm = L->wino.w_s != nullptr;
-    // row padding per Winograd position: whole 256-row tiles where the position GEMMs run on a 256-row kernel (the
-    // S-format one of gemm_sx.hip; the three-stage fp32 one of conv_pw.hip for K >= 1024), else 128
-    bool pw256 = false;
-    if (!s_gemm && L->wino.mode == 0 && conv_pw_enabled()) {     // would the 256-row kernel take it with 256-row padding?
-      wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, 256);
-      pw256 = conv_pw_uses_256(L->wino.cout, 36 * m_pad, (int)(m_pad / 128), L->wino.bn_tile, in.C);
-    }
-    const int gran = (s_gemm || pw256) ? 256 : 128;
+    const bool s_gemm = L->wino.w_s != nullptr && !L->wino.rs;
+    const bool rs_gemm = L->wino.rs != 0;
+    const int gran = wino_gran_for(*L, in.B, in.H, in.W);
     wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran);
     Act v;   // fp32 V (unused in the S form)
     SAct vs;
@@ -273,10 +273,11 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0);
     pl.ops.push_back(a);
     Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, s_gemm, 36 * m_pad, (int)(m_pad / 128)); g.conv = L;
+    (void)rs_gemm;
     g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.in_s = vs; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
     g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
     g.bytes = 36.0 * (double)m_pad * (in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0) + L->d.cout * 4.0) +
-              36.0 * (s_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
+              36.0 * ((s_gemm || rs_gemm) ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
     pl.ops.push_back(g);
     Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
@@ -301,7 +302,7 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
   op.flops = conv_flops(L, out);
   op.bytes = (s_in ? (double)in_s->bytes : (double)in.bytes) + (in2 ? (double)in2->bytes : 0.0) +
              (skip_f32 ? 0.0 : (double)out.bytes) + (res ? (double)out.bytes : 0.0) + (out_s ? (double)out_s->bytes : 0.0) +
-             (s_in ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
+             ((s_in || L->d.rs) ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
                    : (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4);
   pl.ops.push_back(op);
 }
@@ -585,6 +586,8 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       if (op.in_s.valid) {
         a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad;
         a.w_group_stride = op.conv->wino_group_bytes;
+      } else if (op.conv->wino.rs) {
+        a.w_group_stride = op.conv->wino_group_bytes;
       } else {
         a.w_group_stride = op.conv->wino_group_floats;
       }
@@ -616,7 +619,8 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
 extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
-int peanut_abi_version(void) { return 7; }
+const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
+int peanut_abi_version(void) { return 8; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
@@ -625,7 +629,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
   if (cfg->in_channels < 1 || cfg->num_classes < 1 || cfg->num_classes > 32)
     return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
   if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
-  if (cfg->precision < 0 || cfg->precision > 3) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6}");
+  if (cfg->precision < 0 || cfg->precision > 5) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6,BF16X6_RS,BF16X3_RS}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT)
     return fail(PEANUT_EINVAL, "conv_algo must be PEANUT_ALGO_{AUTO,DIRECT}");
   auto h = std::make_unique<peanut_pred>();
@@ -658,7 +662,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
       if (bi == 0 && (stride != 1 || inplanes != planes * 4)) {
         if ((rc = add_conv(h.get(), tm, p + ".downsample.0", p + ".downsample.1", inplanes, inplanes, planes * 4, 1, stride, 0, 1, 0, &b.down))) return rc;
         static const bool fuse = [] { const char* e = getenv("PEANUT_FUSE_C3D"); return !(e && e[0] == '0'); }();
-        if (fuse && s == 1 && cfg->precision == PEANUT_PREC_FP32 && planes % 32 == 0 && inplanes % 32 == 0 && conv_pw_enabled() &&
+        if (fuse && s == 1 && (cfg->precision == PEANUT_PREC_FP32 || rs_planes_of(cfg->precision)) && planes % 32 == 0 && inplanes % 32 == 0 && conv_pw_enabled() &&
             (rc = add_fused_c3d(h.get(), tm, p, planes, inplanes, planes * 4, &b.c3d)))
           return rc;
       }
@@ -871,8 +875,8 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
   if (!out || !w) return fail(PEANUT_EINVAL, "peanut_conv_create: null argument");
   if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
-  if (precision < 0 || precision > 2) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
-  if (precision != PEANUT_PREC_FP32 && cin_pad % 32 != 0)
+  if (precision < 0 || precision > 5 || precision == PEANUT_PREC_BF16X6) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
+  if ((precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3) && cin_pad % 32 != 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: the split-precision modes need cin_pad % 32 == 0 (this layer would "
                                "have to run in fp32); create it with PEANUT_PREC_FP32 explicitly");
   auto c = std::make_unique<peanut_conv>();
@@ -890,7 +894,12 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
 
 void peanut_conv_destroy(peanut_conv_t* c) { delete c; }
 
-int peanut_conv_precision(peanut_conv_t* c) { return c ? c->L.d.mode : PEANUT_EINVAL; }
+int peanut_conv_precision(peanut_conv_t* c) {
+  if (!c) return PEANUT_EINVAL;
+  const ConvDesc& d = (c->L.has_wino && c->L.wino.rs) ? c->L.wino : c->L.d;
+  if (d.rs) return d.s_planes == 3 ? PEANUT_PREC_BF16X6_RS : PEANUT_PREC_BF16X3_RS;
+  return c->L.d.mode;
+}
 
 int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c1, const float* res, float* y, int B,
                         int H, int W, void* stream) {

@@ -274,7 +274,8 @@ int add_fused_c3s(peanut_rcnn* h, const TensorMap& tm, const std::string& blk, i
   }
   auto L = std::make_unique<ConvLayer>();
   L->name = blk + ".conv3+shortcut";
-  if ((rc = upload_conv(*L, w.data(), nullptr, shift.data(), cout, k, k, 1, 1, 1, 0, 1, 1, PEANUT_PREC_FP32))) return rc;
+  if ((rc = upload_conv(*L, w.data(), nullptr, shift.data(), cout, k, k, 1, 1, 1, 0, 1, 1,
+                        rs_planes_of(h->cfg.precision) ? h->cfg.precision : PEANUT_PREC_FP32))) return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
@@ -443,7 +444,7 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
   if (cfg->depth != 50 && cfg->depth != 101 && cfg->depth != 152) return fail(PEANUT_EINVAL, "rcnn: depth must be 50/101/152");
   if (cfg->fpn_out % 32 || cfg->num_anchors < 1 || cfg->min_size < 32 || cfg->size_divisibility != 32)
     return fail(PEANUT_EINVAL, "rcnn: unsupported configuration");
-  if (cfg->precision < 0 || cfg->precision > 2) return fail(PEANUT_EINVAL, "rcnn: bad precision");
+  if (cfg->precision < 0 || cfg->precision > 5 || cfg->precision == PEANUT_PREC_BF16X6) return fail(PEANUT_EINVAL, "rcnn: bad precision");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "rcnn: bad conv_algo");
   auto h = std::make_unique<peanut_rcnn>();
   h->cfg = *cfg;
@@ -469,7 +470,7 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
       if ((rc = add_rconv(h.get(), tm, p + ".conv2", bott, bott, bott, 3, s3, 1, true, 1, &b.c2))) return rc;
       if ((rc = add_rconv(h.get(), tm, p + ".conv3", bott, bott, cout, 1, 1, 0, true, 1, &b.c3))) return rc;   // ReLU after the add
       static const bool fuse = [] { const char* e = getenv("PEANUT_FUSE_C3D"); return !(e && e[0] == '0'); }();
-      if (fuse && b.shortcut && s == 1 && cfg->precision == PEANUT_PREC_FP32 && bott % 32 == 0 && cin % 32 == 0 && conv_pw_enabled() &&
+      if (fuse && b.shortcut && s == 1 && (cfg->precision == PEANUT_PREC_FP32 || rs_planes_of(cfg->precision)) && bott % 32 == 0 && cin % 32 == 0 && conv_pw_enabled() &&
           (rc = add_fused_c3s(h.get(), tm, p, bott, cin, cout, &b.c3s)))
         return rc;
       blocks.push_back(b);

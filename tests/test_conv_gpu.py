@@ -72,7 +72,7 @@ def test_conv_two_source_concat():
     # (B, H, W, c1, c2, cout): 1x1 over [x | x2] -- the fused conv3 + downsample layers (pred_api.hip: add_fused_c3d)
     (2, 30, 30, 64, 64, 256),        # layer1.0 shape class: 128 x 64 tiles, K = 128
     (1, 23, 17, 256, 512, 1024),     # ragged M, 128 x 128 tiles; few tiles, so split-K parts start on either side of the switch
-    (4, 64, 64, 512, 1024, 256),     # M * cout large, K = 1536: the 256 x 128 three-stage kernel
+    (8, 64, 64, 512, 1024, 256),     # M * cout = 8.39 M, K = 1536: the 256 x 128 three-stage kernel (asserted below)
     (1, 9, 9, 32, 2048, 128),        # the switch after the first k-tile, long second source
 ], ids=lambda c: "x".join(map(str, c)))
 def test_pointwise_two_source_matches_torch(case):
@@ -90,6 +90,138 @@ def test_pointwise_two_source_matches_torch(case):
     y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
     err = (y - ref).abs()
     assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+    want = {(2, 30, 30, 64, 64, 256): "conv_pw_glds_128x64", (8, 64, 64, 512, 1024, 256): "conv_pw_glds_256x128"}.get(case)
+    if want:
+        assert _last_kernel() == want
+
+
+def _last_kernel():
+    """Kernel family the last conv / GEMM launch of this thread selected (peanut_last_conv_kernel)."""
+    from peanut_amd import _lib
+    return _lib.load().peanut_last_conv_kernel().decode()
+
+
+# Shapes that cross the gates of the LARGE-tile kernels (csrc/conv_pw.hip: conv_pw_uses_256 needs cin >= 1024 and
+# M * cout >= 256 * 256 * 128 = 8.39 M; csrc/gemm_rs.hip: gemm_rs_uses_256 needs cin >= 512, cout % 256 == 0 and
+# M * cout >= 16.8 M) -- the kernels that carry the headline benchmark.  Every case asserts the kernel family it hit.
+BIG_PW_CASES = [
+    # (B, H, W, cin, cout, stride, relu, residual)
+    (8, 64, 64, 1024, 256, 1, True, False),      # exactly at the fp32 gate (M * cout = 8.39 M), whole tiles
+    (5, 57, 61, 1024, 512, 1, True, True),       # residual; M = 17 385 leaves a ragged last 256-row tile
+    (8, 64, 64, 1024, 384, 1, False, True),      # 384 tiles over 256 CUs: the 128-tile tail runs split-K + the ordered reduce
+    (4, 150, 150, 1024, 512, 2, True, False),    # strided 1x1 (the downsample form), M = 22 500
+]
+
+
+def _pw_case(case, precision, want_kernel, tol):
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout, stride, relu, residual = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.conv2d(x, w, None, stride=stride) * scale[None, :, None, None] + shift[None, :, None, None]
+    res = None
+    if residual:
+        res = _rand(tuple(ref.shape), g)
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    conv = FusedConv(w, scale, shift, stride=stride, relu=relu, precision=precision)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+    y = conv(xd, residual=rd)
+    assert _last_kernel() == want_kernel, _last_kernel()
+    assert torch.equal(y, conv(xd, residual=rd))                 # deterministic (ordered split-K reduce, no atomics)
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= tol * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("case", BIG_PW_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_pw256_kernel_matches_torch(case):
+    """conv_pw_glds256_kernel (256 x 128 tiles, three LDS stages: 41 % of the headline step) against F.conv2d."""
+    _pw_case(case, "fp32", "conv_pw_glds_256x128", 2e-5)
+
+
+def test_pw256_kernel_grouped_winograd_gemm():
+    """The 36 grouped position GEMMs of a Winograd conv on the 256 x 128 kernel (mt_per_group in 256-row tiles, rows
+    padded to whole 256-row tiles per position: the bottleneck's form) against F.conv2d."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout = 2, 88, 88, 1024, 256          # 968 tiles -> m_pad 1024: 36 * 1024 * 256 = 9.4 M
+    g = torch.Generator().manual_seed(5)
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    res = _rand((B, cout, H, W), g)
+    ref = F.relu(F.conv2d(x, w, None, padding=1) + shift[None, :, None, None] + res)
+    conv = FusedConv(w, None, shift, padding=1, relu=True)
+    y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda())
+    assert _last_kernel() == "conv_pw_glds_256x128", _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+# ---- register-split emulated-fp32 GEMM (csrc/gemm_rs.hip): fp32 activations, bf16 pieces peeled off in registers ----
+RS_TOL = {"bf16x6rs": 2e-5, "bf16x3rs": 1e-4}     # bf16x6: fp32-class, held to the fp32 kernels' own tolerance
+
+RS_CASES = [
+    # (B, H, W, cin, cout, stride, relu, residual), kernel family without the piece count
+    ((2, 15, 15, 64, 256, 1, False, True), "128x64"),        # layer1 conv3 + identity: K = 64 (4 k-tiles), 64-row weight tiles
+    ((1, 31, 29, 256, 128, 1, True, False), "128x128"),      # ragged M (899 rows)
+    ((2, 17, 17, 256, 512, 2, False, False), "128x128"),     # strided 1x1 downsample
+    ((1, 1, 36, 2048, 512, 1, True, False), "128x128"),      # PPM 1x1 on pooled bins: tiny M, tail split-K over 128 k-tiles
+    ((3, 13, 13, 512, 320, 1, False, False), "128x128"),     # cout not a tile multiple
+    ((1, 12, 12, 48, 64, 1, True, False), "128x64"),         # K = 48: three k-tiles, exactly the pipeline depth
+    ((1, 9, 9, 16, 128, 1, False, False), "128x64"),         # a single k-tile
+    ((8, 64, 64, 512, 512, 1, True, True), "256x256"),       # at the 256-tile gate (M * cout = 16.8 M), residual
+    ((5, 57, 61, 1024, 1024, 1, True, True), "256x256"),     # ragged last 256-row tile
+    ((8, 64, 64, 512, 768, 1, False, False), "256x256"),     # 384 tiles over 256 CUs: split-K tail
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x6rs", "bf16x3rs"])
+@pytest.mark.parametrize("case,family", RS_CASES, ids=lambda c: "x".join(map(str, c[:6])) if isinstance(c, tuple) else c)
+def test_register_split_gemm_matches_torch(case, family, precision):
+    _pw_case(case, precision, ("gemm_rs6_" if precision == "bf16x6rs" else "gemm_rs3_") + family, RS_TOL[precision])
+
+
+@pytest.mark.parametrize("case", [(2, 30, 30, 64, 64, 256), (1, 23, 17, 256, 512, 1024), (8, 64, 64, 512, 1024, 512),
+                                  (1, 9, 9, 32, 2048, 128), (1, 9, 9, 16, 16, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_register_split_gemm_two_sources(case):
+    """gemm_rs reading its A k-tiles from two fp32 tensors (fused conv3 + downsample layers), incl. a split-K launch whose
+    parts start on either side of the source switch and the switch after the very first k-tile."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, c1, c2, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) + shift[None, :, None, None])
+    conv = FusedConv(w, None, shift, relu=True, precision="bf16x6rs")
+    y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+    assert _last_kernel().startswith("gemm_rs6_"), _last_kernel()
+    err = (y - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("case", [(2, 88, 88, 512, 512, 1), (1, 15, 15, 512, 512, 4), (1, 15, 13, 256, 320, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_register_split_winograd(case):
+    """Winograd form with the position GEMMs on gemm_rs (fp32 transforms, bf16x6 products): the first case pads to whole
+    256-row tiles per position and runs the 256 x 256 kernel grouped."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    res = _rand((B, cout, H, W), g)
+    ref = F.relu(F.conv2d(x, w, None, padding=d, dilation=d) + res)
+    conv = FusedConv(w, None, None, padding=d, dilation=d, relu=True, precision="bf16x6rs")
+    y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda())
+    assert _last_kernel() == ("gemm_rs6_256x256" if case[0] == 2 else "gemm_rs6_128x128"), _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
 
 def test_conv_transpose_detecting():
