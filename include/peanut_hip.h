@@ -60,30 +60,27 @@ typedef struct peanut_pred_cfg {
 /* PEANUT_ALGO_AUTO: Winograd F(4x4,3x3) with fp32 transforms (what cuDNN/MIOpen pick for these layers in the
  * reference's own GPU runs): 4x fewer multiplies; interpolation points 0, +-3/4, +-3/2, inf keep the logits as close to the exact result
  * as the direct form (8e-6 max-abs vs the reference golden vectors, bound 1e-3).
- * PEANUT_ALGO_DIRECT: every conv as the direct implicit GEMM (products summed exactly as an fmaf chain). */
+ * AUTO also runs conv3 and a stride-1 downsample / shortcut conv of a bottleneck block as ONE GEMM over [conv2 output | block
+ * input] with the two BatchNorm scales folded into the weights (same function, another rounding order).
+ * PEANUT_ALGO_DIRECT: every conv as the direct implicit GEMM (products summed exactly as an fmaf chain), every block in
+ * the reference's op-for-op form (conv -> BN, conv -> BN, add, ReLU). */
 #define PEANUT_ALGO_AUTO 0
 #define PEANUT_ALGO_DIRECT 1
 
 /* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32, exact fp32 (bit-identical to an fmaf chain).
- * BF16X3 / FP16X3: every fp32 operand is split into two 16-bit parts and each product is rebuilt from
- * three 16-bit matrix-core products with fp32 accumulation (fp32-class result, ~1e-4 / ~2e-5 max-abs
- * on the logits vs the fp32 reference, bound 1e-3); FP16X3 overflows for |activation| > 65504. */
+ * BF16X6: fp32 emulated on the bf16 matrix cores (csrc/gemm_rs.hip).  Activations stay fp32 in HBM and LDS -- the
+ * forward's tensors, Winograd transforms and fusions are exactly the fp32 mode's; in the 1x1 convs and the Winograd
+ * position GEMMs every fp32 value is split into three bf16 pieces (3 x 8 = 24 mantissa bits: the split is exact; the
+ * activations in registers after the fragment read, the weights once at load time) and every product is rebuilt from
+ * the six piece products that matter (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped ones are <= 2^-24
+ * relative, the size of fp32's own product rounding) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class
+ * results, measured as close to a float64 run of the reference model as the reference's own fp32 CPU path.  The other
+ * layers (3x3 direct convs, the stem) stay on the fp32 MFMA kernels.
+ * BF16X3: the same with two pieces and three products (~2^-16 relative per product: ~7e-5 max-abs on the logits,
+ * bound 1e-3); an opt-in speed mode, not fp32-class. */
 #define PEANUT_PREC_FP32 0
 #define PEANUT_PREC_BF16X3 1
-#define PEANUT_PREC_FP16X3 2
-/* BF16X6: fp32 emulated on the bf16 matrix cores.  Every fp32 value is held as three bf16 pieces (3 x 8 = 24
- * mantissa bits: the split is exact) and every product is rebuilt from the six piece products that matter
- * (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped ones are <= 2^-24 relative, the size of fp32's own
- * product rounding) with fp32 accumulation -- fp32-class results, measured on a par with the fp32 MFMA path.  The
- * 1x1 convs and the Winograd GEMMs use it (csrc/gemm_sx.hip, operands pre-split by their producers); the other
- * layers stay on the fp32 MFMA kernel. */
 #define PEANUT_PREC_BF16X6 3
-/* BF16X6_RS / BF16X3_RS ("register split", csrc/gemm_rs.hip): the same six (three) piece products, but activations
- * stay fp32 in HBM and LDS -- the forward's tensors, transforms and fusions are exactly the fp32 mode's -- and are
- * split into their bf16 pieces in registers after the fragment read; only the weights are pre-split.  Also available
- * at the operator level (peanut_conv_create). */
-#define PEANUT_PREC_BF16X6_RS 4
-#define PEANUT_PREC_BF16X3_RS 5
 
 /* One entry of an mmcv/PyTorch state dict (HOST memory, fp32, contiguous, OIHW for convs). */
 typedef struct peanut_tensor {
@@ -335,10 +332,9 @@ int peanut_seg_accumulate(const uint8_t* masks, const int32_t* classes, const fl
 typedef struct peanut_conv peanut_conv_t;
 /* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
  * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
- * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X3 / FP16X3 / BF16X6_RS / BF16X3_RS (in the RS modes the
- * pointwise layers and the Winograd position GEMMs run on the bf16 matrix cores, every other layer in fp32); the split modes need
- * cin_pad % 32 == 0 and the call FAILS with PEANUT_EINVAL otherwise (no silent change of arithmetic);
- * peanut_conv_precision() returns the PEANUT_PREC_* mode the layer actually runs in.  conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
+ * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X6 / BF16X3: in the emulated modes a pointwise layer with
+ * >= 64 output channels and the position GEMMs of a Winograd layer run on the bf16 matrix cores, every other layer in fp32;
+ * peanut_conv_precision() returns the PEANUT_PREC_* mode the layer actually runs in (no silent change of arithmetic).  conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
  * >= 256 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */
 int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
                        const float* shift_host, int cout, int cin, int cin_pad, int kh, int kw, int stride,

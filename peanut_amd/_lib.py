@@ -131,7 +131,7 @@ SIGNATURES = {
 
 
 CONV_ALGOS = {"auto": 0, "direct": 1}   # PEANUT_ALGO_*
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x3": 2, "bf16x6": 3, "bf16x6rs": 4, "bf16x3rs": 5}   # PEANUT_PREC_* (bf16x6: prediction planner only)
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 3}   # PEANUT_PREC_* (bf16x6: prediction planner only)
 
 
 def lib_path() -> str:

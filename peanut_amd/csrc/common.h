@@ -32,13 +32,14 @@ struct ConvDesc {
   int bn_tile;    // BN used for packing (32/64/128)
   int bk;         // BK used for packing (16/32)
   int cout_pad;   // cout rounded up to bn_tile
-  int mode;       // 0 = fp32 MFMA (exact), 1 = bf16x3 split products, 2 = fp16x3 split products
-  const float* w_packed;   // device
+  const float* w_packed;   // device: fp32 weights packed for the fp32 MFMA kernels
   const float* scale;      // device [cout_pad]
   const float* shift;      // device [cout_pad]
-  const void* w_s;         // device: S-packed weights of a pointwise layer (gemm_sx.hip), or null
-  int s_planes;            // bf16 pieces per value in w_s and in S activations: 2 (bf16x3) or 3 (bf16x6)
-  int rs;                  // 1: pointwise layer on gemm_rs.hip -- fp32 activations split in registers, weights from w_s
+  // emulated-fp32 modes (bf16x6 / bf16x3), pointwise layers only: the layer runs on gemm_rs.hip -- fp32 activations split
+  // into bf16 pieces in registers, the weights' pieces pre-split in w_s
+  int rs;                  // 1: run on gemm_rs.hip
+  const void* w_s;         // device: pre-split weights [n-tile][k-tile of 16][plane][bn_tile][16 bf16] (pack_weights_sx), or null
+  int s_planes;            // bf16 pieces per value: 2 (bf16x3: three products) or 3 (bf16x6: six products)
 };
 
 struct ConvArgs {
@@ -52,14 +53,8 @@ struct ConvArgs {
   float* ws;          // optional scratch for tail split-K partial tiles (see conv_common.h)
   size_t ws_floats;
   int mt_per_group;        // grouped GEMM: 128-row m-tile mt reads weight block mt / mt_per_group (0 = single block)
-  size_t w_group_stride;   // floats between weight blocks (bytes for S-packed weights)
+  size_t w_group_stride;   // floats between weight blocks (bytes for the pre-split weights of a register-split layer)
   int ss_group_stride;     // floats between the scale (and shift) blocks of the weight groups (0: one block for all)
-  // S-format operands (see gemm_sx.hip): A read from xs instead of x; optional S copy of the output
-  const unsigned short* xs;
-  int xs_rows;
-  unsigned short* ys;
-  int ys_rows;
-  int skip_f32;
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 partial 128x128 tiles and then some
@@ -72,8 +67,6 @@ void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk);
 size_t conv_packed_floats(int cin_pad, int cout, int kh, int kw, int bn_tile);
 void pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw,
                        int bn_tile, int bk, float* out);
-void pack_conv_weights_split(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile,
-                             int fp16, void* out);
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream);
 // true unless PEANUT_PW_GLDS=0: fp32 1x1 convs / grouped GEMMs run on the LDS-DMA kernel of conv_pw.hip
 bool conv_pw_enabled();
@@ -83,30 +76,23 @@ int conv_pw_256_min_k();
 
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
 // tiles per sub-grid (th x tw), tile count and its padding to whole `gran`-row GEMM tiles (128; 256 when the position
-// GEMMs run on the 256 x 256 S-format kernel)
+// GEMMs run on a 256-row kernel)
 void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad, int gran = 128);
 // host: OIHW 3x3 weights -> U [36][cout][cin]
 void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out);
-// x [B,H,W,C] -> V [36][m_pad][C] fp32, or (Vs != null) the same tensor as `planes` bf16 pieces in the S layout
-int launch_wino_input(const float* x, float* V, unsigned short* Vs, int planes, int B, int H, int W, int C, int dil,
-                      hipStream_t s, int gran = 128);
-// Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res); optional S copy ys (rows padded to
-// ys_rows); skip_f32 = 1 leaves y untouched
+// x [B,H,W,C] -> V [36][m_pad][C] fp32
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran = 128);
+// Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res)
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
-                       unsigned short* ys, int ys_rows, int planes, int skip_f32, int B, int H, int W, int C, int dil, int relu,
-                       hipStream_t s, int gran = 128);
+                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran = 128);
 
-// ---- emulated-fp32 GEMM on pre-split bf16 operands (gemm_sx.hip) ----
+// ---- emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers (gemm_rs.hip) ----
 // whether the 256 x 256 kernel runs a [M x cout] output (mt_per_group: 128-row tiles per Winograd position, 0 = plain)
-bool gemm_sx_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
-size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
-void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
-// ---- emulated-fp32 GEMM with fp32 activations split in registers (gemm_rs.hip) ----
 bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
 const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_tile, int cin, int planes);
-// bytes of an S tensor of `rows` x `channels`
-inline size_t s_tensor_bytes(size_t rows, int channels, int planes) { return (rows + 127) / 128 * 128 * (size_t)channels * 2 * planes; }
-inline int s_rows_pad(size_t rows) { return (int)((rows + 127) / 128 * 128); }
+// the weights' bf16 pieces, packed per (n-tile of bn_tile rows, k-tile of 16 channels, plane)
+size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
+void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
 
 // ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----
 int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s);

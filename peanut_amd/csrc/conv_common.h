@@ -2,6 +2,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace peanut {
@@ -31,40 +33,7 @@ struct ConvKParams {
   int mtiles;                 // m-tiles of the launch (decode_work's n-chunked tile order)
   int nchunk;                 // n-tiles per chunk of that order; 0 = plain order (n fastest over all n-tiles)
   int res_prefetch;           // epilogue: request the first rows of the residual before the accumulators go through LDS
-  // split-plane ("S") operands of the emulated-fp32 GEMM (gemm_sx.hip): every fp32 value as s_planes bf16 pieces
-  // (x = hi + mid (+ lo), each piece the bf16 rounding of what is left), laid out
-  // [16-channel chunk][plane][row][16 bf16] with the row count padded to a multiple of 128
-  const unsigned short* xs;   // A operand in S form (null: fp32 A in x)
-  int xs_rows;                // padded row count of xs
-  unsigned short* ys;         // optional S copy of the output for a following GEMM (needs cout % 16 == 0)
-  int ys_rows;
-  int s_planes;               // 2 (bf16x3) or 3 (bf16x6)
-  int skip_f32;               // 1: do not write y (the consumer reads ys only)
 };
-
-// next bf16 piece of v (round to nearest even) and the remainder; v - piece is exact in fp32 (the piece agrees
-// with v in its leading bits), so the pieces of a value sum to it exactly as long as nothing underflows
-__device__ __forceinline__ unsigned short bf16_piece(float& v) {
-  unsigned bits = __float_as_uint(v);
-  bits += 0x7fffu + ((bits >> 16) & 1u);
-  bits &= 0xffff0000u;
-  v -= __uint_as_float(bits);
-  return (unsigned short)(bits >> 16);
-}
-
-// one fp32 quad (channels n..n+3 of row m) -> its bf16 planes in an S tensor (8-byte stores)
-__device__ __forceinline__ void store_s_quad(unsigned short* ys, int rows_pad, int planes, int m, int n, f32x4 v) {
-  const int g = n >> 4, e = n & 15;
-  unsigned short* dst = ys + ((size_t)(g * planes) * rows_pad + m) * 16 + e;
-  const size_t plane_stride = (size_t)rows_pad * 16;
-  for (int q = 0; q < planes; ++q) {
-    unsigned short h[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { float t = v[i]; h[i] = bf16_piece(t); v[i] = t; }
-    *reinterpret_cast<uint2*>(dst + (size_t)q * plane_stride) =
-        make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-  }
-}
 
 template <int I>
 struct IC { static constexpr int value = I; };
@@ -83,13 +52,11 @@ struct KIter {
 
 
 const float* zero_page();   // per-device 4 KiB of zeros (allocated on first use)
-int launch_conv_split(const ConvKParams& p, int bn_tile, int fp16, float* ws, size_t ws_floats, hipStream_t stream);
 // conv_pw.hip: fp32 pointwise convs / grouped GEMMs with LDS-DMA staging (PEANUT_PW_GLDS=0 disables)
 bool conv_pw_enabled();
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream);
-// gemm_sx.hip: pointwise layer / grouped GEMM on S-format operands (p.xs, p.w = S-packed weights, nkt = cin / 16)
-int launch_gemm_sx(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
-// gemm_rs.hip: pointwise layer / grouped GEMM, fp32 A (p.x, p.x2) split in registers, p.w = S-packed weights, nkt = cin / 16
+// gemm_rs.hip: pointwise layer / grouped GEMM emulated on the bf16 matrix cores: fp32 A (p.x, p.x2) split into bf16 pieces in
+// registers, p.w = the weights' pre-split pieces, nkt = cin / 16
 int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
 
 
@@ -235,8 +202,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
             v += rpre[i];
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             const size_t o = (size_t)m * p.cout + n;
-            if (!p.skip_f32) *reinterpret_cast<f32x4*>(p.y + o) = v;
-            if (p.ys) *reinterpret_cast<f32x4*>(smem + row * CS + c4) = v;
+            *reinterpret_cast<f32x4*>(p.y + o) = v;
           }
         }
         row_first = r0 + PRE * ROWS_PER_PASS;
@@ -252,8 +218,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
           if (n < p.cout) {
             if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (!p.skip_f32) *reinterpret_cast<f32x4*>(p.y + o) = v;
-            if (p.ys) *reinterpret_cast<f32x4*>(smem + row * CS + c4) = v;   // finished values for the S pass below
+            *reinterpret_cast<f32x4*>(p.y + o) = v;
           }
         } else {
 #pragma unroll
@@ -264,34 +229,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
               if (p.relu) x = fmaxf(x, 0.f);
               p.y[o + e] = x;
             }
-          }
-        }
-      }
-      if (p.ys) {
-        // S copy of the slab: thread -> (row, 8-channel half of a 16-channel chunk), half fastest, so that a wave's
-        // 16-byte piece stores cover 32 consecutive rows of one (chunk, plane): 1 KiB runs of the S layout
-        __syncthreads();
-        constexpr int HALVES = BN / 8;
-        for (int it = tid; it < ER * HALVES; it += NT) {
-          const int half = it & 1, row = (it >> 1) % ER, hc = (it >> 1) / ER;
-          const int col = hc * 16 + half * 8;
-          const int m = m0 + ep * ER + row, nn = n0 + col;
-          if (m >= p.M || nn >= p.cout) continue;
-          f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + row * CS + col);
-          f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + row * CS + col + 4);
-          unsigned short* dst = p.ys + ((size_t)((nn >> 4) * p.s_planes) * p.ys_rows + m) * 16 + half * 8;
-          const size_t plane_stride = (size_t)p.ys_rows * 16;
-          for (int q = 0; q < p.s_planes; ++q) {
-            unsigned short h[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float a = v0[i], b = v1[i];
-              h[i] = bf16_piece(a); h[4 + i] = bf16_piece(b);
-              v0[i] = a; v1[i] = b;
-            }
-            *reinterpret_cast<uint4*>(dst + (size_t)q * plane_stride) =
-                make_uint4((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
-                           (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16));
           }
         }
       }
@@ -367,8 +304,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
       if (n < p.cout) {
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (!p.skip_f32) *reinterpret_cast<f32x4*>(p.y + o) = v;
-        if (p.ys) store_s_quad(p.ys, p.ys_rows, p.s_planes, m, n, v);
+        *reinterpret_cast<f32x4*>(p.y + o) = v;
       }
     } else {
       for (int e = 0; e < 4; ++e) {
@@ -383,23 +319,35 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
   }
 }
 
-// shared host launcher: occupancy query (once per instantiation), tail-split plan, launch, reduce
+// resident workgroup slots (CUs x occupancy) of one kernel, per device: 0 = not queried yet, -1 = unknown (never split).
+// One object per kernel instantiation; the benign race of two threads filling an entry stores the same value twice.
+struct SlotCache {
+  static constexpr int kMaxDevices = 16;
+  std::atomic<int> slots[kMaxDevices];
+  std::atomic<int> cus[kMaxDevices];
+  SlotCache() { for (int i = 0; i < kMaxDevices; ++i) { slots[i].store(0); cus[i].store(0); } }
+};
+
+// shared host launcher: occupancy query (once per instantiation and device), tail-split plan, launch, reduce
 template <typename KernelT, int BM, int BN, int NT = 256>
-int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream,
-                           int* cached_slots) {
-  static int cus = 0;
-  if (*cached_slots == 0) {
-    int dev = 0, occ = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream, SlotCache* cache) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SlotCache::kMaxDevices) return fail(-3, "conv launch: no current device");
+  int slots = cache->slots[dev].load(std::memory_order_relaxed), cus = cache->cus[dev].load(std::memory_order_relaxed);
+  if (slots == 0) {
+    int occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, NT, 0) != hipSuccess || occ < 1)
-      *cached_slots = -1;   // unknown -> never split
+      slots = -1;
     else
-      *cached_slots = cus * occ;
+      slots = cus * occ;
+    cache->cus[dev].store(cus, std::memory_order_relaxed);
+    cache->slots[dev].store(slots, std::memory_order_relaxed);
   }
   const int mtiles = (p.M + BM - 1) / BM;
   const int T = mtiles * p.ntiles;
   int sp = 1;
-  const int t = plan_tail_split(T, *cached_slots, cus, p.nkt, (size_t)BM * BN, ws ? ws_floats : 0, &sp);
+  const int t = plan_tail_split(T, slots, cus, p.nkt, (size_t)BM * BN, ws ? ws_floats : 0, &sp);
   p.split_p = sp;
   p.n_sp = t * sp;
   p.n_full = T - t;

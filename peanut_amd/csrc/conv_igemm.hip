@@ -317,7 +317,7 @@ void pack_conv_weights(const float* w, int cout, int cin_real, int cin_pad, int 
 
 template <int BM, int BN, int BK, int WM, int WN>
 static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
-  static int slots = 0;
+  static SlotCache slots;
   return launch_with_tail_split<decltype(&conv_igemm_kernel<BM, BN, BK, WM, WN>), BM, BN>(
       &conv_igemm_kernel<BM, BN, BK, WM, WN>, p, ws, ws_floats, stream, &slots);
 }
@@ -342,24 +342,11 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
-  p.ys = a.ys; p.ys_rows = a.ys_rows; p.s_planes = d.s_planes; p.skip_f32 = a.skip_f32;
-  if (p.ys && (d.cout % 16 || (d.s_planes != 2 && d.s_planes != 3))) return fail(-2, "launch_conv: S output needs cout % 16 == 0 and 2 or 3 planes");
-  if (d.rs) {   // emulated-fp32 GEMM, fp32 activations split in registers
-    if (!d.w_s || a.xs || a.ys) return fail(-2, "launch_conv: register-split layer needs S-packed weights and fp32 tensors");
+  if (d.rs) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
+    if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");
     p.w = static_cast<const float*>(d.w_s);
     p.nkt = d.cin / 16;
     return launch_gemm_rs(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
-  }
-  if (a.xs) {   // emulated-fp32 GEMM on pre-split operands
-    if (!d.w_s) return fail(-2, "launch_conv: layer has no S-packed weights");
-    p.xs = a.xs; p.xs_rows = a.xs_rows; p.w = static_cast<const float*>(d.w_s);
-    p.nkt = d.cin / 16;
-    return launch_gemm_sx(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
-  }
-  if (d.mode != 0) {
-    if (d.bk != 32) return fail(-2, "launch_conv: split precision needs BK = 32");
-    note_kernel(d.mode == 2 ? "conv_igemm_fp16x3" : "conv_igemm_bf16x3");
-    return launch_conv_split(p, d.bn_tile, d.mode == 2, a.ws, a.ws_floats, stream);
   }
   if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c1 % 32 == 0 && p.c2 % 32 == 0 && (p.c2 == 0 || p.stride == 1) && conv_pw_enabled())
     return launch_conv_pw(p, d.bn_tile, a.ws, a.ws_floats, stream);

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
 
 template <int BN, int WM, int WN>
 int launch_pw_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
-  static int slots = 0;
+  static SlotCache slots;
   return launch_with_tail_split<decltype(&conv_pw_glds_kernel<BN, WM, WN>), 128, BN>(&conv_pw_glds_kernel<BN, WM, WN>, p, ws,
                                                                                       ws_floats, stream, &slots);
 }
@@ -341,7 +341,7 @@ bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
   if (conv_pw_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2)) {
-    static int slots256 = 0;
+    static SlotCache slots256;
     ConvKParams q = p;
     if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
     note_kernel("conv_pw_glds_256x128");

@@ -1,10 +1,10 @@
 // fp32 GEMM emulated on the bf16 matrix cores with fp32 activations: the A operand stays fp32 in HBM and in LDS and is
 // split into bf16 pieces IN REGISTERS, after the fragment read ("RS" = register split); only the weights are pre-split.
 //
-// Why (round 3): gemm_sx.hip keeps activations as pre-split bf16 pieces ("S" format, 6 bytes per value, written by the
-// producer next to the fp32 tensor).  Its k-loop is nothing but LDS-DMA + fragment reads + MFMAs, but the forward then
-// moves 81.6 GB per batch-32 step against 58.9 GB in fp32 mode, and its expanding 1x1 convs (fp32 output + S copy +
-// residual: 14-15.5 bytes per output element) are HBM-bound as a pipeline.  Here the data flow is EXACTLY the fp32
+// Why (round 3): round 2 kept activations as pre-split bf16 pieces ("S" format, 6 bytes per value, written by the
+// producer next to the fp32 tensor).  That k-loop was nothing but LDS-DMA + fragment reads + MFMAs, but the forward then
+// moved 81.6 GB per batch-32 step against 58.9 GB in fp32 mode, and its expanding 1x1 convs (fp32 output + S copy +
+// residual: 14-15.5 bytes per output element) were HBM-bound as a pipeline.  Here the data flow is EXACTLY the fp32
 // mode's (same tensors, same Winograd transforms, same fused conv3 + downsample layers, same epilogue); what changes
 // is the inner product: a k-tile of 16 channels of A travels global -> LDS as fp32 by LDS-DMA (64-byte rows, like
 // conv_pw.hip), a lane reads its 8 consecutive k of a row (two ds_read_b128) and peels off the bf16 pieces
@@ -15,18 +15,26 @@
 // <= 5 issue slots a bf16 MFMA hides (MI355X_MICROARCH.md, cycle constants).  The split is repeated by the WN waves that
 // share an A row block -- which is why the wave tile is wide in N, not in M.
 //
-// Product terms as in gemm_sx.hip: NP = 3 -> hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (bf16x6, dropped terms
+// Product terms: NP = 3 -> hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (bf16x6, dropped terms
 // <= 2^-24 |ab|: fp32-class), NP = 2 -> hi*hi + hi*lo + lo*hi (bf16x3), smallest terms first, fp32 accumulation.
 //
 // LDS image of a stage: A [BM rows][16 floats], 16-byte chunk c of row r stored at chunk position c ^ ((r >> 2) & 3)
 // (applied to the DMA source address and to the ds_read_b128 address alike): the 16 lanes of a ds_read_b128 lane group
-// then hit 16 distinct 16-byte bank groups.  B: the S-packed weights of gemm_sx.hip, [plane][BN rows][16 bf16] per
-// k-tile (a 256-wide n-tile is two adjacent packed 128-row tiles), the two halves of a row swapped for rows with bit 3
-// set.  Three stages; a k-tile is requested two iterations before it is read (counted s_waitcnt vmcnt(N) + raw
+// then hit 16 distinct 16-byte bank groups (measured: SQ_LDS_BANK_CONFLICT = 0).  B: the weights' pieces, packed once at
+// load time as [n-tile][k-tile][plane][rows][16 bf16] (pack_weights_sx; a 256-wide n-tile is two adjacent packed 128-row
+// tiles), the two 16-byte halves of a row swapped for rows with bit 3 set.  Three stages; a k-tile is requested two iterations before it is read (counted s_waitcnt vmcnt(N) + raw
 // s_barrier: a __syncthreads would drain the DMA queue).
 //
-// Replaces the same reference call sites as conv_pw.hip / gemm_sx.hip: resnet.py:267-307 (conv1 / conv3 / downsample),
-// the position GEMMs of the Winograd form of conv2 and of psp_head.py:86-93.
+// Measured (MI355X, profiles/r3a-r3d): headline forward 946 (round 2: activations pre-split by their producers, "S"
+// format) -> 1075-1090 maps/s; the 256 x 256 kernel sustains 195-230 TF/s fp32-equivalent on the K >= 1024 layers with
+// the matrix pipes busy 58 % of the cycles at an effective 2.0 GHz.  On all-zero operands the same launch runs 27 %
+// faster (242-251 TF/s): it is bound by the power / clock governor, not by its schedule -- a rotated schedule for the
+// two waves of a SIMD, a four-stage software-pipelined loop (split of k-tile kt + 1 under the MFMAs of kt: 3.6 % fewer
+// cycles at a 1.3 % lower clock) and spreading the LDS-DMA requests between the MFMAs all measured within 1 %, and were
+// not kept.  Removing the split arithmetic altogether (wrong results) gains 11 %, removing the LDS-DMA 13 %.
+//
+// Replaces the same reference call sites as conv_pw.hip: resnet.py:267-307 (conv1 / conv3 / downsample), the position
+// GEMMs of the Winograd form of conv2 and of psp_head.py:86-93.
 #include <stdlib.h>
 
 #include "common.h"
@@ -69,7 +77,7 @@ __device__ __forceinline__ void split_frag(const f32x4& v0, const f32x4& v1, bf1
   for (int q = 0; q < NP; ++q) pc[q] = __builtin_bit_cast(bf16x8, w[q]);
 }
 
-template <int BM, int BN, int WM, int WN, int NP, bool STAG>
+template <int BM, int BN, int WM, int WN, int NP>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams p) {
   constexpr int NT = 64 * WM * WN, NW = WM * WN, STAGES = 3;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -86,7 +94,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   constexpr int SMEM_BYTES = (STAGES * STAGE > ER * CS * 4) ? STAGES * STAGE : ER * CS * 4;
   static_assert(TM % 32 == 0 && TN % 32 == 0 && (NP == 2 || NP == 3) && PER_WAVE <= 6, "tile configuration");
   static_assert(BN <= 128 || BN == 256, "a 256-wide n-tile is two packed 128-row weight tiles");
-  static_assert(!STAG || (NW == 8 && MI == 2), "the rotated schedule is for two waves per SIMD and two row blocks per wave");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x;
@@ -229,49 +236,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   rp.on = false;
   int o_cur = 0, o_fill = 2 * STAGE, o_mid = STAGE;
   bf16x8 ap[MI][NP], bf[NP][NI];
-  // Eight-wave workgroups put two waves on every SIMD (waves w and w + 4: MI355X_MICROARCH.md, LDS section).  One
-  // barrier per k-tile would start both on their split (VALU only) at the same moment, with the SIMD's matrix pipe idle,
-  // and then make them queue for it.  STAG: the second half of the waves runs its loop rotated by half a k-tile --
-  //     first half :  barrier | read + split kt | MFMAs rows 0 (kt) | MFMAs rows 1 (kt)          | barrier
-  //     second half:  barrier | MFMAs rows 1 (kt - 1, operands kept in registers) | read + split kt | MFMAs rows 0 (kt) | barrier
-  // so that on every SIMD one wave's split runs under the other wave's MFMAs.  Same LDS intervals for both halves
-  // (a stage is read between the barrier that publishes it and the next one), same number of barriers and DMA requests.
-  if (STAG && wave >= NW / 2) {
-    {   // k-tile 0: nothing pending from a previous tile
-      const bool more = 2 < nk;
-      if (more) RS_DMA_TILE(smem + o_fill);
-      RS_HEAD(smem + o_cur);
-      RS_MFMA_ROWS(0, MI / 2);
-      RS_NEXT_TILE_BARRIER(more);
-      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
-    }
-    for (int kt = 1; kt < nk; ++kt) {
-      const unsigned char* const cur = smem + o_cur;
-      const bool more = kt + 2 < nk;
-      if (more) RS_DMA_TILE(smem + o_fill);
-      RS_MFMA_ROWS(MI / 2, MI);
-      __builtin_amdgcn_sched_barrier(0);      // the reads below must not be hoisted over the MFMAs: the old operands die first
-      RS_HEAD(cur);
-      RS_MFMA_ROWS(0, MI / 2);
-      RS_NEXT_TILE_BARRIER(more);
-      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
-    }
-    RS_MFMA_ROWS(MI / 2, MI);
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned char* const cur = smem + o_cur;
-      const bool more = kt + 2 < nk;
-      if (more) RS_DMA_TILE(smem + o_fill);
-      // residual rows requested under the last k-tile's MFMAs -- not in the 244-register eight-wave kernels, where the 32
-      // registers of the prefetch spill; their epilogue requests them before the accumulators go through LDS
-      if (NW < 8 && kt == nk - 1) rp = conv_res_prefetch<BM, BN, EP, NT>(p, wk, m0, n0);
-      RS_HEAD(cur);
-      RS_MFMA_ROWS(0, MI);
-      RS_NEXT_TILE_BARRIER(more);
-      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
-    }
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* const cur = smem + o_cur;
+    const bool more = kt + 2 < nk;
+    if (more) RS_DMA_TILE(smem + o_fill);
+    // residual rows requested under the last k-tile's MFMAs -- not in the 232-register eight-wave kernel, where the 32
+    // registers of the prefetch spill; its epilogue requests them before the accumulators go through LDS
+    if (NW < 8 && kt == nk - 1) rp = conv_res_prefetch<BM, BN, EP, NT>(p, wk, m0, n0);
+    RS_HEAD(cur);
+    RS_MFMA_ROWS(0, MI);
+    RS_NEXT_TILE_BARRIER(more);
+    { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
   }
-  if (STAG) { RS_BARRIER(); }     // the rotated half finishes after the loop's last barrier; the epilogue reuses the stages
 #undef RS_HEAD
 #undef RS_MFMA_ROWS
 #undef RS_NEXT_TILE_BARRIER
@@ -285,22 +261,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
 
 template <int BM, int BN, int WM, int WN, int NP>
 int launch_rs_t(ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream) {
-  p.ntiles = (p.cout + BN - 1) / BN;             // n-tiles of THIS kernel (decode_work)
+  static SlotCache slots;
+  p.ntiles = (p.cout + BN - 1) / BN;                // n-tiles of THIS kernel (decode_work)
   if (p.mt_per_group) p.mt_per_group /= BM / 128;   // BM-row tiles per weight group
-  if constexpr (WM * WN == 8) {
-    static const bool stag = [] { const char* e = getenv("PEANUT_RS_STAG"); return !(e && e[0] == '0'); }();
-    if (stag) {
-      static int slots_s = 0;
-      return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP, true>), BM, BN, 64 * WM * WN>(
-          &gemm_rs_kernel<BM, BN, WM, WN, NP, true>, p, ws, ws_floats, stream, &slots_s);
-    }
-  }
-  static int slots = 0;
-  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP, false>), BM, BN, 64 * WM * WN>(
-      &gemm_rs_kernel<BM, BN, WM, WN, NP, false>, p, ws, ws_floats, stream, &slots);
+  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP>), BM, BN, 64 * WM * WN>(
+      &gemm_rs_kernel<BM, BN, WM, WN, NP>, p, ws, ws_floats, stream, &slots);
+}
+
+inline unsigned short bf16_piece_host(float& v) {   // next bf16 piece of v (round to nearest even), v <- remainder (exact)
+  unsigned bits;
+  __builtin_memcpy(&bits, &v, 4);
+  bits += 0x7fffu + ((bits >> 16) & 1u);
+  bits &= 0xffff0000u;
+  float piece;
+  __builtin_memcpy(&piece, &bits, 4);
+  v -= piece;
+  return (unsigned short)(bits >> 16);
 }
 
 }  // namespace
+
+// bytes of the pre-split weights of a 1x1 layer: [n-tile][k-tile of 16][plane][bn_tile][16 bf16]
+size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes) {
+  const size_t ntiles = (cout + bn_tile - 1) / bn_tile;
+  return ntiles * (size_t)(cin_pad / 16) * planes * bn_tile * 32;
+}
+
+// w: [cout][cin_real] fp32 (a 1x1 conv's OIHW weights, or one Winograd position of U)
+void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out) {
+  unsigned short* o = static_cast<unsigned short*>(out);
+  const int ntiles = (cout + bn_tile - 1) / bn_tile, nkt = cin_pad / 16;
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int kt = 0; kt < nkt; ++kt) {
+      unsigned short* tile = o + ((size_t)nt * nkt + kt) * planes * bn_tile * 16;
+      for (int r = 0; r < bn_tile; ++r)
+        for (int e = 0; e < 16; ++e) {
+          const int n = nt * bn_tile + r, c = kt * 16 + e;
+          float v = (n < cout && c < cin_real) ? w[(size_t)n * cin_real + c] : 0.f;
+          for (int q = 0; q < planes; ++q) tile[((size_t)q * bn_tile + r) * 16 + e] = bf16_piece_host(v);
+        }
+    }
+}
 
 // 256 x 256 tiles (one workgroup per CU) where the shape fills the chip with them and K is long enough to amortise
 // a tile's epilogue, which nobody computes under with one workgroup per CU; else 128 x 128 (two per CU) / 128 x 64.

@@ -92,17 +92,15 @@ struct ConvLayer {
   ConvDesc wino{};
   size_t wino_group_floats = 0;
   DevBuf wino_w, wino_ss;
-  // S-packed bf16 pieces of the weights (gemm_sx.hip) for the emulated-fp32 modes: of the layer itself when it is
+  // pre-split bf16 pieces of the weights (gemm_rs.hip) for the emulated-fp32 modes: of the layer itself when it is
   // pointwise (d.w_s), of the 36 Winograd position matrices (wino.w_s, wino_group_bytes apart)
   DevBuf w_s, wino_w_s;
   size_t wino_group_bytes = 0;
 };
 
-// bf16 pieces per value of the S-format operands in a precision mode (0: the mode has none)
-inline int s_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : 0); }
-// bf16 pieces per value in the register-split modes (gemm_rs.hip; 0: not such a mode)
-inline int rs_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6_RS ? 3 : (precision == PEANUT_PREC_BF16X3_RS ? 2 : 0); }
-// n-tile of a pointwise layer's S-packed weights in the register-split modes (0: the layer stays on the fp32 kernel)
+// bf16 pieces per value in the emulated-fp32 modes (gemm_rs.hip; 0: fp32 MFMA mode)
+inline int rs_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : 0); }
+// n-tile of a pointwise layer's pre-split weights in the emulated-fp32 modes (0: the layer stays on the fp32 kernel)
 inline int rs_bn_tile(int cin_pad, int cout, int kh, int kw, int pad) {
   if (kh != 1 || kw != 1 || pad != 0 || cin_pad % 16 != 0 || cout < 64) return 0;
   // 128 x 64 tiles (three workgroups per CU) for the short-K layers whose time is their epilogue's HBM traffic
@@ -116,19 +114,19 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   ConvDesc& d = L.d;
   d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
   conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
-  // the S-format GEMMs (emulated-fp32 modes) run 256 x 256 tiles built from 128-row packed weight tiles
-  if (s_planes_of(precision) && kh == 1 && kw == 1 && pad == 0 && cout >= 128) d.bn_tile = 128;
-  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) d.bn_tile = rs_bn_tile(cin_pad, cout, kh, kw, pad);
+  // emulated-fp32 modes: the pointwise layers run on gemm_rs.hip (every other layer stays on the fp32 MFMA kernels)
+  d.rs = 0;
+  d.s_planes = 0;
+  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) {
+    d.rs = 1;
+    d.s_planes = rs_planes_of(precision);
+    d.bn_tile = rs_bn_tile(cin_pad, cout, kh, kw, pad);
+  }
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
-  const bool split_mode = precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3;
-  if (split_mode && cin_pad % 32 == 0) d.bk = 32;            // split kernels are BK = 32 only
-  d.mode = (split_mode && d.bk == 32) ? precision : 0;       // 16-channel (stem.0) layers stay fp32; so does every
-                                                             // non-pointwise layer of the bf16x6 mode
   L.cin_real = cin;
-  const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);   // same byte count in every mode
+  const size_t nw = conv_packed_floats(cin_pad, cout, kh, kw, d.bn_tile);
   std::vector<float> packed(nw);
-  if (d.mode == 0) pack_conv_weights(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.bk, packed.data());
-  else pack_conv_weights_split(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.mode == 2, packed.data());
+  pack_conv_weights(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.bk, packed.data());
   std::vector<float> ss(2 * (size_t)d.cout_pad, 0.f);
   for (int n = 0; n < cout; ++n) {
     ss[n] = scale ? scale[n] : 1.f;
@@ -142,14 +140,8 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.w_packed = (const float*)L.w.p;
   d.scale = (const float*)L.ss.p;
   d.shift = (const float*)L.ss.p + d.cout_pad;
-  d.s_planes = s_planes_of(precision);
   d.w_s = nullptr;
-  d.rs = 0;
-  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) {   // pointwise, register-split mode: gemm_rs.hip
-    d.rs = 1;
-    d.s_planes = rs_planes_of(precision);
-  }
-  if (d.s_planes && kh == 1 && kw == 1 && pad == 0 && cin_pad % 16 == 0) {   // pointwise: may run on gemm_sx.hip / gemm_rs.hip
+  if (d.rs) {
     std::vector<unsigned char> ps(sx_packed_bytes(cin_pad, cout, d.bn_tile, d.s_planes));
     pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, ps.data());
     if ((rc = L.w_s.ensure(ps.size()))) return rc;
@@ -161,25 +153,27 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
 
 // Adds the Winograd form to an uploaded stride-1 3x3 layer (keeps the direct form for the two-source path).
 inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int pad, int dil, int precision) {
-  // measured (profiles/r2s): from 128 input channels on in fp32 (+1.2 % on the headline, +1.8 % on the detector;
-  // 64 adds 0.1 %), from 256 on in the split / emulated modes (their transforms move 6-byte S values: 128 loses 1 %)
+  // measured (profiles/r2s): from 128 input channels on (+1.2 % on the headline, +1.8 % on the detector; 64 adds 0.1 %);
+  // the transforms are fp32 in every precision mode
   static const int env_min = [] { const char* e = getenv("PEANUT_WINO_MIN_CIN"); return e ? atoi(e) : 0; }();
-  const int min_cin = env_min ? env_min : ((precision == PEANUT_PREC_FP32 || rs_planes_of(precision)) ? 128 : 256);
-  return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 &&
-         cout >= 64 && precision != PEANUT_PREC_FP16X3;   // fp16x3: the 1/24-scaled weight tails would underflow
+  const int min_cin = env_min ? env_min : 128;
+  (void)precision;
+  return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 && cout >= 64;
 }
 
 inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int cin_pad, int precision) {
   ConvDesc& g = L.wino;
   g.cin = cin_pad; g.cout = cout; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
   conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
-  if (s_planes_of(precision) && cout >= 128) g.bn_tile = 128;   // see upload_conv
   g.rs = 0;
-  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, 1, 1, 0)) { g.rs = 1; g.bn_tile = rs_bn_tile(cin_pad, cout, 1, 1, 0); }
+  g.s_planes = 0;
+  if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, 1, 1, 0)) {   // see upload_conv
+    g.rs = 1;
+    g.s_planes = rs_planes_of(precision);
+    g.bn_tile = rs_bn_tile(cin_pad, cout, 1, 1, 0);
+  }
   g.bk = 32;
   g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
-  g.mode = (precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3) ? precision : 0;
-  g.s_planes = g.rs ? rs_planes_of(precision) : s_planes_of(precision);
   g.w_s = nullptr;
   const size_t gf = conv_packed_floats(cin_pad, cout, 1, 1, g.bn_tile);
   std::vector<float> U((size_t)36 * cout * cin);
@@ -187,8 +181,7 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   std::vector<float> packed(36 * gf);
   for (int pos = 0; pos < 36; ++pos) {
     const float* u = U.data() + (size_t)pos * cout * cin;
-    if (g.mode == 0) pack_conv_weights(u, cout, cin, cin_pad, 1, 1, g.bn_tile, g.bk, packed.data() + pos * gf);
-    else pack_conv_weights_split(u, cout, cin, cin_pad, 1, 1, g.bn_tile, g.mode == 2, packed.data() + pos * gf);
+    pack_conv_weights(u, cout, cin, cin_pad, 1, 1, g.bn_tile, g.bk, packed.data() + pos * gf);
   }
   std::vector<float> ss(2 * (size_t)g.cout_pad, 0.f);
   for (int n = 0; n < g.cout_pad; ++n) ss[n] = 1.f;
@@ -201,7 +194,7 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   g.scale = (const float*)L.wino_ss.p;
   g.shift = (const float*)L.wino_ss.p + g.cout_pad;
   L.wino_group_floats = gf;
-  if (g.s_planes && cin_pad % 16 == 0) {
+  if (g.rs) {
     const size_t gb = sx_packed_bytes(cin_pad, cout, g.bn_tile, g.s_planes);
     std::vector<unsigned char> ps(36 * gb);
     for (int pos = 0; pos < 36; ++pos)
@@ -215,17 +208,15 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   return 0;
 }
 
-// Row padding per Winograd position: whole 256-row tiles where the position GEMMs run on a 256-row kernel (the S-format
-// one of gemm_sx.hip; the three-stage fp32 one of conv_pw.hip for K >= 1024; the register-split one of gemm_rs.hip),
-// else 128
+// Row padding per Winograd position: whole 256-row tiles where the position GEMMs run on a 256-row kernel (the
+// three-stage fp32 one of conv_pw.hip for K >= 1024; the 256 x 256 one of gemm_rs.hip), else 128
 inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
   int th, tw;
   long long n_tiles, m_pad;
   wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, 256);
   const ConvDesc& g = L.wino;
   if (g.rs) return gemm_rs_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;
-  if (g.w_s) return 256;
-  return (g.mode == 0 && conv_pw_enabled() && conv_pw_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
+  return (conv_pw_enabled() && conv_pw_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
 }
 
 // floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]
@@ -246,14 +237,14 @@ inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_
   const int gran = wino_gran_for(L, a.B, a.H, a.W);
   wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad, gran);
   if (36 * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
-  if ((rc = launch_wino_input(a.x, wino_v, nullptr, 0, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran))) return rc;
+  if ((rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran))) return rc;
   ConvArgs g{};
   g.x = wino_v; g.y = wino_m;
   g.B = 1; g.H = 1; g.W = (int)(36 * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
   g.ws = a.ws; g.ws_floats = a.ws_floats;
   g.mt_per_group = (int)(m_pad / 128); g.w_group_stride = L.wino.rs ? L.wino_group_bytes : L.wino_group_floats;
   if ((rc = launch_conv(L.wino, g, s))) return rc;
-  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, nullptr, 0, 0, 0, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s, gran);
+  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s, gran);
 }
 
 // ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----

@@ -31,13 +31,6 @@ const char* noted_kernel() { return g_kernel; }
 
 namespace {
 
-// an activation in the S layout of gemm_sx.hip
-struct SAct {
-  size_t off = 0, bytes = 0;
-  int rows_pad = 0;
-  bool valid = false;
-};
-
 enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE, OP_WINO_IN, OP_WINO_GEMM, OP_WINO_OUT };
 
 struct Op {
@@ -51,8 +44,6 @@ struct Op {
   double bytes = 0;            // algorithmic HBM bytes: every operand read once, the result written once
   int wino_mt_per_group = 0;   // OP_WINO_GEMM: 128-row tiles per Winograd position
   int wino_gran = 128;         // row padding of the Winograd position GEMMs
-  SAct in_s, out_s;            // S-format (pre-split bf16 pieces, gemm_sx.hip) copies of the input / output, if any
-  bool skip_f32 = false;       // the fp32 output is not written (only out_s is consumed)
   // two-stream schedule of the PSP head (build_plan): branch 1 ops run on the handle's side stream; the first of them
   // waits for everything enqueued so far on the caller's stream (fork), join_before makes the caller's stream wait for
   // the side stream before this op
@@ -200,7 +191,7 @@ std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, c
   if (parts.size() < 2) return nullptr;
   const ConvDesc& d0 = parts[0]->d;
   for (const ConvLayer* L : parts)
-    if (L->d.mode != 0 || L->d.kh != 1 || L->d.kw != 1 || L->d.cin != d0.cin || L->d.cout != d0.cout || L->d.bn_tile != d0.bn_tile ||
+    if (L->d.kh != 1 || L->d.kw != 1 || L->d.cin != d0.cin || L->d.cout != d0.cout || L->d.bn_tile != d0.bn_tile ||
         L->d.bk != d0.bk || L->d.relu != d0.relu || L->w.bytes != parts[0]->w.bytes || L->ss.bytes != parts[0]->ss.bytes)
       return nullptr;
   auto G = std::make_unique<ConvLayer>();
@@ -226,84 +217,54 @@ std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, c
 }
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
-std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, bool s_input = false, long long M = 0, int mt_per_group = 0) {
+std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long long M = 0, int mt_per_group = 0) {
   if (d.rs) return gemm_rs_kernel_name(d.cout, M, mt_per_group, d.bn_tile, d.cin, d.s_planes);
-  if (s_input) {
-    if (gemm_sx_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return d.s_planes == 3 ? "gemm_sx6_256x256" : "gemm_sx3_256x256";
-    return std::string(d.s_planes == 3 ? "gemm_sx6_128x" : "gemm_sx3_128x") + std::to_string(d.bn_tile);
-  }
-  if (d.mode == 0 && d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
+  if (d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
     return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
                                                                          : "conv_pw_glds_128x" + std::to_string(d.bn_tile);
-  return std::string(d.mode == 0 ? "conv_igemm_128x" : (d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
-         std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
+  return "conv_igemm_128x" + std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
 }
 
-SAct make_sact(Arena& ar, size_t rows, int channels, int planes) {
-  SAct t;
-  t.rows_pad = s_rows_pad(rows);
-  t.bytes = s_tensor_bytes(rows, channels, planes);
-  t.off = ar.alloc(t.bytes);
-  t.valid = true;
-  return t;
-}
-
-// One conv layer into the plan.
-//   in_s   S copy of the input: a pointwise layer with S-packed weights then runs on gemm_sx.hip
-//   out_s  where the epilogue (or the Winograd output transform) shall also write the S form of the result
-//   skip_f32  the fp32 result has no consumer (out.off is then never written)
-// `ar` is only needed for layers that carry a Winograd form (scratch for the transformed tensors).
-void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr,
-               const SAct* in_s = nullptr, const SAct* out_s = nullptr, bool skip_f32 = false) {
+// One conv layer into the plan.  `ar` is only needed for layers that carry a Winograd form (scratch for the transformed
+// tensors).
+void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr) {
   if (L->has_wino && !in2 && ar) {
     // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
     int th, tw;
     long long n_tiles, m_pad;
-    const bool s_gemm = L->wino.w_s != nullptr && !L->wino.rs;
     const bool rs_gemm = L->wino.rs != 0;
     const int gran = wino_gran_for(*L, in.B, in.H, in.W);
     wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran);
-    Act v;   // fp32 V (unused in the S form)
-    SAct vs;
-    if (s_gemm) vs = make_sact(*ar, (size_t)(36 * m_pad), in.C, L->wino.s_planes);
-    else v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
+    Act v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
     Act m = make_act(*ar, 1, 1, (int)(36 * m_pad), L->d.cout);
     Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
-    a.out_s = vs; a.wino_gran = gran;
-    a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0);
+    a.wino_gran = gran;
+    a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * 4.0;
     pl.ops.push_back(a);
-    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, s_gemm, 36 * m_pad, (int)(m_pad / 128)); g.conv = L;
-    (void)rs_gemm;
-    g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.in_s = vs; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
+    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, 36 * m_pad, (int)(m_pad / 128)); g.conv = L;
+    g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
     g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
-    g.bytes = 36.0 * (double)m_pad * (in.C * (s_gemm ? 2.0 * L->wino.s_planes : 4.0) + L->d.cout * 4.0) +
-              36.0 * ((s_gemm || rs_gemm) ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
+    g.bytes = 36.0 * (double)m_pad * (in.C * 4.0 + L->d.cout * 4.0) +
+              36.0 * (rs_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
     pl.ops.push_back(g);
     Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
-    if (out_s) o.out_s = *out_s;
-    o.skip_f32 = skip_f32; o.wino_gran = gran;
-    o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (skip_f32 ? 0.0 : (double)out.bytes) + (res ? (double)out.bytes : 0.0) +
-              (out_s ? (double)out_s->bytes : 0.0);
+    o.wino_gran = gran;
+    o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (double)out.bytes + (res ? (double)out.bytes : 0.0);
     pl.ops.push_back(o);
-    if (s_gemm) ar->release(vs.off, vs.bytes); else ar->release(v.off, v.bytes);
+    ar->release(v.off, v.bytes);
     ar->release(m.off, m.bytes);
     return;
   }
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  const bool s_in = in_s && in_s->valid && L->d.w_s && !in2;
-  op.kernel = conv_kernel_name(L->d, in2 != nullptr, s_in, (long long)out.B * out.H * out.W, 0);
+  op.kernel = conv_kernel_name(L->d, in2 != nullptr, (long long)out.B * out.H * out.W, 0);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
-  if (s_in) op.in_s = *in_s;
-  if (out_s) op.out_s = *out_s;
-  op.skip_f32 = skip_f32;
   op.flops = conv_flops(L, out);
-  op.bytes = (s_in ? (double)in_s->bytes : (double)in.bytes) + (in2 ? (double)in2->bytes : 0.0) +
-             (skip_f32 ? 0.0 : (double)out.bytes) + (res ? (double)out.bytes : 0.0) + (out_s ? (double)out_s->bytes : 0.0) +
-             ((s_in || L->d.rs) ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
-                   : (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4);
+  op.bytes = (double)in.bytes + (in2 ? (double)in2->bytes : 0.0) + (double)out.bytes + (res ? (double)out.bytes : 0.0) +
+             (L->d.rs ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
+                      : (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4);
   pl.ops.push_back(op);
 }
 
@@ -339,50 +300,35 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     rel(x);
     x = y;
   }
-  // residual stages.  In the emulated-fp32 modes (S-format operands, gemm_sx.hip) the pointwise convs read the bf16
-  // pieces their producers wrote: block outputs carry both forms (fp32 for the identity / pooling, S for the next
-  // block's conv1 and downsample), conv2's output only the S form (its single consumer is conv3).
-  const int planes = s_planes_of(h->cfg.precision);
-  SAct xs;   // S copy of the running activation x (invalid until a conv epilogue has produced one)
+  // residual stages (the same plan in every precision mode: activations are fp32 throughout)
   for (size_t li = 0; li < h->layers.size(); ++li) {
     for (size_t bi = 0; bi < h->layers[li].size(); ++bi) {
       const auto& blk = h->layers[li][bi];
       const ConvDesc& d2 = blk.c2->d;
-      const bool last_block = li + 1 == h->layers.size() && bi + 1 == h->layers[li].size();
       Act t1 = make_act(ar, B, x.H, x.W, blk.c1->d.cout);
-      push_conv(*pl, blk.c1, x, nullptr, nullptr, t1, nullptr, &xs);
+      push_conv(*pl, blk.c1, x, nullptr, nullptr, t1);
       const int h2 = conv_out_dim(x.H, 3, d2.stride, d2.pad, d2.dil), w2 = conv_out_dim(x.W, 3, d2.stride, d2.pad, d2.dil);
-      const bool t2_s = planes && blk.c3->d.w_s && d2.cout % 16 == 0;   // conv3 can take its input as S
-      Act t2;
-      SAct t2s;
-      if (t2_s) { t2s = make_sact(ar, (size_t)B * h2 * w2, d2.cout, planes); t2.B = B; t2.H = h2; t2.W = w2; t2.C = d2.cout; }
-      else t2 = make_act(ar, B, h2, w2, d2.cout);
-      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2, &ar, nullptr, t2_s ? &t2s : nullptr, t2_s);
+      Act t2 = make_act(ar, B, h2, w2, d2.cout);
+      push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2, &ar);
       rel(t1);
       Act idn = x;
       bool own_idn = false;
-      const bool fused_c3d = blk.c3d != nullptr && !planes && !t2_s && !h->keep_all;   // debug plans keep the two separate layers
+      const bool fused_c3d = blk.c3d != nullptr && !h->keep_all;   // debug plans keep the two separate layers
       if (blk.down && !fused_c3d) {
         idn = make_act(ar, B, h2, w2, blk.down->d.cout);
-        push_conv(*pl, blk.down, x, nullptr, nullptr, idn, nullptr, &xs);
+        push_conv(*pl, blk.down, x, nullptr, nullptr, idn);
         own_idn = true;
       }
       Act y = make_act(ar, B, h2, w2, blk.c3->d.cout);
-      SAct ys;
-      const bool y_s = planes && !last_block && blk.c3->d.cout % 16 == 0;   // next block's conv1 (+ downsample) read it
-      if (y_s) ys = make_sact(ar, (size_t)B * h2 * w2, blk.c3->d.cout, planes);
       if (fused_c3d) push_conv(*pl, blk.c3d, t2, &x, nullptr, y);     // [t2 | x] x [W3'; Wd'] + shifts, ReLU: conv3 and the downsample in one GEMM
-      else push_conv(*pl, blk.c3, t2, nullptr, &idn, y, nullptr, &t2s, y_s ? &ys : nullptr);  // BN3 + identity + ReLU fused (resnet.py:289-305)
-      if (t2_s) ar.release(t2s.off, t2s.bytes); else rel(t2);
+      else push_conv(*pl, blk.c3, t2, nullptr, &idn, y);              // BN3 + identity + ReLU fused (resnet.py:289-305)
+      rel(t2);
       if (own_idn) rel(idn);
       rel(x);
-      if (xs.valid) ar.release(xs.off, xs.bytes);
       x = y;
-      xs = ys;
     }
     pl->named["layer" + std::to_string(li + 1)] = x;
   }
-  if (xs.valid) { ar.release(xs.off, xs.bytes); xs = SAct(); }
   // PSP head.  In the folded form the pyramid branch (pooling, the per-scale 1x1 convs, the Q tables and the 9-tap
   // term R: small, latency- or HBM-bound kernels) only meets the 3x3 bottleneck conv over x at that conv's residual
   // input, so it runs on a side stream underneath the bottleneck's Winograd input transform and GEMM.  Its buffers
@@ -522,11 +468,8 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
 static size_t plan_high_water(const Plan& pl) {
   size_t hw = 0;
   auto upd = [&](const Act& a) { if (a.bytes && a.off + Arena::round_up(a.bytes) > hw) hw = a.off + Arena::round_up(a.bytes); };
-  auto upd_s = [&](const SAct& a) { if (a.valid && a.off + Arena::round_up(a.bytes) > hw) hw = a.off + Arena::round_up(a.bytes); };
   for (const auto& op : pl.ops) {
-    upd(op.in); upd(op.in2); upd(op.res);
-    if (!op.skip_f32) upd(op.out);
-    upd_s(op.in_s); upd_s(op.out_s);
+    upd(op.in); upd(op.in2); upd(op.res); upd(op.out);
   }
   for (const auto& kv : pl.named) upd(kv.second);
   upd(pl.splitk);
@@ -563,9 +506,6 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       a.c1 = op.in.C; a.c2 = op.has_in2 ? op.in2.C : 0;
       a.Ho = op.out.H; a.Wo = op.out.W;
       a.ws = P(op.branch ? pl.splitk2 : pl.splitk); a.ws_floats = kSplitKScratchFloats;
-      if (op.in_s.valid) { a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad; }
-      if (op.out_s.valid) { a.ys = (unsigned short*)(base + op.out_s.off); a.ys_rows = op.out_s.rows_pad; }
-      a.skip_f32 = op.skip_f32;
       if (op.group_mt) {     // per-scale PSP convs as one grouped GEMM over [scales * srows, C]
         a.mt_per_group = op.group_mt;
         a.w_group_stride = op.conv->w.bytes / sizeof(float) / (size_t)h->cfg.n_pool_scales;
@@ -574,30 +514,19 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       return launch_conv(op.conv->d, a, s);
     }
     case OP_WINO_IN:
-      return launch_wino_input(P(op.in), op.out_s.valid ? nullptr : P(op.out),
-                               op.out_s.valid ? (unsigned short*)(base + op.out_s.off) : nullptr, op.conv->wino.s_planes, op.in.B,
-                               op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran);
+      return launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran);
     case OP_WINO_GEMM: {
       ConvArgs a{};
       a.x = P(op.in); a.y = P(op.out);
       a.B = 1; a.H = 1; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = 1; a.Wo = op.in.W;
       a.ws = P(op.branch ? pl.splitk2 : pl.splitk); a.ws_floats = kSplitKScratchFloats;
       a.mt_per_group = op.wino_mt_per_group;
-      if (op.in_s.valid) {
-        a.xs = (const unsigned short*)(base + op.in_s.off); a.xs_rows = op.in_s.rows_pad;
-        a.w_group_stride = op.conv->wino_group_bytes;
-      } else if (op.conv->wino.rs) {
-        a.w_group_stride = op.conv->wino_group_bytes;
-      } else {
-        a.w_group_stride = op.conv->wino_group_floats;
-      }
+      a.w_group_stride = op.conv->wino.rs ? op.conv->wino_group_bytes : op.conv->wino_group_floats;
       return launch_conv(op.conv->wino, a, s);
     }
     case OP_WINO_OUT:
       return launch_wino_output(P(op.in), op.conv->d.scale, op.conv->d.shift, op.has_res ? P(op.res) : nullptr, P(op.out),
-                                op.out_s.valid ? (unsigned short*)(base + op.out_s.off) : nullptr, op.out_s.rows_pad,
-                                op.conv->d.s_planes, op.skip_f32 ? 1 : 0, op.out.B, op.out.H, op.out.W, op.out.C,
-                                op.conv->d.dil, op.conv->d.relu, s, op.wino_gran);
+                                op.out.B, op.out.H, op.out.W, op.out.C, op.conv->d.dil, op.conv->d.relu, s, op.wino_gran);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:
@@ -629,7 +558,8 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
   if (cfg->in_channels < 1 || cfg->num_classes < 1 || cfg->num_classes > 32)
     return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
   if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
-  if (cfg->precision < 0 || cfg->precision > 5) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6,BF16X6_RS,BF16X3_RS}");
+  if (cfg->precision != PEANUT_PREC_FP32 && cfg->precision != PEANUT_PREC_BF16X3 && cfg->precision != PEANUT_PREC_BF16X6)
+    return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,BF16X6}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT)
     return fail(PEANUT_EINVAL, "conv_algo must be PEANUT_ALGO_{AUTO,DIRECT}");
   auto h = std::make_unique<peanut_pred>();
@@ -661,8 +591,8 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
       if ((rc = add_conv(h.get(), tm, p + ".conv3", p + ".bn3", planes, planes, planes * 4, 1, 1, 0, 1, 1, &b.c3))) return rc;
       if (bi == 0 && (stride != 1 || inplanes != planes * 4)) {
         if ((rc = add_conv(h.get(), tm, p + ".downsample.0", p + ".downsample.1", inplanes, inplanes, planes * 4, 1, stride, 0, 1, 0, &b.down))) return rc;
-        static const bool fuse = [] { const char* e = getenv("PEANUT_FUSE_C3D"); return !(e && e[0] == '0'); }();
-        if (fuse && s == 1 && (cfg->precision == PEANUT_PREC_FP32 || rs_planes_of(cfg->precision)) && planes % 32 == 0 && inplanes % 32 == 0 && conv_pw_enabled() &&
+        // conv_algo AUTO only: DIRECT keeps the reference's op-for-op form (conv3 -> BN, downsample -> BN, add, ReLU)
+        if (cfg->conv_algo == PEANUT_ALGO_AUTO && s == 1 && planes % 32 == 0 && inplanes % 32 == 0 && conv_pw_enabled() &&
             (rc = add_fused_c3d(h.get(), tm, p, planes, inplanes, planes * 4, &b.c3d)))
           return rc;
       }
@@ -875,10 +805,8 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
   if (!out || !w) return fail(PEANUT_EINVAL, "peanut_conv_create: null argument");
   if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
-  if (precision < 0 || precision > 5 || precision == PEANUT_PREC_BF16X6) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
-  if ((precision == PEANUT_PREC_BF16X3 || precision == PEANUT_PREC_FP16X3) && cin_pad % 32 != 0)
-    return fail(PEANUT_EINVAL, "peanut_conv_create: the split-precision modes need cin_pad % 32 == 0 (this layer would "
-                               "have to run in fp32); create it with PEANUT_PREC_FP32 explicitly");
+  if (precision != PEANUT_PREC_FP32 && precision != PEANUT_PREC_BF16X3 && precision != PEANUT_PREC_BF16X6)
+    return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
   auto c = std::make_unique<peanut_conv>();
   c->L.name = "conv";
   if (conv_algo != PEANUT_ALGO_AUTO && conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "peanut_conv_create: bad conv_algo");
@@ -897,8 +825,8 @@ void peanut_conv_destroy(peanut_conv_t* c) { delete c; }
 int peanut_conv_precision(peanut_conv_t* c) {
   if (!c) return PEANUT_EINVAL;
   const ConvDesc& d = (c->L.has_wino && c->L.wino.rs) ? c->L.wino : c->L.d;
-  if (d.rs) return d.s_planes == 3 ? PEANUT_PREC_BF16X6_RS : PEANUT_PREC_BF16X3_RS;
-  return c->L.d.mode;
+  if (d.rs) return d.s_planes == 3 ? PEANUT_PREC_BF16X6 : PEANUT_PREC_BF16X3;
+  return PEANUT_PREC_FP32;
 }
 
 int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c1, const float* res, float* y, int B,

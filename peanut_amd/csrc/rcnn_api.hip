@@ -299,8 +299,8 @@ void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
 void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
   ROp op;
   op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = std::string(L->d.mode == 0 ? "conv_igemm_128x" : (L->d.mode == 1 ? "conv_igemm_bf16x3_128x" : "conv_igemm_fp16x3_128x")) +
-              std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
+  op.kernel = L->d.rs ? std::string(L->d.s_planes == 3 ? "gemm_rs6" : "gemm_rs3")
+                      : "conv_igemm_128x" + std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
   op.ext_slot = ext_slot;
@@ -444,7 +444,8 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
   if (cfg->depth != 50 && cfg->depth != 101 && cfg->depth != 152) return fail(PEANUT_EINVAL, "rcnn: depth must be 50/101/152");
   if (cfg->fpn_out % 32 || cfg->num_anchors < 1 || cfg->min_size < 32 || cfg->size_divisibility != 32)
     return fail(PEANUT_EINVAL, "rcnn: unsupported configuration");
-  if (cfg->precision < 0 || cfg->precision > 5 || cfg->precision == PEANUT_PREC_BF16X6) return fail(PEANUT_EINVAL, "rcnn: bad precision");
+  if (cfg->precision != PEANUT_PREC_FP32 && cfg->precision != PEANUT_PREC_BF16X3 && cfg->precision != PEANUT_PREC_BF16X6)
+    return fail(PEANUT_EINVAL, "rcnn: precision must be PEANUT_PREC_{FP32,BF16X3,BF16X6}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "rcnn: bad conv_algo");
   auto h = std::make_unique<peanut_rcnn>();
   h->cfg = *cfg;
@@ -469,8 +470,8 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
       if ((rc = add_rconv(h.get(), tm, p + ".conv1", cin, cin, bott, 1, s1, 0, true, 1, &b.c1))) return rc;
       if ((rc = add_rconv(h.get(), tm, p + ".conv2", bott, bott, bott, 3, s3, 1, true, 1, &b.c2))) return rc;
       if ((rc = add_rconv(h.get(), tm, p + ".conv3", bott, bott, cout, 1, 1, 0, true, 1, &b.c3))) return rc;   // ReLU after the add
-      static const bool fuse = [] { const char* e = getenv("PEANUT_FUSE_C3D"); return !(e && e[0] == '0'); }();
-      if (fuse && b.shortcut && s == 1 && (cfg->precision == PEANUT_PREC_FP32 || rs_planes_of(cfg->precision)) && bott % 32 == 0 && cin % 32 == 0 && conv_pw_enabled() &&
+      // conv_algo AUTO only: DIRECT keeps detectron2's op-for-op form (conv3 -> FrozenBN, shortcut -> FrozenBN, add, ReLU)
+      if (cfg->conv_algo == PEANUT_ALGO_AUTO && b.shortcut && s == 1 && bott % 32 == 0 && cin % 32 == 0 && conv_pw_enabled() &&
           (rc = add_fused_c3s(h.get(), tm, p, bott, cin, cout, &b.c3s)))
         return rc;
       blocks.push_back(b);

@@ -69,34 +69,22 @@ __device__ __forceinline__ void decode_tile(const WinoGeom& g, long long t, int&
   b = (int)(t / g.d);
 }
 
-// Thread -> (tile, 4-channel group).  Default: channel group fastest (a wave = 256 consecutive channels of one tile:
-// 1 KiB fp32 runs).  For S-format output a wave instead covers 16 consecutive tiles x one 16-channel chunk, so that
-// its 8-byte piece stores form 512-byte runs in the [chunk][plane][row][16] layout (reads become 64-byte runs).
-__device__ __forceinline__ bool decode_thread(long long idx, int groups, long long n_tiles, bool s_layout, int& cg, long long& tile) {
-  if (!s_layout) {
-    cg = (int)(idx % groups);
-    tile = idx / groups;
-    return tile < n_tiles;
-  }
-  const int nchunks = groups >> 2;
-  const int quad = (int)(idx & 3), tile_lo = (int)((idx >> 2) & 15);
-  const long long rest = idx >> 6;
-  cg = (int)(rest % nchunks) * 4 + quad;
-  tile = (rest / nchunks) * 16 + tile_lo;
+// Thread -> (tile, 4-channel group), channel group fastest: a wave = 256 consecutive channels of one tile (1 KiB fp32 runs)
+__device__ __forceinline__ bool decode_thread(long long idx, int groups, long long n_tiles, int& cg, long long& tile) {
+  cg = (int)(idx % groups);
+  tile = idx / groups;
   return tile < n_tiles;
 }
 
 // V[(i*6+j)][tile][c] = (B^T d B)[i][j]
-// (or, when Vs is given, the same values as bf16 pieces in the S layout of gemm_sx.hip: rows = pos * m_pad + tile)
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                         unsigned short* __restrict__ Vs, int planes, const WinoGeom g) {
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, const WinoGeom g) {
   const int groups = g.C >> 2;
-  const long long total = (Vs ? (g.n_tiles + 15) / 16 * 16 : g.n_tiles) * groups;
+  const long long total = g.n_tiles * groups;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     int cg;
     long long tile;
-    if (!decode_thread(idx, groups, g.n_tiles, Vs != nullptr, cg, tile)) continue;
+    if (!decode_thread(idx, groups, g.n_tiles, cg, tile)) continue;
     int b, oy, ox, ty, tx;
     decode_tile(g, tile, b, oy, ox, ty, tx);
     const int r0 = oy + g.d * (4 * ty - 1), c0 = ox + g.d * (4 * tx - 1);
@@ -123,17 +111,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     for (int i = 0; i < 6; ++i) {  // rows: (p B)[i][:]
       f32x4 t0, t1, t2, t3, t4, t5;
       bt6(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], t0, t1, t2, t3, t4, t5);
-      if (Vs) {
-        const int rows_pad = (int)(36 * g.m_pad);
-        const int row = (int)((long long)(i * 6) * g.m_pad + tile);
-        store_s_quad(Vs, rows_pad, planes, row, cg * 4, t0);
-        store_s_quad(Vs, rows_pad, planes, row + (int)g.m_pad, cg * 4, t1);
-        store_s_quad(Vs, rows_pad, planes, row + 2 * (int)g.m_pad, cg * 4, t2);
-        store_s_quad(Vs, rows_pad, planes, row + 3 * (int)g.m_pad, cg * 4, t3);
-        store_s_quad(Vs, rows_pad, planes, row + 4 * (int)g.m_pad, cg * 4, t4);
-        store_s_quad(Vs, rows_pad, planes, row + 5 * (int)g.m_pad, cg * 4, t5);
-        continue;
-      }
       float* o = vb + (size_t)(i * 6) * pos_stride;
       *reinterpret_cast<f32x4*>(o) = t0;
       *reinterpret_cast<f32x4*>(o + pos_stride) = t1;
@@ -148,15 +125,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // y[pixel][n] = relu(scale[n] * (A^T M A)[a][b] + shift[n] + res[pixel][n])
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ res,
-                                                          float* __restrict__ y, unsigned short* __restrict__ ys, int ys_rows,
-                                                          int planes, int skip_f32, const WinoGeom g, int relu) {
+                                                          float* __restrict__ y, const WinoGeom g, int relu) {
   const int groups = g.C >> 2;
-  const long long total = (ys ? (g.n_tiles + 15) / 16 * 16 : g.n_tiles) * groups;
+  const long long total = g.n_tiles * groups;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     int ng;
     long long tile;
-    if (!decode_thread(idx, groups, g.n_tiles, ys != nullptr, ng, tile)) continue;
+    if (!decode_thread(idx, groups, g.n_tiles, ng, tile)) continue;
     int b, oy, ox, ty, tx;
     decode_tile(g, tile, b, oy, ox, ty, tx);
     const int r0 = oy + g.d * 4 * ty, c0 = ox + g.d * 4 * tx;
@@ -193,8 +169,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         f32x4 v = o[a] * sc + sh;
         if (res) v += *reinterpret_cast<const f32x4*>(res + off);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (!skip_f32) *reinterpret_cast<f32x4*>(y + off) = v;
-        if (ys) store_s_quad(ys, ys_rows, planes, (int)(img + (size_t)r * g.W + c), ng * 4, v);
+        *reinterpret_cast<f32x4*>(y + off) = v;
       }
     }
   }
@@ -239,27 +214,24 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out) 
     }
 }
 
-int launch_wino_input(const float* x, float* V, unsigned short* Vs, int planes, int B, int H, int W, int C, int dil,
-                      hipStream_t s, int gran) {
-  if (C % 4 || (Vs && C % 16)) return fail(-2, "wino_input: channels must be a multiple of 4 (16 for the S layout)");
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran) {
+  if (C % 4) return fail(-2, "wino_input: channels must be a multiple of 4");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran);
-  const long long total = (Vs ? (g.n_tiles + 15) / 16 * 16 : g.n_tiles) * (C / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, Vs, planes, g);
+  const long long total = g.n_tiles * (C / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_input launch: ") + hipGetErrorString(e));
   return 0;
 }
 
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
-                       unsigned short* ys, int ys_rows, int planes, int skip_f32, int B, int H, int W, int C, int dil, int relu,
-                       hipStream_t s, int gran) {
-  if (C % 4 || (ys && C % 16)) return fail(-2, "wino_output: channels must be a multiple of 4 (16 for the S layout)");
+                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran) {
+  if (C % 4) return fail(-2, "wino_output: channels must be a multiple of 4");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran);
-  const long long total = (ys ? (g.n_tiles + 15) / 16 * 16 : g.n_tiles) * (C / 4);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, ys, ys_rows, planes,
-                     skip_f32, g, relu);
+  const long long total = g.n_tiles * (C / 4);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_output launch: ") + hipGetErrorString(e));
   return 0;

@@ -60,20 +60,35 @@ class MapComm:
         self._lib = _lib.load()
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # Every step that can fail on one rank only is followed by a collective exchange of its status, so that all ranks
+        # raise (or carry on) TOGETHER: a rank that raised alone would leave the others blocked in the next collective.
         ident = (C.c_ubyte * 128)()
+        status, err = 0, ""
         if self.rank == 0:
-            _lib.check(self._lib.peanut_comm_unique_id(C.byref(ident)), "peanut_comm_unique_id")
-        t = torch.tensor(list(ident), dtype=torch.uint8)
+            try:
+                _lib.check(self._lib.peanut_comm_unique_id(C.byref(ident)), "peanut_comm_unique_id")
+            except Exception as e:  # noqa: BLE001 - reported to every rank below
+                status, err = 1, str(e)
+        t = torch.tensor([status] + list(ident), dtype=torch.uint8)
         on_gpu = dist.get_backend() == "nccl"
         if on_gpu:
             t = t.to(self.device)
         dist.broadcast(t, src=0)
-        for i, v in enumerate(t.cpu().tolist()):
+        vals = t.cpu().tolist()
+        if vals[0] != 0:
+            raise _lib.PeanutHipError("MapComm: rank 0 could not create the communicator id" + (f": {err}" if err else ""))
+        for i, v in enumerate(vals[1:]):
             ident[i] = v
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.peanut_comm_create(C.byref(self._h), self.world, self.rank, C.byref(ident)),
-                       "peanut_comm_create")
+            rc = self._lib.peanut_comm_create(C.byref(self._h), self.world, self.rank, C.byref(ident))
+        msg = (self._lib.peanut_last_error() or b"").decode() if rc else ""
+        bad = torch.tensor([1 if rc else 0], dtype=torch.int32, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            if not rc:                       # this rank's communicator is fine, a peer's is not: give it back
+                self.close()
+            raise _lib.PeanutHipError("MapComm: peanut_comm_create failed on " + ("this rank: " + msg if rc else "another rank"))
         self.backend = (self._lib.peanut_comm_backend() or b"").decode()
 
     def allgather_maps(self, local: torch.Tensor) -> torch.Tensor:

@@ -163,7 +163,7 @@ def test_pw256_kernel_grouped_winograd_gemm():
 
 
 # ---- register-split emulated-fp32 GEMM (csrc/gemm_rs.hip): fp32 activations, bf16 pieces peeled off in registers ----
-RS_TOL = {"bf16x6rs": 2e-5, "bf16x3rs": 1e-4}     # bf16x6: fp32-class, held to the fp32 kernels' own tolerance
+RS_TOL = {"bf16x6": 2e-5, "bf16x3": 1e-4}     # bf16x6: fp32-class, held to the fp32 kernels' own tolerance
 
 RS_CASES = [
     # (B, H, W, cin, cout, stride, relu, residual), kernel family without the piece count
@@ -180,10 +180,10 @@ RS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["bf16x6rs", "bf16x3rs"])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
 @pytest.mark.parametrize("case,family", RS_CASES, ids=lambda c: "x".join(map(str, c[:6])) if isinstance(c, tuple) else c)
 def test_register_split_gemm_matches_torch(case, family, precision):
-    _pw_case(case, precision, ("gemm_rs6_" if precision == "bf16x6rs" else "gemm_rs3_") + family, RS_TOL[precision])
+    _pw_case(case, precision, ("gemm_rs6_" if precision == "bf16x6" else "gemm_rs3_") + family, RS_TOL[precision])
 
 
 @pytest.mark.parametrize("case", [(2, 30, 30, 64, 64, 256), (1, 23, 17, 256, 512, 1024), (8, 64, 64, 512, 1024, 512),
@@ -198,7 +198,7 @@ def test_register_split_gemm_two_sources(case):
     w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
     shift = _rand((cout,), g, 0.1)
     ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) + shift[None, :, None, None])
-    conv = FusedConv(w, None, shift, relu=True, precision="bf16x6rs")
+    conv = FusedConv(w, None, shift, relu=True, precision="bf16x6")
     y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
     assert _last_kernel().startswith("gemm_rs6_"), _last_kernel()
     err = (y - ref).abs()
@@ -217,7 +217,7 @@ def test_register_split_winograd(case):
     w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
     res = _rand((B, cout, H, W), g)
     ref = F.relu(F.conv2d(x, w, None, padding=d, dilation=d) + res)
-    conv = FusedConv(w, None, None, padding=d, dilation=d, relu=True, precision="bf16x6rs")
+    conv = FusedConv(w, None, None, padding=d, dilation=d, relu=True, precision="bf16x6")
     y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda())
     assert _last_kernel() == ("gemm_rs6_256x256" if case[0] == 2 else "gemm_rs6_128x128"), _last_kernel()
     err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
@@ -239,35 +239,22 @@ def test_conv_transpose_detecting():
     assert torch.equal(y, ref)
 
 
-SPLIT_TOL = {"bf16x3": 1e-4, "fp16x3": 2e-5}   # relative to (1 + |ref|); fp32 products rebuilt from 3 halves
-
-
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
-@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 32 == 0], ids=lambda c: "x".join(map(str, c[:9])))
-def test_split_precision_conv(case, precision):
-    """bf16x3 / fp16x3 split-product kernels against the same fp32 PyTorch reference."""
-    from peanut_amd.ops import FusedConv, to_nhwc_padded, round_up
-    B, H, W, cin, cout, k, s, p, d, relu, residual = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
-    x = _rand((B, cin, H, W), g)
-    w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
-    scale = torch.rand(cout, generator=g) + 0.5
-    shift = _rand((cout,), g, 0.1)
-    ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d) * scale[None, :, None, None] \
-        + shift[None, :, None, None]
-    res = None
-    if residual:
-        res = _rand(tuple(ref.shape), g)
-        ref = ref + res
-    if relu:
-        ref = F.relu(ref)
-    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, precision=precision, conv_algo="direct")
-    xd = to_nhwc_padded(x.cuda(), round_up(cin, 16))
-    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
-    y = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
-    err = (y - ref).abs()
-    tol = SPLIT_TOL[precision] * (1 + ref.abs())
-    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}"
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+def test_emulated_modes_leave_non_pointwise_layers_in_fp32(precision):
+    """In the emulated-fp32 modes only pointwise layers (and Winograd position GEMMs) run on the bf16 matrix cores: a 3x3
+    direct conv and a narrow (cout < 64) 1x1 stay exact fp32 -- bit-identical to the fp32 handle -- and the handle says so."""
+    from peanut_amd import _lib
+    from peanut_amd.ops import FusedConv
+    g = torch.Generator().manual_seed(3)
+    for (cin, cout, k, pad) in [(64, 64, 3, 1), (512, 6, 1, 0)]:
+        x = _rand((2, 20, 20, cin), g).cuda()
+        w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
+        a = FusedConv(w, None, None, padding=pad, conv_algo="direct")
+        b = FusedConv(w, None, None, padding=pad, precision=precision, conv_algo="direct")
+        assert _lib.load().peanut_conv_precision(b._h) == _lib.PRECISIONS["fp32"]
+        assert torch.equal(a(x), b(x))
+    wide = FusedConv(_rand((128, 64, 1, 1), g, 0.1), None, None, precision=precision)
+    assert _lib.load().peanut_conv_precision(wide._h) == _lib.PRECISIONS[precision]
 
 
 WINO_CASES = [
@@ -282,7 +269,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-4), ("bf16x3", 1.5e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-4), ("bf16x6", 1.5e-4), ("bf16x3", 1.5e-3)])
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c[:6])))
 def test_winograd_conv_matches_torch(case, precision, tol):
     """conv_algo='auto' on a stride-1 3x3 layer with >= 256 input channels = Winograd F(4x4,3x3) (winograd.hip):

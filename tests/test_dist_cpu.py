@@ -74,3 +74,83 @@ def test_single_process_identity():
     t = torch.randn(2, 6, 4, 4)
     assert pdist.allgather_maps(t) is t
     assert pdist.max_over_ranks(3.5) == 3.5
+
+
+class _CountingAgent:
+    """Stands in for PEANUT_Agent in the outer-loop test: counts resets and frames, 'predicts' every second frame."""
+
+    def __init__(self):
+        self.resets, self.frames = 0, 0
+
+    def reset(self):
+        self.resets += 1
+
+    def act(self, observations):
+        self.frames += 1
+        assert set(observations) >= {"rgb", "depth", "gps", "compass", "objectgoal"}
+        return {"predicted": self.frames % 2 == 0}
+
+
+def _worker8(rank, world, port, ep_dir, n_eps, q):
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if root not in sys.path:
+            sys.path.insert(0, root)
+        import bench
+        from peanut_amd import replay
+        r, lr, w = pdist.init_process_group(backend="gloo")
+        assert (r, w) == (rank, world)
+        # (1) bench.py's map shards: rank r owns global maps [r * B, (r + 1) * B) -- the seeds make the union of the shards
+        #     exactly the global batch a single process would generate
+        B, C, S = 2, 6, 32
+        mine = bench.synth_maps(B, C, S, "cpu", seed0=rank * B)
+        allmaps = pdist.allgather_maps(mine)
+        assert allmaps.shape == (world * B, C, S, S)
+        assert torch.equal(allmaps, bench.synth_maps(world * B, C, S, "cpu", seed0=0))
+        # (2) episode shards (nav/arguments.py:15-20: --start_ep / --end_ep per process): contiguous, disjoint, complete
+        paths = [os.path.join(ep_dir, f"ep{i:02d}.npz") for i in range(n_eps)]
+        ids = replay.episode_shard(n_eps)
+        s, e = pdist.shard_range(n_eps, rank, world)
+        assert ids == list(range(s, e))
+        agent = _CountingAgent()
+        done = replay.run_recorded_shard(agent, paths, start_ep=s, end_ep=e) if e > s else {}
+        assert sorted(done) == ids and agent.resets == len(ids)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ids, dict(done), agent.frames))
+        owners = [i for g in gathered for i in g[0]]
+        assert owners == list(range(n_eps))                           # every episode exactly once, in rank order
+        assert sum(g[2] for g in gathered) == sum(3 + (i % 3) for i in range(n_eps))
+        # (3) the bench's timing reduction
+        assert pdist.max_over_ranks(float(rank + 1)) == float(world)
+        pdist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(ex) + traceback.format_exc()[-600:]))
+
+
+@pytest.mark.parametrize("n_eps", [8, 11])
+def test_world8_gloo_map_and_episode_shards(tmp_path, n_eps):
+    """SURVEY.md sec. 8d config 4 / 5 at the driver's scale: EIGHT ranks (gloo, CPU).  bench.py's shard seeds, the episode
+    windows of the reference's outer loop (8 episodes over 8 GPUs; 11 for a ragged split) and the rank-major collation."""
+    import numpy as np
+    from peanut_amd import episodes as E
+    for i in range(n_eps):
+        frames = [{"rgb": np.zeros((4, 4, 3), np.uint8), "depth": np.zeros((4, 4, 1), np.float32),
+                   "gps": np.zeros(2, np.float32), "compass": np.zeros(1, np.float32), "objectgoal": np.array([i % 6])}
+                  for _ in range(3 + (i % 3))]
+        E.save_episode(str(tmp_path / f"ep{i:02d}.npz"), frames)
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, str(tmp_path), n_eps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Max-abs distance of a precision mode's logits from the committed reference golden vectors (tests/golden/pspnet_golden.npz)
-and from the float64 run of the reference model (pspnet_fp64_golden.npz).  Usage: tools/check_mode.py bf16x6rs [fp32 ...]"""
+and from the float64 run of the reference model (pspnet_fp64_golden.npz).  Usage: tools/check_mode.py bf16x6 [fp32 ...]"""
 import os
 import sys
 from types import SimpleNamespace
