@@ -33,6 +33,9 @@ const char* peanut_last_conv_kernel(void);
 /* library / ABI version and the arch it was compiled for ("gfx950") */
 int peanut_abi_version(void);
 const char* peanut_build_arch(void);
+/* hash of the sources this library was compiled from (peanut_amd/build.py: source_hash), "" when built by other means: the
+ * Python binding compares it with the sources lying next to it and rebuilds or refuses a stale library */
+const char* peanut_source_hash(void);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 3 -- map-completion forward (PSPNet: ResNet-50-V1c-D8 + PSP head)
@@ -366,6 +369,9 @@ int peanut_goal_reset(peanut_goal_t* g);
 /* relaxation rounds / second-order ordering passes the last solve took (diagnostics) */
 int peanut_goal_rounds(peanut_goal_t* g);
 int peanut_goal_passes(peanut_goal_t* g);
+/* 1 when the last solve's ordering passes reached their fixed point (a pass that changed nothing), 0 when they stopped at
+ * the pass cap (6) with the last pass still changing tiles: the field is then the last iterate, not the fixed point. */
+int peanut_goal_converged(peanut_goal_t* g);
 /* agent_state.py:382-386: trav = ~binary_dilation(rint(full_map[0]), disk(col_rad)); trav[collision_map == 1] = 0;
  * trav[visited_vis == 1] = 1.  full_obstacle device fp32 [H,W]; collision_map / visited_vis device uint8 [H,W] or
  * NULL; trav_out device uint8 [H,W] (NULL: kept inside the handle). */

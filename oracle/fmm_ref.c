@@ -19,14 +19,22 @@
  *                d2 <= v1 use the second-order term  (9/4) (u - (4 v1 - d2)/3)^2 , else (u - v1)^2 ; solve
  *                sum = 1 for the larger root (distanceMarcher::updatePointOrderTwo / solveQuadratic).
  *
- * Second-order rule.  The second upwind neighbour n2 (two cells from the point, behind the Frozen neighbour n1) is
- * used when it is Frozen and strictly closer to the contour than n1 on the point's own side (phi > 0: d2 < v1).
- * Two details of scikit-fmm's test could not be checked without its source and are fixed here by what its
- * documented outputs imply: (i) the comparison is strict -- the `skfmm.distance` docstring example
- * (phi = ones((3,3)), phi[1,1] = -1 -> corners 1.20710678 = 0.5 + 1/sqrt(2)) is the FIRST-order value although the
- * second neighbour is Frozen at an equal 0.5; (ii) the side is taken from the sign of phi at the point, so a cell
- * next to an exact zero of phi (the reference plants one at the agent / goal cell) gets distance 1, not the 1/3 a
- * sign test on v1 == 0 would give.  Either way only cells within two steps of a seed are affected.
+ * Second-order rule (revised in round 3 after review).  The second upwind neighbour n2 (two cells from the point, behind
+ * the Frozen neighbour n1) is used when it is Frozen and NOT FARTHER from the contour than n1 on the point's own side
+ * (phi > 0: d2 <= v1) -- updatePointOrderTwo's test is `distance_[naddr2] <= value1 && value1 >= 0` (and its mirror
+ * for the negative side) -- and a value2 picked up in the j = -1 direction is NOT reset when the j = +1 direction then
+ * supplies the smaller value1 without a qualifying second neighbour of its own (the library's loop simply leaves the
+ * variable alone).  Consequence that matters for PEANUT: next to two adjacent equal seeds (FMMPlanner.set_multi_goal
+ * goal blobs, fmm_planner.py:67-75) the cell in line with them gets 2/3, not 1.  Round 2 had the comparison strict and
+ * justified it with the `skfmm.distance` docstring example (phi = ones((3,3)), phi[1,1] = -1 -> corners 1.20710678);
+ * that was a misreading: a corner's second neighbour along an axis is another corner, which is never Frozen with a
+ * smaller value, so the example says nothing about strictness.
+ * One detail stays a choice of this restatement (scikit-fmm's source is not available here): the side is taken from
+ * the sign of phi at the point, so that for v1 == 0 exactly (a cell next to an exact zero of phi: the reference plants
+ * one at the agent / goal cell) only a second neighbour with d2 <= 0 -- another seed -- qualifies.  A literal sign
+ * test on value1 (`value1 <= 0` is true at 0 as well) would also admit a Frozen cell at distance 1 on the far side of
+ * the seed and yield 1/3 on one side of a single seed; whether the library does that could not be checked.  Only cells
+ * within two steps of a seed are affected either way.
  *
  * Heap tie-breaking follows a textbook binary heap (push at the end + sift up, pop = move last to the root + sift
  * down, strict comparisons); scikit-fmm's exact order among EQUAL keys cannot be reproduced without its source and
@@ -142,12 +150,11 @@ static double update_point_order_two(const grid_t* g, int i) {
       if (n != -1 && g->flag[n] == FROZEN && fabs(g->dist[n]) < fabs(value1)) {
         value1 = g->dist[n];
         int n2 = get_n(g, i, dim, j * 2);
-        /* monotone second neighbour on the side phi[i] lies on (see "Second-order rule" in the header) */
+        /* monotone second neighbour on the side phi[i] lies on; value2 is NOT reset otherwise (see "Second-order rule"
+         * in the header) */
         if (n2 != -1 && g->flag[n2] == FROZEN &&
-            ((g->phi[i] > 0 && g->dist[n2] < value1) || (g->phi[i] < 0 && g->dist[n2] > value1)))
+            ((g->phi[i] > 0 && g->dist[n2] <= value1) || (g->phi[i] < 0 && g->dist[n2] >= value1)))
           value2 = g->dist[n2];
-        else
-          value2 = DBL_MAX;
       }
     }
     if (value2 < DBL_MAX) {

@@ -31,9 +31,25 @@ def reference_module(cfg: mapping_ref.MapCfg):
     return SM(args).eval()
 
 
+# non-default flags of mapping.py:15-37 (round 3): (name, MapCfg overrides, scene seed, frames)
+FLAG_VARIANTS = [
+    ("du2", dict(du_scale=2), 4, 5),                                       # depth sub-sampled, semantics average-pooled 2x2
+    ("vr64_map2400", dict(vision_range=64, map_size_cm=2400), 5, 5),       # smaller egocentric window, 240 x 240 local map
+    ("f96x128", dict(frame_height=96, frame_width=128, hfov=90.0, camera_height=1.25), 6, 6),   # another camera
+]
+
+
 def generate(report):
     _generate(report, mapping_ref.MapCfg(), SEQS, "mapping_golden.npz")
     _generate(report, mapping_ref.MapCfg(num_sem_categories=22), SEQS_C22, "mapping_golden_c22.npz")
+    out = {}
+    for name, over, seed, n in FLAG_VARIANTS:
+        cfg = mapping_ref.MapCfg(**over)
+        part = _generate(report, cfg, [(name, seed, n)], None)
+        for k, v in over.items():
+            part[f"{name}/cfg_{k}"] = np.array(v)
+        out.update(part)
+    np.savez_compressed(os.path.join(GOLDEN, "mapping_golden_flags.npz"), **out)
 
 
 def _generate(report, cfg, seqs, fname):
@@ -41,7 +57,8 @@ def _generate(report, cfg, seqs, fname):
     out = {}
     torch.set_grad_enabled(False)
     for name, seed, n in seqs:
-        frames = mapping_scenes.make_sequence(seed, n, ncat=cfg.num_sem_categories)
+        frames = mapping_scenes.make_sequence(seed, n, h=cfg.frame_height, w=cfg.frame_width, ncat=cfg.num_sem_categories,
+                                              hfov=cfg.hfov, cam_h_cm=cfg.camera_height * 100.0)
         M, C = cfg.map_cells, 4 + cfg.num_sem_categories
         maps_ref = torch.zeros(C, M, M)
         maps_mine = torch.zeros(C, M, M)
@@ -83,4 +100,6 @@ def _generate(report, cfg, seqs, fname):
                                        stairs_frames=[i for i, s in enumerate(stairs) if s])
         print(f"[mapping] {name}: {n} frames, restatement bit-identical, final nnz {idx.size}, "
               f"stairs branch taken in frames {[i for i, s in enumerate(stairs) if s]}")
-    np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    if fname:
+        np.savez_compressed(os.path.join(GOLDEN, fname), **out)
+    return out

@@ -199,7 +199,7 @@ def forward(obs: torch.Tensor, pose_obs: torch.Tensor, maps_last: torch.Tensor, 
     ncat = cfg.num_sem_categories
     coords = point_cloud_std(obs[:, 3, :, :], cfg)
     feat = torch.ones(1, 1 + ncat, (h // cfg.du_scale) * (w // cfg.du_scale))
-    feat[:, 1:, :] = obs[:, 4:, :, :].reshape(bs, c - 4, -1)          # AvgPool2d(1) == identity
+    feat[:, 1:, :] = torch.nn.AvgPool2d(cfg.du_scale)(obs[:, 4:, :, :]).reshape(bs, c - 4, -1)     # mapping.py:80-82
     mask = stairs_mask(coords, feat)
     coords[:, :, mask] = 99999
     vr, zb = cfg.vision_range, cfg.z_bins

@@ -70,6 +70,7 @@ SIGNATURES = {
     "peanut_last_conv_kernel": (C.c_char_p, []),
     "peanut_abi_version": (C.c_int, []),
     "peanut_build_arch": (C.c_char_p, []),
+    "peanut_source_hash": (C.c_char_p, []),
     "peanut_pred_create": (C.c_int, [C.POINTER(_P), C.POINTER(PredCfgC), C.POINTER(TensorC), C.c_int]),
     "peanut_pred_destroy": (None, [_P]),
     "peanut_pred_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "peanut_goal_reset": (C.c_int, [_P]),
     "peanut_goal_rounds": (C.c_int, [_P]),
     "peanut_goal_passes": (C.c_int, [_P]),
+    "peanut_goal_converged": (C.c_int, [_P]),
     "peanut_goal_traversible": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "peanut_fmm_distance": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_goal_select": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int * 4), C.c_int, C.c_int, _P, C.c_double, C.c_int,
@@ -138,13 +140,30 @@ def lib_path() -> str:
     return os.environ.get("PEANUT_HIP_LIB", _build.LIB_PATH)
 
 
+def _stale_reason(lib, path) -> str:
+    """'' when the loaded in-tree library was built from the csrc/ + include/ sources lying next to it (content hash,
+    not file times), else what differs.  A library given through PEANUT_HIP_LIB is taken as it is."""
+    if path != _build.LIB_PATH or not os.path.isdir(_build.CSRC):
+        return ""
+    have = (lib.peanut_source_hash() or b"").decode()
+    want = _build.source_hash()
+    return "" if have == want else f"built from sources {have or '<unknown>'}, the tree holds {want}"
+
+
 def load() -> C.CDLL:
-    """dlopen libpeanut_hip.so and attach signatures; raises PeanutHipError if it is absent."""
+    """dlopen libpeanut_hip.so and attach signatures; raises PeanutHipError if it is absent, exports the wrong ABI, or is
+    stale with respect to the sources next to it and cannot be rebuilt."""
     global _LIB
     with _LOCK:
         if _LIB is not None:
             return _LIB
         path = lib_path()
+        if path == _build.LIB_PATH and os.path.exists(path) and os.path.isdir(_build.CSRC) and _build._built_hash() and \
+                _build._built_hash() != _build.source_hash():
+            try:                                   # sources edited since the last build: rebuild before the first dlopen
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                raise PeanutHipError(f"{path} is stale (csrc/ changed since it was built) and rebuilding failed: {e}") from e
         if not os.path.exists(path):
             raise PeanutHipError(
                 f"HIP extension not built: {path} is missing. Build it with "
@@ -165,6 +184,10 @@ def load() -> C.CDLL:
         if got != ABI_VERSION:
             raise PeanutHipError(f"{path} implements ABI version {got}, this package binds version {ABI_VERSION}: "
                                  "rebuild the extension (python -m peanut_amd.build --force)")
+        why = _stale_reason(lib, path)
+        if why:
+            raise PeanutHipError(f"{path} is stale: {why}.  Rebuild it (python -m peanut_amd.build --force); a stale kernel "
+                                 "library must not answer for the sources next to it")
         _LIB = lib
         return lib
 

@@ -28,11 +28,38 @@ def _deps() -> List[str]:
     return sources() + hdrs + [os.path.abspath(__file__)]
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the names and contents of every source and header the library is built from.
+    Compiled into the library (peanut_source_hash()): the binding refuses -- or rebuilds -- a library whose sources have
+    changed since it was built, whatever the file times say (a repo snapshot copied to another box keeps no useful
+    mtimes)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    files += sorted(os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h"))
+    for p in files:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def _built_hash() -> str:
+    try:
+        with open(LIB_PATH + ".srchash") as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
+    if _built_hash() != source_hash():
+        return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    return os.path.getmtime(os.path.abspath(__file__)) > t
 
 
 def hipcc() -> str:
@@ -49,14 +76,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
+    src_hash = source_hash()
     common = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
               "-Wall", "-Wno-unused-function"]
+    stamp = os.path.join(objdir, "srchash")          # objects are reused only while they were built from these very sources
+    try:
+        with open(stamp) as fh:
+            reuse = fh.read().strip() == src_hash
+    except OSError:
+        reuse = False
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or any(os.path.getmtime(p) > os.path.getmtime(obj) for p in _deps()):
-            cmd = common + ["-c", src, "-o", obj]
+        if force or not reuse or not os.path.exists(obj):
+            cmd = common + ([f'-DPEANUT_SOURCE_HASH="{src_hash}"'] if os.path.basename(src) == "pred_api.hip" else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -72,6 +106,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
     os.replace(tmp, LIB_PATH)
+    for path in (stamp, LIB_PATH + ".srchash"):
+        with open(path, "w") as fh:
+            fh.write(src_hash + "\n")
     return LIB_PATH
 
 

@@ -98,8 +98,10 @@ struct AxisTerm { double a, b, c, v1; };
 __device__ __forceinline__ AxisTerm axis_term(double m1, double m2, double p1, double p2) {
   AxisTerm t{0.0, 0.0, 0.0, INFINITY};
   double v1 = INFINITY, v2 = INFINITY;
-  if (m1 < v1) { v1 = m1; v2 = (m2 < v1) ? m2 : INFINITY; }      // j = -1 first; j = +1 only when strictly closer
-  if (p1 < v1) { v1 = p1; v2 = (p2 < v1) ? p2 : INFINITY; }
+  // j = -1 first; j = +1 only when strictly closer; the second neighbour when it is not farther than the first (<=),
+  // and -- like the library's loop -- a v2 from j = -1 survives a j = +1 that brings none of its own
+  if (m1 < v1) { v1 = m1; if (m2 <= v1) v2 = m2; }
+  if (p1 < v1) { v1 = p1; if (p2 <= v1) v2 = p2; }
   t.v1 = v1;
   if (v2 < INFINITY) {
     const double aa = 9.0 / 4.0, tp = (1.0 / 3.0) * (4.0 * v1 - v2);
@@ -138,8 +140,8 @@ __device__ __forceinline__ double update_cell(const AxisTerm& y, const AxisTerm&
 struct AxisPick { double v1, v2; };      // nearest upwind value and the one behind it (INFINITY: none)
 __device__ __forceinline__ AxisPick axis_pick(double m1, double m2, double p1, double p2) {
   AxisPick t{INFINITY, INFINITY};
-  if (m1 < t.v1) { t.v1 = m1; t.v2 = (m2 < t.v1) ? m2 : INFINITY; }      // j = -1 first; j = +1 only when strictly closer
-  if (p1 < t.v1) { t.v1 = p1; t.v2 = (p2 < t.v1) ? p2 : INFINITY; }
+  if (m1 < t.v1) { t.v1 = m1; if (m2 <= t.v1) t.v2 = m2; }      // as axis_term
+  if (p1 < t.v1) { t.v1 = p1; if (p2 <= t.v1) t.v2 = p2; }
   return t;
 }
 __device__ __forceinline__ double update_cell_local(const AxisPick& y, const AxisPick& x) {
@@ -216,8 +218,9 @@ __global__ __launch_bounds__(1024) void fmm_round_kernel(double* __restrict__ di
     const double oi = o[ly][lx];
     const double oym = o[ly - 1][lx], oyp = o[ly + 1][lx], oxm = o[ly][lx - 1], oxp = o[ly][lx + 1];
     feed |= (oym < oi ? 1u : 0u) | (oyp < oi ? 2u : 0u) | (oxm < oi ? 4u : 0u) | (oxp < oi ? 8u : 0u);
-    feed |= (o[ly - 2][lx] < oym ? 16u : 0u) | (o[ly + 2][lx] < oyp ? 32u : 0u) | (o[ly][lx - 2] < oxm ? 64u : 0u) |
-            (o[ly][lx + 2] < oxp ? 128u : 0u);
+    // (<=: two equal seeds in line feed the cell next to them; the graph stays acyclic, the first step is strict)
+    feed |= (o[ly - 2][lx] <= oym ? 16u : 0u) | (o[ly + 2][lx] <= oyp ? 32u : 0u) | (o[ly][lx - 2] <= oxm ? 64u : 0u) |
+            (o[ly][lx + 2] <= oxp ? 128u : 0u);
   } else {
     feed |= 0xfu;
   }
@@ -377,6 +380,7 @@ struct peanut_goal {
   bool have_last = false;
   int last_lw = 0, last_lh = 0;
   int last_rounds = 0, last_passes = 0;
+  bool last_converged = true;      // false: the ordering passes hit MAX_ORDER_PASSES with the last one still changing tiles
   int round_hint[1 + 8] = {0};     // rounds each stage needed in the previous solve (run_stage)
 };
 
@@ -442,6 +446,7 @@ int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* 
   if (int rc = run_stage<false>(g, 0, &cur, &rounds, &changed, s)) return rc;
   // stage B: second order on the graph ordered by the previous field, until a pass changes nothing
   g->last_passes = 0;
+  g->last_converged = false;
   for (int pass = 0; pass < MAX_ORDER_PASSES; ++pass) {
     PEANUT_HIP_CHECK(hipMemcpyAsync(g->order.p, g->dist.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (pass == 0) {      // from the seeds again
@@ -454,7 +459,7 @@ int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* 
     }
     if (int rc = run_stage<true>(g, 1 + pass, &cur, &rounds, &changed, s)) return rc;
     g->last_passes = pass + 1;
-    if (pass > 0 && changed == 0) break;
+    if (pass > 0 && changed == 0) { g->last_converged = true; break; }
   }
   g->last_rounds = rounds;
   hipError_t e = hipGetLastError();
@@ -494,6 +499,7 @@ int peanut_goal_reset(peanut_goal_t* g) {
 
 int peanut_goal_rounds(peanut_goal_t* g) { return g ? g->last_rounds : PEANUT_EINVAL; }
 int peanut_goal_passes(peanut_goal_t* g) { return g ? g->last_passes : PEANUT_EINVAL; }
+int peanut_goal_converged(peanut_goal_t* g) { return g ? (g->last_converged ? 1 : 0) : PEANUT_EINVAL; }
 
 int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint8_t* goal_mask, int goal_r, int goal_c, int fill_mode,
                         double* dist_out, void* stream) {

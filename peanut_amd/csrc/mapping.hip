@@ -48,7 +48,8 @@ namespace {
 constexpr unsigned INVALID_KEY = 1u << 20;   // > 100*100*80; keys are sorted on 21 bits
 
 struct MapP {
-  int h, w, N, ncat, F, C;       // frame, points, semantic channels, feature rows (1+ncat), map channels (4+ncat)
+  int h, w, N, ncat, F, C;       // point grid (frame / du_scale), points, semantic channels, feature rows (1+ncat), map channels (4+ncat)
+  int du, fh, fw;                // du_scale and the full frame size (mapping.py:23,49,60,80)
   int vr, zb, M;                 // vision range (cells), z bins, local map size (cells)
   float xc, zc, f;               // camera matrix (depth_utils.py:27-34)
   float agent_h, shift_x;        // 88 cm, 250 cm
@@ -96,6 +97,26 @@ __device__ __forceinline__ bool stairs_branch(const StairStats& s) {
 }
 
 // ---- 1. depth -> normalised coordinates (mapping.py:59-88) + stairs statistics ----
+// ---- 0. du_scale > 1 (mapping.py:60,80-82): depth sub-sampled [::s, ::s], semantic channels AvgPool2d(s) -> an observation
+//         of (h / s) x (w / s) points in the layout the other kernels read (RGB channels are not used by the mapping) ----
+__global__ __launch_bounds__(256) void map_decimate_kernel(const float* __restrict__ obs, float* __restrict__ dec, MapP P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ch = 3 + blockIdx.y;                       // depth, then the semantic channels
+  if (p >= P.N) return;
+  const int r = p / P.w, c = p - r * P.w;
+  const float* src = obs + (size_t)ch * P.fh * P.fw;
+  float v;
+  if (ch == 3) {
+    v = src[(size_t)(r * P.du) * P.fw + c * P.du];
+  } else {                                             // ATen's avg_pool2d: window summed row by row, then divided
+    float sum = 0.0f;
+    for (int i = 0; i < P.du; ++i)
+      for (int j = 0; j < P.du; ++j) sum += src[(size_t)(r * P.du + i) * P.fw + c * P.du + j];
+    v = sum / (float)(P.du * P.du);
+  }
+  dec[(size_t)ch * P.N + p] = v;
+}
+
 __global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict__ obs, float* __restrict__ coords,
                                                          StairStats* __restrict__ stats, MapP P) {
   __shared__ unsigned s_n, s_mid, s_le, s_max, s_min;
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(256) void map_points_kernel(const float* __restrict
   if (p < P.N) {
     const int r = p / P.w, c = p - r * P.w;
     const float d = obs[3 * P.N + p];
-    const float gx = (float)c, gz = (float)(P.h - 1 - r);
+    const float gx = (float)(c * P.du), gz = (float)(P.fh - 1 - r * P.du);     // grid_x / grid_z [::scale, ::scale]
     float X = ((gx - P.xc) * d) / P.f;          // get_point_cloud_from_z_t
     float Z = ((gz - P.zc) * d) / P.f;
     float Y = d;
@@ -312,9 +333,13 @@ __device__ __forceinline__ void map_pose(const float* __restrict__ rel, float* _
   const float k = 57.29577951308232f;
   float p0 = pose[0], p1 = pose[1], p2 = pose[2];
   const float r0 = rel[0], r1 = rel[1], r2 = rel[2];
+  // sin / cos of a float32 argument, evaluated in double and rounded once: the correctly rounded float32 value, which is
+  // what ATen's CPU kernels (SLEEF, <= 1 ulp) return in all but rare cases; the device's sinf / cosf are 1-2 ulp off more
+  // often, and the warp's grid_sample amplifies a last-bit difference of the rotation into ~3e-5 on map cells
   const float ang = p2 / k;
-  p1 = p1 + (r0 * sinf(ang) + r1 * cosf(ang));
-  p0 = p0 + (r0 * cosf(ang) - r1 * sinf(ang));
+  const float sa = (float)sin((double)ang), ca = (float)cos((double)ang);
+  p1 = p1 + (r0 * sa + r1 * ca);
+  p0 = p0 + (r0 * ca - r1 * sa);
   p2 = p2 + r2 * k;
   p2 = fmodf(p2 - 180.0f, 360.0f) + 180.0f;
   p2 = fmodf(p2 + 180.0f, 360.0f) - 180.0f;
@@ -323,8 +348,8 @@ __device__ __forceinline__ void map_pose(const float* __restrict__ rel, float* _
   const float sy = (-(((p1 * 100.0f) / P.res) - P.half_cells)) / P.half_cells;
   const float st2 = 90.0f - p2;
   const float tr = (st2 * 3.14159265358979323846f) / 180.0f;
-  wt->c = cosf(tr);
-  wt->s = sinf(tr);
+  wt->c = (float)cos((double)tr);
+  wt->s = (float)sin((double)tr);
   wt->tx = sx;
   wt->ty = sy;
 }
@@ -453,6 +478,7 @@ struct peanut_map {
   float* feat_s = nullptr;   // [ncat][N]
   float* proj = nullptr;     // [2][F][vr][vr]
   float* view = nullptr;     // [C][vr][vr]
+  float* obs_dec = nullptr;  // [C][N]: the observation at du_scale > 1 (map_decimate_kernel)
   WarpT* wt = nullptr;
   bool use_graph = false;    // peanut_map_use_graph: the launches of a step replayed as one hipGraph
   GraphCache graphs;
@@ -460,7 +486,7 @@ struct peanut_map {
     graphs.clear();
     for (void* p : {(void*)coords, (void*)pos, (void*)keys, (void*)seg, (void*)skeys, (void*)sidx, (void*)cell_head,
                     (void*)cell_cnt, (void*)cell_first, (void*)cell_fill, (void*)cursor,
-                    (void*)stats, (void*)wts6, (void*)feat_s, (void*)proj, (void*)view, (void*)wt})
+                    (void*)stats, (void*)wts6, (void*)feat_s, (void*)proj, (void*)view, (void*)obs_dec, (void*)wt})
       if (p) (void)hipFree(p);
   }
 };
@@ -469,14 +495,16 @@ extern "C" {
 
 int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
   if (!out || !c) return fail(PEANUT_EINVAL, "peanut_map_create: null argument");
-  if (c->du_scale != 1) return fail(PEANUT_EINVAL, "peanut_map_create: only du_scale == 1 is supported");
+  if (c->du_scale < 1 || c->du_scale > 8 || c->frame_height % c->du_scale || c->frame_width % c->du_scale)
+    return fail(PEANUT_EINVAL, "peanut_map_create: du_scale must be 1..8 and divide the frame size");
   if (c->frame_height < 2 || c->frame_width < 2 || c->num_sem_categories < 5 || c->num_sem_categories > 28 ||
       c->map_resolution < 1 || c->vision_range < 2 || c->global_downscaling < 1)
     return fail(PEANUT_EINVAL, "peanut_map_create: unsupported configuration");
   auto h = std::make_unique<peanut_map>();
   h->cfg = *c;
   MapP& P = h->P;
-  P.h = c->frame_height; P.w = c->frame_width; P.N = P.h * P.w;
+  P.du = c->du_scale; P.fh = c->frame_height; P.fw = c->frame_width;
+  P.h = P.fh / P.du; P.w = P.fw / P.du; P.N = P.h * P.w;
   P.ncat = c->num_sem_categories; P.F = 1 + P.ncat; P.C = 4 + P.ncat;
   P.vr = c->vision_range;
   const int res = c->map_resolution;
@@ -487,9 +515,9 @@ int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
   if ((long long)P.vr * P.vr * P.zb >= (long long)INVALID_KEY)
     return fail(PEANUT_EINVAL, "peanut_map_create: voxel grid too large for 20-bit keys");
   // camera matrix in double like numpy, then to fp32 as torch does for python scalars
-  P.xc = (float)((P.w - 1.0) / 2.0);
-  P.zc = (float)((P.h - 1.0) / 2.0);
-  P.f = (float)((P.w / 2.0) / tan(c->hfov / 2.0 * 3.14159265358979323846 / 180.0));   // np.deg2rad(x) = x * pi / 180
+  P.xc = (float)((P.fw - 1.0) / 2.0);
+  P.zc = (float)((P.fh - 1.0) / 2.0);
+  P.f = (float)((P.fw / 2.0) / tan(c->hfov / 2.0 * 3.14159265358979323846 / 180.0));   // np.deg2rad(x) = x * pi / 180
   P.agent_h = (float)(c->camera_height * 100.0);
   P.shift_x = (float)(P.vr * res / 2);
   P.res = (float)res;
@@ -537,6 +565,7 @@ int peanut_map_create(peanut_map_t** out, const peanut_map_cfg* c) {
   PEANUT_HIP_CHECK(hipMemset(h->proj, 0, 2 * P.F * cells * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->view, P.C * cells * sizeof(float)));
   PEANUT_HIP_CHECK(hipMalloc(&h->wt, sizeof(WarpT)));
+  if (P.du > 1) PEANUT_HIP_CHECK(hipMalloc(&h->obs_dec, (size_t)P.C * N * sizeof(float)));
   PEANUT_HIP_CHECK(hipDeviceSynchronize());
   *out = h.release();
   return 0;
@@ -556,9 +585,15 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
     return fail(PEANUT_EINVAL, "peanut_map_forward: null argument");
   if (maps_last == map_pred) return fail(PEANUT_EINVAL, "peanut_map_forward: map_pred must not alias maps_last");
   hipStream_t s = (hipStream_t)stream;
+  const float* obs_full = obs;
   auto enqueue = [&]() -> int {
     const MapP& P = h->P;
     const int nb = (P.N + 255) / 256;
+    const float* obs = obs_full;
+    if (P.du > 1) {
+      hipLaunchKernelGGL(map_decimate_kernel, dim3(nb, 1 + P.ncat), dim3(256), 0, s, obs_full, h->obs_dec, P);
+      obs = h->obs_dec;
+    }
     hipLaunchKernelGGL(map_points_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, P);
     hipLaunchKernelGGL(map_keys_kernel, dim3(nb), dim3(256), 0, s, obs, h->coords, h->stats, h->pos, h->keys, h->cell_cnt,
                        h->cell_first, P);

@@ -551,6 +551,10 @@ const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
 int peanut_abi_version(void) { return 8; }
 const char* peanut_build_arch(void) { return "gfx950"; }
+#ifndef PEANUT_SOURCE_HASH
+#define PEANUT_SOURCE_HASH ""
+#endif
+const char* peanut_source_hash(void) { return PEANUT_SOURCE_HASH; }
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
   if (!out || !cfg || (!tensors && n > 0)) return fail(PEANUT_EINVAL, "peanut_pred_create: null argument");

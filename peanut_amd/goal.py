@@ -54,6 +54,11 @@ class GeodesicSolver:
     def passes(self) -> int:
         return int(self._lib.peanut_goal_passes(self._h))
 
+    @property
+    def converged(self) -> bool:
+        """False when the last solve stopped at the ordering-pass cap with its last pass still changing tiles."""
+        return bool(self._lib.peanut_goal_converged(self._h))
+
     def reset(self):
         _lib.check(self._lib.peanut_goal_reset(self._h), "peanut_goal_reset")
 

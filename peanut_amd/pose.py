@@ -1,4 +1,5 @@
-"""Pose helpers of the reference (nav/agent/utils/pose.py:4-42), host-side NumPy like the original.
+"""The pose helpers of the reference that the per-step path uses (nav/agent/utils/pose.py:4-21: `get_l2_distance`,
+`get_rel_pose_change`; the planner-side `get_new_pose` / `threshold_poses` are not part of it), host-side NumPy like the original.
 
 Arithmetic note: Habitat hands over ``gps`` / ``compass`` as float32 arrays and the reference's environment is
 NumPy 1.x, where ``float32 scalar ** 2`` (scalar with a Python number) is evaluated in float64 and
@@ -27,27 +28,6 @@ def get_rel_pose_change(pos2, pos1):
     dy = dist * np.sin(theta)
     do = o2 - o1
     return dx, dy, do
-
-
-def get_new_pose(pose, rel_pose_change):
-    """pose.py:24-36 (angles of ``pose`` in degrees, of the change in radians)."""
-    x, y, o = pose
-    dx, dy, do = rel_pose_change
-    global_dx = dx * np.sin(np.deg2rad(o)) + dy * np.cos(np.deg2rad(o))
-    global_dy = dx * np.cos(np.deg2rad(o)) - dy * np.sin(np.deg2rad(o))
-    x += global_dy
-    y += global_dx
-    o += np.rad2deg(do)
-    if o > 180.:
-        o -= 360.
-    return x, y, o
-
-
-def threshold_poses(coords, shape):
-    """pose.py:39-42."""
-    coords[0] = min(max(0, coords[0]), shape[0] - 1)
-    coords[1] = min(max(0, coords[1]), shape[1] - 1)
-    return coords
 
 
 class PoseTracker:

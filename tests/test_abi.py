@@ -116,3 +116,15 @@ def test_bench_refuses_more_gpus_than_visible():
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+def test_library_carries_the_hash_of_its_sources(monkeypatch):
+    """The library answers for the csrc/ + include/ sources next to it: it embeds their content hash, and the binding
+    refuses a library whose hash differs (file times do not survive the copy to the GPU box, contents do)."""
+    build.build()
+    lib = _lib.load()
+    assert lib.peanut_source_hash().decode() == build.source_hash()
+    assert not build.is_stale()
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 16)          # "the sources changed"
+    assert _lib._stale_reason(lib, build.LIB_PATH)
+    assert _lib._stale_reason(lib, "/elsewhere/libpeanut_hip.so") == ""   # a library given by path is taken as it is

@@ -77,3 +77,23 @@ def test_goal_restatement_matches_reference_golden(golden_dir):
     assert (w_far * 1.0 > w_near * 0.9) == (tuple(int(v) for v in g[0]) == (5, 28))
     g2 = sel.update(obst, (16, 48, 16, 48), (16, 2), tp, zero, zero)          # same argmax again: goal list unchanged
     assert g2 == g
+
+
+def test_adjacent_equal_seeds_use_the_second_order_term():
+    """updatePointOrderTwo admits the second upwind neighbour when it is NOT FARTHER than the first (`<=`): next to two
+    adjacent seeds the cell in line with them solves (9/4) u^2 = 1 -> 2/3, where a lone seed gives the first-order 1.
+    (FMMPlanner.set_multi_goal's goal blobs, fmm_planner.py:67-75; the region feeds get_short_term_goal's stop test.)"""
+    t = ma.masked_values(np.ones((9, 21)), 0)
+    t[4, 9] = 0
+    t[4, 10] = 0                                      # two seeds side by side in a row
+    d = fmm_ref.distance(t, dx=1)
+    assert d[4, 9] == 0 and d[4, 10] == 0
+    assert abs(d[4, 11] - 2.0 / 3.0) < 1e-12 and abs(d[4, 8] - 2.0 / 3.0) < 1e-12     # in line with the pair
+    assert abs(d[3, 9] - 1.0) < 1e-12 and abs(d[5, 10] - 1.0) < 1e-12                 # across the pair: one seed per axis
+    lone = ma.masked_values(np.ones((9, 21)), 0)
+    lone[4, 9] = 0
+    dl = fmm_ref.distance(lone, dx=1)
+    assert abs(dl[4, 10] - 1.0) < 1e-12 and abs(dl[4, 8] - 1.0) < 1e-12 and abs(dl[3, 9] - 1.0) < 1e-12
+    # mirror symmetry about the pair (column c <-> 19 - c) holds to a few hundredths of a cell only: the j = -1 direction is
+    # examined first and its value2 survives (the library's loop), and equal keys leave the heap in insertion order
+    assert np.abs(d[:, 0:9] - d[:, 19:10:-1]).max() < 0.05

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 from peanut_amd import episodes as E
-from peanut_amd.pose import PoseTracker, get_new_pose, get_rel_pose_change, threshold_poses
+from peanut_amd.pose import PoseTracker, get_rel_pose_change
 
 
 def _run(gps, compass):
@@ -36,9 +36,6 @@ def test_pose_change_float32_readings(golden_dir):
 def test_pose_helpers():
     dx, dy, do = get_rel_pose_change((1.0, 1.0, 0.5), (0.0, 0.0, 0.0))
     assert abs(dx - 1.0) < 1e-12 and abs(dy - 1.0) < 1e-12 and do == 0.5
-    x, y, o = get_new_pose((1.0, 2.0, 170.0), (0.5, 0.0, np.deg2rad(20.0)))
-    assert abs(o - (-170.0)) < 1e-9
-    assert threshold_poses([-3, 500], (480, 480)) == [0, 479]
 
 
 def test_recorded_episode_roundtrip(tmp_path):

@@ -68,7 +68,7 @@ def _nhwc(t):
 @pytest.fixture(scope="module")
 def small_net():
     from oracle import rcnn_ref
-    from peanut_amd.rcnn import MaskRCNN
+    from rcnn_glue import GlueMaskRCNN as MaskRCNN      # the product class + the torch-glue stage methods (tests/rcnn_glue.py)
     from peanut_amd.rcnn_weights import make_seeded_rcnn_state_dict, resized_hw
     cfg = _small_cfg()
     sd = make_seeded_rcnn_state_dict(cfg, seed=7)
@@ -97,7 +97,8 @@ def test_nms_bit_exact():
 
 def test_roi_align_matches_restatement():
     from oracle import rcnn_ref
-    from peanut_amd.rcnn import assign_levels, roi_align_pyramid
+    from peanut_amd.rcnn import roi_align_pyramid
+    from rcnn_glue import assign_levels
     g = torch.Generator().manual_seed(3)
     B, Cc = 2, 32
     pyr = {f"p{l + 2}": torch.randn((B, Cc, 64 >> l, 80 >> l), generator=g) for l in range(4)}
@@ -341,7 +342,8 @@ def test_c_entry_matches_the_stagewise_glue(small_net):
 def test_nms_kernel_matches_published_iou_known_answers():
     """peanut_nms on detectron2's test_pairwise_iou boxes (tests/structures/test_boxes.py) and torchvision's
     test_nms_float16 boxes (test/test_ops.py): the same decisions as the published values imply."""
-    from peanut_amd.rcnn import batched_nms, nms_keep
+    from peanut_amd.rcnn import nms_keep
+    from rcnn_glue import batched_nms
     unit = [0.0, 0.0, 1.0, 1.0]
     others = [[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 1.0], [0.0, 0.0, 1.0, 0.5], [0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 1.0, 1.0],
               [0.5, 0.5, 1.5, 1.5]]
