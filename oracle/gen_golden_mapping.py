@@ -81,8 +81,8 @@ def _generate(report, cfg, seqs, fname):
             poses.append(pose_ref.numpy().copy())
             fps.append(np.packbits(fp_r.numpy().astype(bool)))
             coords = mapping_ref.point_cloud_std(obs[:, 3], cfg)
-            feat = torch.ones(1, 1 + cfg.num_sem_categories, obs.shape[2] * obs.shape[3])
-            feat[:, 1:] = obs[:, 4:].reshape(1, cfg.num_sem_categories, -1)
+            feat = torch.ones(1, 1 + cfg.num_sem_categories, (obs.shape[2] // cfg.du_scale) * (obs.shape[3] // cfg.du_scale))
+            feat[:, 1:] = torch.nn.AvgPool2d(cfg.du_scale)(obs[:, 4:]).reshape(1, cfg.num_sem_categories, -1)
             stairs.append(bool(mapping_ref.stairs_mask(coords, feat).any()))
         final = maps_ref.numpy()
         idx = np.flatnonzero(final)

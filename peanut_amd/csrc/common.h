@@ -37,7 +37,7 @@ struct ConvDesc {
   const float* shift;      // device [cout_pad]
   // emulated-fp32 modes (bf16x6 / bf16x3), pointwise layers only: the layer runs on gemm_rs.hip -- fp32 activations split
   // into bf16 pieces in registers, the weights' pieces pre-split in w_s
-  int rs;                  // 1: run on gemm_rs.hip
+  int rs;                  // 1: pointwise layer on gemm_rs.hip; 2: any other conv on conv_rs.hip (k-tile = 16 channels of one tap)
   const void* w_s;         // device: pre-split weights [n-tile][k-tile of 16][plane][bn_tile][16 bf16] (pack_weights_sx), or null
   int s_planes;            // bf16 pieces per value: 2 (bf16x3: three products) or 3 (bf16x6: six products)
 };
@@ -93,6 +93,9 @@ const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_
 // the weights' bf16 pieces, packed per (n-tile of bn_tile rows, k-tile of 16 channels, plane)
 size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
 void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
+// conv_rs.hip: the same for a kh x kw layer, k-tiles ordered channel chunk outer / filter tap inner
+size_t sx_conv_packed_bytes(int cin_pad, int cout, int kh, int kw, int bn_tile, int planes);
+void pack_weights_sx_conv(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile, int planes, void* out);
 
 // ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----
 int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s);

@@ -58,6 +58,8 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
 // gemm_rs.hip: pointwise layer / grouped GEMM emulated on the bf16 matrix cores: fp32 A (p.x, p.x2) split into bf16 pieces in
 // registers, p.w = the weights' pre-split pieces, nkt = cin / 16
 int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
+// conv_rs.hip: every other conv in the emulated-fp32 modes (implicit GEMM, p.w = pack_weights_sx_conv weights, nkt = cin / 16 * taps)
+int launch_conv_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);
 
 
 // Work decomposition of one launch.

@@ -345,7 +345,8 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   if (d.rs) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
     if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");
     p.w = static_cast<const float*>(d.w_s);
-    p.nkt = d.cin / 16;
+    p.nkt = (d.cin / 16) * p.ntaps;
+    if (d.rs == 2) return launch_conv_rs(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
     return launch_gemm_rs(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
   }
   if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c1 % 32 == 0 && p.c2 % 32 == 0 && (p.c2 == 0 || p.stride == 1) && conv_pw_enabled())

@@ -98,10 +98,13 @@ struct AxisTerm { double a, b, c, v1; };
 __device__ __forceinline__ AxisTerm axis_term(double m1, double m2, double p1, double p2) {
   AxisTerm t{0.0, 0.0, 0.0, INFINITY};
   double v1 = INFINITY, v2 = INFINITY;
-  // j = -1 first; j = +1 only when strictly closer; the second neighbour when it is not farther than the first (<=),
-  // and -- like the library's loop -- a v2 from j = -1 survives a j = +1 that brings none of its own
-  if (m1 < v1) { v1 = m1; if (m2 <= v1) v2 = m2; }
-  if (p1 < v1) { v1 = p1; if (p2 <= v1) v2 = p2; }
+  // j = -1 first; j = +1 only when strictly closer; the second neighbour when it is not farther than the first (<=).
+  // The library's loop leaves a v2 found in the j = -1 direction in place when j = +1 then supplies the closer v1 without
+  // a qualifying second neighbour (oracle/fmm_ref.c keeps that); here v2 always belongs to v1's own side: the mixed pair
+  // (v1 from one side, v2 from the other) only arises where two fronts meet, is not an upwind difference, and with it the
+  // ordering passes of this solver stop reaching a fixed point (measured: profiles/r3f)
+  if (m1 < v1) { v1 = m1; v2 = (m2 <= v1) ? m2 : INFINITY; }
+  if (p1 < v1) { v1 = p1; v2 = (p2 <= v1) ? p2 : INFINITY; }
   t.v1 = v1;
   if (v2 < INFINITY) {
     const double aa = 9.0 / 4.0, tp = (1.0 / 3.0) * (4.0 * v1 - v2);
@@ -140,8 +143,8 @@ __device__ __forceinline__ double update_cell(const AxisTerm& y, const AxisTerm&
 struct AxisPick { double v1, v2; };      // nearest upwind value and the one behind it (INFINITY: none)
 __device__ __forceinline__ AxisPick axis_pick(double m1, double m2, double p1, double p2) {
   AxisPick t{INFINITY, INFINITY};
-  if (m1 < t.v1) { t.v1 = m1; if (m2 <= t.v1) t.v2 = m2; }      // as axis_term
-  if (p1 < t.v1) { t.v1 = p1; if (p2 <= t.v1) t.v2 = p2; }
+  if (m1 < t.v1) { t.v1 = m1; t.v2 = (m2 <= t.v1) ? m2 : INFINITY; }      // as axis_term
+  if (p1 < t.v1) { t.v1 = p1; t.v2 = (p2 <= t.v1) ? p2 : INFINITY; }
   return t;
 }
 __device__ __forceinline__ double update_cell_local(const AxisPick& y, const AxisPick& x) {

@@ -100,6 +100,11 @@ struct ConvLayer {
 
 // bf16 pieces per value in the emulated-fp32 modes (gemm_rs.hip; 0: fp32 MFMA mode)
 inline int rs_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : 0); }
+// PEANUT_RS_CONV=0 keeps the non-pointwise layers of the emulated modes on the fp32 MFMA kernel (A/B measurements)
+inline bool rs_conv_enabled() {
+  static const bool on = [] { const char* e = getenv("PEANUT_RS_CONV"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // n-tile of a pointwise layer's pre-split weights in the emulated-fp32 modes (0: the layer stays on the fp32 kernel)
 inline int rs_bn_tile(int cin_pad, int cout, int kh, int kw, int pad) {
   if (kh != 1 || kw != 1 || pad != 0 || cin_pad % 16 != 0 || cout < 64) return 0;
@@ -121,6 +126,10 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
     d.rs = 1;
     d.s_planes = rs_planes_of(precision);
     d.bn_tile = rs_bn_tile(cin_pad, cout, kh, kw, pad);
+  } else if (rs_planes_of(precision) && rs_conv_enabled() && (kh > 1 || kw > 1) && cin_pad % 16 == 0) {
+    d.rs = 2;                                                   // conv_rs.hip
+    d.s_planes = rs_planes_of(precision);
+    d.bn_tile = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
   }
   d.cout_pad = (cout + d.bn_tile - 1) / d.bn_tile * d.bn_tile;
   L.cin_real = cin;
@@ -142,8 +151,10 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.shift = (const float*)L.ss.p + d.cout_pad;
   d.w_s = nullptr;
   if (d.rs) {
-    std::vector<unsigned char> ps(sx_packed_bytes(cin_pad, cout, d.bn_tile, d.s_planes));
-    pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, ps.data());
+    std::vector<unsigned char> ps(d.rs == 2 ? sx_conv_packed_bytes(cin_pad, cout, kh, kw, d.bn_tile, d.s_planes)
+                                            : sx_packed_bytes(cin_pad, cout, d.bn_tile, d.s_planes));
+    if (d.rs == 2) pack_weights_sx_conv(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.s_planes, ps.data());
+    else pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, ps.data());
     if ((rc = L.w_s.ensure(ps.size()))) return rc;
     PEANUT_HIP_CHECK(hipMemcpy(L.w_s.p, ps.data(), ps.size(), hipMemcpyHostToDevice));
     d.w_s = L.w_s.p;

@@ -218,6 +218,7 @@ std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, c
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
 std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long long M = 0, int mt_per_group = 0) {
+  if (d.rs == 2) return std::string(d.s_planes == 3 ? "conv_rs6_128x" : "conv_rs3_128x") + std::to_string(d.bn_tile);
   if (d.rs) return gemm_rs_kernel_name(d.cout, M, mt_per_group, d.bn_tile, d.cin, d.s_planes);
   if (d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
     return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
@@ -263,7 +264,8 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
   op.bytes = (double)in.bytes + (in2 ? (double)in2->bytes : 0.0) + (double)out.bytes + (res ? (double)out.bytes : 0.0) +
-             (L->d.rs ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
+             (L->d.rs == 2 ? (double)sx_conv_packed_bytes(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile, L->d.s_planes)
+              : L->d.rs ? (double)sx_packed_bytes(L->d.cin, L->d.cout, L->d.bn_tile, L->d.s_planes)
                       : (double)conv_packed_floats(L->d.cin, L->d.cout, L->d.kh, L->d.kw, L->d.bn_tile) * 4);
   pl.ops.push_back(op);
 }

@@ -299,7 +299,7 @@ void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
 void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
   ROp op;
   op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = L->d.rs ? std::string(L->d.s_planes == 3 ? "gemm_rs6" : "gemm_rs3")
+  op.kernel = L->d.rs ? std::string(L->d.rs == 2 ? "conv_rs" : "gemm_rs") + (L->d.s_planes == 3 ? "6" : "3")
                       : "conv_igemm_128x" + std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);

@@ -240,21 +240,43 @@ def test_conv_transpose_detecting():
 
 
 @pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
-def test_emulated_modes_leave_non_pointwise_layers_in_fp32(precision):
-    """In the emulated-fp32 modes only pointwise layers (and Winograd position GEMMs) run on the bf16 matrix cores: a 3x3
-    direct conv and a narrow (cout < 64) 1x1 stay exact fp32 -- bit-identical to the fp32 handle -- and the handle says so."""
+@pytest.mark.parametrize("case", [c for c in CASES if c[5] == 3], ids=lambda c: "x".join(map(str, c[:9])))
+def test_register_split_conv_matches_torch(case, precision):
+    """conv_rs.hip: 3x3 (stride 1 / 2, dilation 1 / 2 / 4, 14 -> 16 padded channels, cout 32 / 64 / 128 / 256 / 512) as an
+    implicit GEMM on the bf16 matrix cores with the A fragments split in registers, against F.conv2d."""
+    from peanut_amd.ops import FusedConv, to_nhwc_padded, round_up
+    B, H, W, cin, cout, k, s, p, d, relu, residual = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d) * scale[None, :, None, None] + shift[None, :, None, None]
+    if relu:
+        ref = F.relu(ref)
+    conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, precision=precision, conv_algo="direct")
+    y = conv(to_nhwc_padded(x.cuda(), round_up(cin, 16))).permute(0, 3, 1, 2).cpu()
+    bn = 128 if cout >= 128 else (64 if cout > 32 else 32)
+    assert _last_kernel() == ("conv_rs6_128x" if precision == "bf16x6" else "conv_rs3_128x") + str(bn), _last_kernel()
+    err = (y - ref).abs()
+    assert bool((err <= RS_TOL[precision] * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+def test_emulated_modes_report_what_they_run(precision):
+    """peanut_conv_precision tells which arithmetic a handle really runs: a narrow 1x1 (cout < 64: conv_seg) stays exact
+    fp32 -- bit-identical to the fp32 handle -- in every mode; wider pointwise layers and 3x3 convs report the mode."""
     from peanut_amd import _lib
     from peanut_amd.ops import FusedConv
     g = torch.Generator().manual_seed(3)
-    for (cin, cout, k, pad) in [(64, 64, 3, 1), (512, 6, 1, 0)]:
-        x = _rand((2, 20, 20, cin), g).cuda()
-        w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
-        a = FusedConv(w, None, None, padding=pad, conv_algo="direct")
-        b = FusedConv(w, None, None, padding=pad, precision=precision, conv_algo="direct")
-        assert _lib.load().peanut_conv_precision(b._h) == _lib.PRECISIONS["fp32"]
-        assert torch.equal(a(x), b(x))
-    wide = FusedConv(_rand((128, 64, 1, 1), g, 0.1), None, None, precision=precision)
-    assert _lib.load().peanut_conv_precision(wide._h) == _lib.PRECISIONS[precision]
+    x = _rand((2, 20, 20, 512), g).cuda()
+    w = _rand((6, 512, 1, 1), g, (2.0 / 512) ** 0.5)
+    a, b = FusedConv(w, None, None), FusedConv(w, None, None, precision=precision)
+    assert _lib.load().peanut_conv_precision(b._h) == _lib.PRECISIONS["fp32"]
+    assert torch.equal(a(x), b(x))
+    for shape, pad in (((128, 64, 1, 1), 0), ((64, 64, 3, 3), 1)):
+        c = FusedConv(_rand(shape, g, 0.1), None, None, padding=pad, precision=precision, conv_algo="direct")
+        assert _lib.load().peanut_conv_precision(c._h) == _lib.PRECISIONS[precision]
 
 
 WINO_CASES = [

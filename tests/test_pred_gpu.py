@@ -300,6 +300,43 @@ def test_full_size_batch_properties(model_and_sd):
     assert (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
 
 
+def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
+    """Ten 480 x 480 maps against the ORACLE, at a size where every layer of the headline benchmark that runs on a
+    large-tile kernel does so here too (36 000 rows: conv_pw_uses_256 needs M * cout >= 8.39 M, gemm_rs_uses_256 16.8 M) --
+    asserted by kernel family name per op, so that a change of a gate cannot silently take these kernels out of the
+    oracle's reach again.  fp32: conv_pw_glds256_kernel (layer3 conv1, layer4 conv1, layer4.0 conv3 + downsample, the
+    bottleneck's Winograd GEMM); bf16x6: gemm_rs_kernel<256,256> (layer3.0 / layer4.0 conv3 + downsample, layer4 conv1 /
+    conv3 / Winograd GEMMs, the bottleneck)."""
+    from bench import synth_maps
+    from oracle import pspnet_ref
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    x = synth_maps(10, cfg.in_channels, 480, torch.device("cpu"), seed0=4242)
+    with torch.no_grad():
+        ref = pspnet_ref.forward_batch(sd, x, cfg)
+    xd = x.cuda()
+    want = {
+        "fp32": ("conv_pw_glds_256x128", ["layer3.1.conv1", "layer4.0.conv1", "layer4.0.conv3+downsample", "layer4.2.conv1",
+                                          "bottleneck.conv[x][wino_gemm]"]),
+        "bf16x6": ("gemm_rs6_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
+                                        "layer4.1.conv2[wino_gemm]", "bottleneck.conv[x][wino_gemm]"]),
+    }
+    for precision, (family, layers) in want.items():
+        mm = m if precision == "fp32" else PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
+        got = mm.get_prediction_batch(xd, apply_sigmoid=False).cpu()
+        err = (got - ref).abs().max().item()
+        ops = {name: kern for name, kern, *_ in mm.model.profile(xd)}
+        on_family = [n for n, k in ops.items() if k == family]
+        print(f"{precision}: B=10 480x480 vs oracle max-abs {err:.3e} (|logit| max {ref.abs().max().item():.2f}); "
+              f"{len(on_family)} ops on {family}")
+        assert err <= TOL, f"{precision}: logits max err {err:.3e}"
+        for layer in layers:
+            hit = [n for n in on_family if n.endswith(layer)]
+            assert hit, f"{precision}: {layer} did not run on {family}: {[(n, k) for n, k in ops.items() if n.endswith(layer)]}"
+        if mm is not m:
+            del mm
+
+
 def test_distance_to_the_fp64_reference(golden_dir):
     """How far is each arithmetic mode from the EXACT result?  tests/golden/pspnet_fp64_golden.npz holds the logits of
     the reference's own model files run in float64 (oracle/gen_golden.py: gen_pspnet_fp64); the reference's fp32 CPU
