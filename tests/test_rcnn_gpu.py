@@ -65,6 +65,28 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().cuda()
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x6", 4e-5), ("bf16x3", 2e-3)])
+def test_front_end_in_the_emulated_modes(precision, tol):
+    """The detector's backbone + FPN + RPN head with its 1x1 convs, Winograd GEMMs and direct 3x3 convs on the bf16 matrix
+    cores (gemm_rs.hip / conv_rs.hip): bf16x6 is held to the fp32 path's level (twice its asserted 2e-5, relative to
+    1 + max|ref|, over 104 stacked convs), bf16x3 to 2e-3."""
+    from oracle import rcnn_ref
+    from peanut_amd.rcnn import MaskRCNNFront
+    from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+    cfg = RcnnCfg(depth=50, min_size=160, max_size=300)
+    sd = make_seeded_rcnn_state_dict(cfg, seed=50)
+    img = torch.randint(0, 256, (1, 120, 90, 3), generator=torch.Generator().manual_seed(9), dtype=torch.uint8)
+    ref_p, ref_o, ref_d = rcnn_ref.forward_front(sd, img, cfg)
+    pyr, obj, dl = MaskRCNNFront(cfg, sd, precision=precision).forward_front(img.cuda())
+    worst = 0.0
+    for i, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
+        for got, ref in ((pyr[i], ref_p[k]), (obj[i], ref_o[i]), (dl[i], ref_d[i])):
+            err = (got.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() / (1 + ref.abs().max().item())
+            worst = max(worst, err)
+    print(f"{precision}: front end worst relative error {worst:.3e}")
+    assert worst <= tol
+
+
 @pytest.fixture(scope="module")
 def small_net():
     from oracle import rcnn_ref

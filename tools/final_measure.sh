@@ -5,25 +5,32 @@ OUT=${1:-gpurun_out/final}
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/$OUT
 cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_gpu.txt
+python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|max-abs|max \|GPU|final map|vs oracle|fp64|worst" > $OUT/pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 --op-table $OUT/op_table_fp32.json > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
-for m in bf16x6 bf16x3; do python bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --also "" --traffic none --op-table $OUT/op_table_$m.json 2>/dev/null | grep "^{" ; done > $OUT/bench_modes.json
-python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --also "" --traffic none 2>/dev/null | grep "^{" > $OUT/bench_config5.json
-python bench.py --batch 1 --size 240 --steps 50 --warmup 5 --no-cpu-baseline --also "" --traffic none --no-probe 2>/dev/null | grep "^{" > $OUT/bench_b1_240.json
-python bench.py --batch 1 --size 720 --steps 50 --warmup 5 --no-cpu-baseline --also "" --traffic none --no-probe 2>/dev/null | grep "^{" > $OUT/bench_b1_720.json
+for m in bf16x6 bf16x3; do python bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --also "" --traffic measure --op-table $OUT/op_table_$m.json 2>/dev/null | grep "^{" ; done > $OUT/bench_modes.json
+python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --also "bf16x6" --traffic none 2>/dev/null | grep "^{" > $OUT/bench_config5.json
+for m in fp32 bf16x6; do
+python bench.py --batch 1 --size 240 --precision $m --steps 50 --warmup 5 --no-cpu-baseline --also "" --traffic none --no-probe 2>/dev/null | grep "^{"
+python bench.py --batch 1 --size 720 --precision $m --steps 50 --warmup 5 --no-cpu-baseline --also "" --traffic none --no-probe 2>/dev/null | grep "^{"
+done > $OUT/bench_b1.jsonl
 python tools/bench_rcnn.py 16 2>/dev/null | grep "^{" > $OUT/rcnn_b16.jsonl
 python tools/bench_rcnn.py 1 2>/dev/null | grep "^{" > $OUT/rcnn_b1.jsonl
 : > $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
-python tools/bench_pipeline.py --episodes 2 --frames 60 --no-goal 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
+python tools/bench_pipeline.py --episodes 2 --frames 60 --precision bf16x6 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
+python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision bf16x6 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision bf16x3 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 cd /tmp; export TMPDIR=/tmp
+for m in fp32 bf16x6; do
 rm -rf /tmp/fm_trace
-rocprofv3 --kernel-trace --stats -d /tmp/fm_trace -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probe --also "" --traffic none > /tmp/fm_trace.log 2>&1
-db=$(find /tmp/fm_trace -name '*.db' | head -1); [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $R/$OUT/trace.txt
+rocprofv3 --kernel-trace --stats -d /tmp/fm_trace -- python $R/bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --no-probe --also "" --traffic none > /tmp/fm_trace.log 2>&1
+db=$(find /tmp/fm_trace -name '*.db' | head -1); [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $R/$OUT/trace_$m.txt
+done
+rm -rf /tmp/fm_trace2
 rocprofv3 --kernel-trace -d /tmp/fm_trace2 -- python $R/tools/measure_mapping.py > $R/$OUT/mapping_measure.json 2>/dev/null
 db=$(find /tmp/fm_trace2 -name '*.db' | head -1); [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $R/$OUT/mapping_trace.txt
 cd $R
 tools/pmc_passes.sh $OUT/pmc_fp32 --precision fp32
+tools/pmc_passes.sh $OUT/pmc_bf16x6 --precision bf16x6
 ls $OUT
