@@ -48,13 +48,15 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WM, int WN, int NP>
+// PACK = rows of one packed weight tile (the layer's bn_tile: 128 or 64); the n-tile of the kernel may be wider (256 = two
+// packed tiles) or narrower (64 rows of a 128-row packed tile)
+template <int BM, int BN, int WM, int WN, int NP, int PACK>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams p) {
   constexpr int NT = 64 * WM * WN, NW = WM * WN, STAGES = 3;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int A_BYTES = BM * 64, B_BYTES = NP * BN * 32, STAGE = A_BYTES + B_BYTES;   // one k-tile = 16 channels
-  constexpr int BSUB = BN > 128 ? 128 : BN;            // rows of one packed weight tile
+  constexpr int BSUB = PACK;
   constexpr int BSUB_BYTES = NP * BSUB * 32;
   constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024, PIECES = A_PIECES + B_PIECES;   // 1 KiB DMA pieces
   constexpr int PER_WAVE = (PIECES + NW - 1) / NW;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   constexpr int ER = BM / EP;
   constexpr int SMEM_BYTES = (STAGES * STAGE > ER * CS * 4) ? STAGES * STAGE : ER * CS * 4;
   static_assert(TM % 32 == 0 && TN % 32 == 0 && (NP == 2 || NP == 3) && PER_WAVE <= 6, "tile configuration");
-  static_assert(BN <= 128 || BN == 256, "a 256-wide n-tile is two packed 128-row weight tiles");
+  static_assert(BN % PACK == 0 || PACK % BN == 0, "the n-tile is whole packed weight tiles, or a whole fraction of one");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x;
@@ -101,11 +103,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
       const int pb = piece - A_PIECES;
       const int pbc = pb < B_PIECES ? pb : B_PIECES - 1;      // past the end (uneven split): clamp, never issued
       const int q = pbc / (BN / 32), r = (pbc % (BN / 32)) * 32 + (lane >> 1);
-      const int sub = r / BSUB, rs = r % BSUB;
+      const int nrow = nt * BN + r;                            // row of the layer's weight matrix
+      const int sub = nrow / BSUB, rs = nrow % BSUB;           // packed tile, row inside it
       const int h = (lane & 1) ^ ((r >> 3) & 1);
       const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w) +
                                    (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * (size_t)p.w_group_stride : 0) +
-                                   ((size_t)(nt * (BN / BSUB) + sub) * p.nkt + wk.kt0) * BSUB_BYTES;
+                                   ((size_t)sub * p.nkt + wk.kt0) * BSUB_BYTES;
       src[j] = wtile + ((size_t)q * BSUB + rs) * 32 + h * 16;
       src2[j] = src[j];
       step[j] = BSUB_BYTES;
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   conv_epilogue<BM, BN, WM, WN, EP, NT>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0, NW < 8 ? &rp : nullptr);
 }
 
-template <int BM, int BN, int WM, int WN, int NP>
+template <int BM, int BN, int WM, int WN, int NP, int PACK>
 int launch_rs_t(ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream) {
   static SlotCache slots;
   p.ntiles = (p.cout + BN - 1) / BN;                // n-tiles of THIS kernel (decode_work)
-  if (p.mt_per_group) p.mt_per_group /= BM / 128;   // BM-row tiles per weight group
-  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP>), BM, BN, 64 * WM * WN>(
-      &gemm_rs_kernel<BM, BN, WM, WN, NP>, p, ws, ws_floats, stream, &slots);
+  if (p.mt_per_group) p.mt_per_group = p.mt_per_group * 128 / BM;   // BM-row tiles per weight group
+  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP, PACK>), BM, BN, 64 * WM * WN>(
+      &gemm_rs_kernel<BM, BN, WM, WN, NP, PACK>, p, ws, ws_floats, stream, &slots);
 }
 
 inline unsigned short bf16_piece_host(float& v) {   // next bf16 piece of v (round to nearest even), v <- remainder (exact)
@@ -281,7 +284,20 @@ bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
   return cin >= min_k && bn_tile == 128 && cout % 256 == 0 && mt_per_group % 2 == 0 && M * cout >= 256LL * 256 * 256;
 }
 
+// 64 x 64 tiles when the 128-row tiling would leave more than half of the CUs without a tile AND the k-loop is too short
+// for split-K to fill them (batch-1 shapes: layer1-3 of a 240 x 240 map).  Measured (profiles/r3i): 240 x 240 map forward
+// 1.46 -> 1.31 ms; with long k-loops the opposite holds -- the detector's res4 conv1 at 3 350 pixels (K = 1024: 54 tiles
+// cut 4 ways along K, 16 k-tiles per workgroup) beats 212 workgroups of 64 k-tiles each: batch-1 detector 4.96 vs 5.51 ms
+// -- hence the K bound.
+bool gemm_rs_uses_64(int cout, long long M, int bn_tile, int cin) {
+  static const int max_tiles = [] { const char* e = getenv("PEANUT_RS64_MAXTILES"); return e ? atoi(e) : 128; }();
+  static const int max_k = [] { const char* e = getenv("PEANUT_RS64_MAXK"); return e ? atoi(e) : 512; }();
+  const long long t128 = ((M + 127) / 128) * ((cout + bn_tile - 1) / bn_tile);
+  return cout % 64 == 0 && cin <= max_k && t128 < max_tiles;
+}
+
 const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_tile, int cin, int planes) {
+  if (gemm_rs_uses_64(cout, M, bn_tile, cin)) return planes == 3 ? "gemm_rs6_64x64" : "gemm_rs3_64x64";
   if (gemm_rs_uses_256(cout, M, mt_per_group, bn_tile, cin)) return planes == 3 ? "gemm_rs6_256x256" : "gemm_rs3_256x256";
   if (bn_tile == 128) return planes == 3 ? "gemm_rs6_128x128" : "gemm_rs3_128x128";
   return planes == 3 ? "gemm_rs6_128x64" : "gemm_rs3_128x64";
@@ -293,11 +309,16 @@ int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, siz
       (planes != 2 && planes != 3))
     return fail(-2, "launch_gemm_rs: needs a pointwise layer with 16-channel granularity and 64- or 128-row weight tiles");
   note_kernel(gemm_rs_kernel_name(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, planes));
+  if (gemm_rs_uses_64(p.cout, p.M, bn_tile, p.c1 + p.c2)) {
+    if (bn_tile == 128)
+      return planes == 3 ? launch_rs_t<64, 64, 2, 2, 3, 128>(p, ws, ws_floats, stream) : launch_rs_t<64, 64, 2, 2, 2, 128>(p, ws, ws_floats, stream);
+    return planes == 3 ? launch_rs_t<64, 64, 2, 2, 3, 64>(p, ws, ws_floats, stream) : launch_rs_t<64, 64, 2, 2, 2, 64>(p, ws, ws_floats, stream);
+  }
   if (gemm_rs_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2))
-    return planes == 3 ? launch_rs_t<256, 256, 4, 2, 3>(p, ws, ws_floats, stream) : launch_rs_t<256, 256, 4, 2, 2>(p, ws, ws_floats, stream);
+    return planes == 3 ? launch_rs_t<256, 256, 4, 2, 3, 128>(p, ws, ws_floats, stream) : launch_rs_t<256, 256, 4, 2, 2, 128>(p, ws, ws_floats, stream);
   if (bn_tile == 128)
-    return planes == 3 ? launch_rs_t<128, 128, 2, 2, 3>(p, ws, ws_floats, stream) : launch_rs_t<128, 128, 2, 2, 2>(p, ws, ws_floats, stream);
-  return planes == 3 ? launch_rs_t<128, 64, 2, 2, 3>(p, ws, ws_floats, stream) : launch_rs_t<128, 64, 2, 2, 2>(p, ws, ws_floats, stream);
+    return planes == 3 ? launch_rs_t<128, 128, 2, 2, 3, 128>(p, ws, ws_floats, stream) : launch_rs_t<128, 128, 2, 2, 2, 128>(p, ws, ws_floats, stream);
+  return planes == 3 ? launch_rs_t<128, 64, 2, 2, 3, 64>(p, ws, ws_floats, stream) : launch_rs_t<128, 64, 2, 2, 2, 64>(p, ws, ws_floats, stream);
 }
 
 }  // namespace peanut

@@ -117,10 +117,19 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int 
     const int nb = 1 << bits[pass];
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-      const unsigned key = ord_key(x[i]);
-      const bool match = pass == 0 || (key >> (shift[pass] + bits[pass])) == prefix;
-      if (match) atomicAdd(&hist[(key >> shift[pass]) & (nb - 1)], 1);
+    // eight loads in flight per thread before the first LDS atomic: at batch 1 this kernel is five workgroups, and a
+    // load-use-load chain over the 163 200 logits of the finest level cost 155 us (profiles/r3h)
+    for (int i0 = tid; i0 < n; i0 += 1024 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i0 + u * 1024 < n) ? x[i0 + u * 1024] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u * 1024 >= n) break;
+        const unsigned key = ord_key(v[u]);
+        const bool match = pass == 0 || (key >> (shift[pass] + bits[pass])) == prefix;
+        if (match) atomicAdd(&hist[(key >> shift[pass]) & (nb - 1)], 1);
+      }
     }
     __syncthreads();
     find_bin(hist, nb < 64 ? 64 : nb, need, part, res);
@@ -134,9 +143,17 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int 
   sbuf[tid] = 0ull;
   __syncthreads();
   if (eq_count == need) {           // every element equal to the threshold is in: one unordered pass
-    for (int i = tid; i < n; i += 1024) {
-      const unsigned key = ord_key(x[i]);
-      if (key >= thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+    for (int i0 = tid; i0 < n; i0 += 1024 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i0 + u * 1024 < n) ? x[i0 + u * 1024] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 1024;
+        if (i >= n) break;
+        const unsigned key = ord_key(v[u]);
+        if (key >= thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+      }
     }
   } else {                          // ties across the cut: the first `need` of them by index (ordered chunks)
     for (int i0 = 0; i0 < n; i0 += 1024) {

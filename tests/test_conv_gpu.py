@@ -167,13 +167,21 @@ RS_TOL = {"bf16x6": 2e-5, "bf16x3": 1e-4}     # bf16x6: fp32-class, held to the 
 
 RS_CASES = [
     # (B, H, W, cin, cout, stride, relu, residual), kernel family without the piece count
-    ((2, 15, 15, 64, 256, 1, False, True), "128x64"),        # layer1 conv3 + identity: K = 64 (4 k-tiles), 64-row weight tiles
-    ((1, 31, 29, 256, 128, 1, True, False), "128x128"),      # ragged M (899 rows)
-    ((2, 17, 17, 256, 512, 2, False, False), "128x128"),     # strided 1x1 downsample
-    ((1, 1, 36, 2048, 512, 1, True, False), "128x128"),      # PPM 1x1 on pooled bins: tiny M, tail split-K over 128 k-tiles
-    ((3, 13, 13, 512, 320, 1, False, False), "128x128"),     # cout not a tile multiple
-    ((1, 12, 12, 48, 64, 1, True, False), "128x64"),         # K = 48: three k-tiles, exactly the pipeline depth
-    ((1, 9, 9, 16, 128, 1, False, False), "128x64"),         # a single k-tile
+    # -- fewer than 128 tiles of 128 rows: 64 x 64 tiles (the batch-1 shapes)
+    ((2, 15, 15, 64, 256, 1, False, True), "64x64"),         # layer1 conv3 + identity: K = 64 (4 k-tiles), 64-row packed weights
+    ((1, 31, 29, 256, 128, 1, True, False), "64x64"),        # ragged M (899 rows), 64 rows of a 128-row packed tile
+    ((2, 17, 17, 256, 512, 2, False, False), "64x64"),       # strided 1x1 downsample
+    ((1, 1, 36, 2048, 512, 1, True, False), "128x128"),      # PPM 1x1 on pooled bins: tiny M, K > 512: split-K over 128 k-tiles
+    ((3, 13, 13, 512, 320, 1, False, False), "64x64"),       # cout = 5 x 64: the last n-tile sits in the padded half of a packed tile
+    ((1, 12, 12, 48, 64, 1, True, False), "64x64"),          # K = 48: three k-tiles, exactly the pipeline depth
+    ((1, 9, 9, 16, 128, 1, False, False), "64x64"),          # a single k-tile
+    ((1, 50, 67, 1024, 256, 1, True, False), "128x128"),     # res4 conv1 of the detector at batch 1 (3 350 pixels): K > 512, split-K
+    ((1, 50, 67, 256, 1024, 1, True, True), "128x128"),      # its conv3: 216 tiles
+    # -- 128-row tiles
+    ((3, 75, 75, 256, 128, 1, True, True), "128x128"),       # 132 x 1 tiles, ragged M, residual
+    ((4, 64, 64, 64, 256, 1, False, True), "128x64"),        # K <= 128: 128 x 64 tiles (three workgroups per CU)
+    ((2, 100, 100, 384, 320, 1, True, False), "128x128"),    # cout not a multiple of the tile
+    # -- 256 x 256 tiles
     ((8, 64, 64, 512, 512, 1, True, True), "256x256"),       # at the 256-tile gate (M * cout = 16.8 M), residual
     ((5, 57, 61, 1024, 1024, 1, True, True), "256x256"),     # ragged last 256-row tile
     ((8, 64, 64, 512, 768, 1, False, False), "256x256"),     # 384 tiles over 256 CUs: split-K tail
@@ -219,7 +227,8 @@ def test_register_split_winograd(case):
     ref = F.relu(F.conv2d(x, w, None, padding=d, dilation=d) + res)
     conv = FusedConv(w, None, None, padding=d, dilation=d, relu=True, precision="bf16x6")
     y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda())
-    assert _last_kernel() == ("gemm_rs6_256x256" if case[0] == 2 else "gemm_rs6_128x128"), _last_kernel()
+    want = {(2, 88, 88, 512, 512, 1): "gemm_rs6_256x256", (1, 15, 15, 512, 512, 4): "gemm_rs6_128x128", (1, 15, 13, 256, 320, 1): "gemm_rs6_64x64"}
+    assert _last_kernel() == want[case], _last_kernel()
     err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
     assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
