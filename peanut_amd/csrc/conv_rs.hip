@@ -178,16 +178,6 @@ int launch_crs_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t 
                                                                                     ws_floats, stream, &slots);
 }
 
-inline unsigned short bf16_piece_host(float& v) {   // as in gemm_rs.hip
-  unsigned bits;
-  __builtin_memcpy(&bits, &v, 4);
-  bits += 0x7fffu + ((bits >> 16) & 1u);
-  bits &= 0xffff0000u;
-  float piece;
-  __builtin_memcpy(&piece, &bits, 4);
-  v -= piece;
-  return (unsigned short)(bits >> 16);
-}
 
 }  // namespace
 

@@ -242,16 +242,6 @@ int launch_rs_t(ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream) 
       &gemm_rs_kernel<BM, BN, WM, WN, NP, PACK>, p, ws, ws_floats, stream, &slots);
 }
 
-inline unsigned short bf16_piece_host(float& v) {   // next bf16 piece of v (round to nearest even), v <- remainder (exact)
-  unsigned bits;
-  __builtin_memcpy(&bits, &v, 4);
-  bits += 0x7fffu + ((bits >> 16) & 1u);
-  bits &= 0xffff0000u;
-  float piece;
-  __builtin_memcpy(&piece, &bits, 4);
-  v -= piece;
-  return (unsigned short)(bits >> 16);
-}
 
 }  // namespace
 

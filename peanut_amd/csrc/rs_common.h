@@ -6,6 +6,19 @@
 namespace peanut {
 namespace {
 
+// host side: next bf16 piece of v (round to nearest even), v <- the remainder (exact in fp32: the piece agrees with v in
+// its leading bits).  The same rounding as v_cvt_pk_bf16_f32 on the device, so weights and activations split alike.
+inline unsigned short bf16_piece_host(float& v) {
+  unsigned bits;
+  __builtin_memcpy(&bits, &v, 4);
+  bits += 0x7fffu + ((bits >> 16) & 1u);
+  bits &= 0xffff0000u;
+  float piece;
+  __builtin_memcpy(&piece, &bits, 4);
+  v -= piece;
+  return (unsigned short)(bits >> 16);
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
