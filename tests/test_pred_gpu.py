@@ -341,7 +341,7 @@ def test_distance_to_the_fp64_reference(golden_dir):
     """How far is each arithmetic mode from the EXACT result?  tests/golden/pspnet_fp64_golden.npz holds the logits of
     the reference's own model files run in float64 (oracle/gen_golden.py: gen_pspnet_fp64); the reference's fp32 CPU
     path is 5.4-5.7e-6 away from them.  'fp32-class' = the same order of magnitude: asserted for the fp32 MFMA modes
-    and for the bf16x6 emulation; the split modes are reported."""
+    and for the bf16x6 emulation; bf16x3 is reported (and bounded)."""
     from peanut_amd.prediction import PEANUT_Prediction_Model
     from peanut_amd.weights import PredCfg, make_seeded_state_dict
     z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
