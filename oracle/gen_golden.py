@@ -92,6 +92,40 @@ def gen_pspnet_fp64(report):
     np.savez_compressed(os.path.join(GOLDEN, "pspnet_fp64_golden.npz"), **out)
 
 
+# nav/pred_model_cfg.py fields beyond their committed values (round 3): (name, PredCfg overrides, B, H, W, weight seed)
+PSP_VARIANTS = [
+    ("align_corners", dict(align_corners=True), 2, 72, 88, 11),
+    ("pool124_k9_c20", dict(pool_scales=(1, 2, 4), num_classes=9, in_channels=20), 1, 96, 96, 12),
+    ("os16_no_contract", dict(strides=(1, 2, 2, 1), dilations=(1, 1, 1, 2), contract_dilation=False), 2, 96, 80, 13),
+]
+
+
+def gen_pspnet_variants(report):
+    """pspnet_golden_variants.npz: the reference's own model files built from nav/pred_model_cfg.py with some of its fields
+    edited (align_corners, pool_scales / num_classes / in_channels, an output-stride-16 backbone), seeded weights and inputs."""
+    out = {}
+    for name, over, b, h, w, wseed in PSP_VARIANTS:
+        cfg = PredCfg(**over)
+        bb = {k: over[k] for k in ("strides", "dilations", "contract_dilation") if k in over}
+        dh = {k: over[k] for k in ("pool_scales", "num_classes", "align_corners") if k in over}
+        m = ref_import.build_reference_model(in_channels=cfg.in_channels, backbone=bb, decode_head=dh)
+        sd = make_seeded_state_dict(cfg, wseed, with_aux=True)
+        m.load_state_dict(sd, strict=True)
+        x = psp_input(b, cfg.in_channels, h, w, wseed)
+        ref = np.stack(ref_import.reference_forward(m, x))
+        mine = pspnet_ref.forward_batch(sd, x, cfg).numpy()
+        err = float(np.abs(ref - mine).max())
+        assert err <= 1e-5, f"{name}: oracle restatement deviates from the reference by {err}"
+        out[f"{name}/input"] = x.numpy().astype(np.uint8)
+        out[f"{name}/logits"] = ref.astype(np.float32)
+        out[f"{name}/weight_seed"] = np.int64(wseed)
+        for k, v in over.items():
+            out[f"{name}/cfg_{k}"] = np.asarray(v)
+        report["pspnet"][name] = dict(shape=[b, cfg.in_channels, h, w], restatement_max_abs=err, logits_absmax=float(np.abs(ref).max()))
+        print(f"[pspnet] {name}: ref vs restatement max-abs {err:.2e}, |logit|max {np.abs(ref).max():.2f}")
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_golden_variants.npz"), **out)
+
+
 def gen_pspnet_round2(report):
     """Round-2 additions, written to their own files so that the round-1 fixtures stay byte-identical:
     * pspnet_golden_c25.npz -- config 5's channel count (C_in = 25) at 240x240 (one map);
@@ -131,6 +165,12 @@ def gen_pspnet_round2(report):
 
 
 def main():
+    if "--round3" in sys.argv:       # only the round-3 fixtures (variant configs; mapping flags: oracle.gen_golden_mapping)
+        report = {"pspnet": {}, "mapping": {}}
+        gen_pspnet_variants(report)
+        with open(os.path.join(GOLDEN, "golden_report_r3.json"), "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        return
     if "--round2" in sys.argv:       # only the added fixtures (the round-1 files are left untouched)
         report = {"pspnet": {}, "pspnet_fp64": {}}
         gen_pspnet_round2(report)
@@ -144,6 +184,7 @@ def main():
     gen_pspnet(report)
     gen_pspnet_fp64(report)
     gen_pspnet_round2(report)
+    gen_pspnet_variants(report)
     from oracle import gen_golden_agent, gen_golden_mapping
     gen_golden_mapping.generate(report)
     gen_golden_agent.generate(report)

@@ -231,8 +231,10 @@ def load_reference_mmseg():
     return builder
 
 
-def build_reference_model(cfg_path: str | None = None, in_channels: int | None = None):
-    """``init_segmentor`` without a checkpoint (prediction/mmseg/apis/inference.py:29-39)."""
+def build_reference_model(cfg_path: str | None = None, in_channels: int | None = None, backbone: dict | None = None,
+                          decode_head: dict | None = None):
+    """``init_segmentor`` without a checkpoint (prediction/mmseg/apis/inference.py:29-39).  ``backbone`` / ``decode_head``:
+    fields of nav/pred_model_cfg.py overridden before the build (the variants a maintainer could edit in that file)."""
     builder = load_reference_mmseg()
     cfg_path = cfg_path or os.path.join(REF, "nav", "pred_model_cfg.py")
     ns = {}
@@ -243,6 +245,12 @@ def build_reference_model(cfg_path: str | None = None, in_channels: int | None =
     model_cfg.train_cfg = None                       # inference.py:30
     if in_channels is not None:
         model_cfg.backbone.in_channels = in_channels
+    for k, v in (backbone or {}).items():
+        setattr(model_cfg.backbone, k, v)
+    for k, v in (decode_head or {}).items():
+        setattr(model_cfg.decode_head, k, v)
+        if k in ("align_corners", "num_classes") and getattr(model_cfg, "auxiliary_head", None) is not None:
+            setattr(model_cfg.auxiliary_head, k, v)
     model = builder.build_segmentor(model_cfg, test_cfg=None)
     model.eval()
     return model

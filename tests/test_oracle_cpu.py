@@ -103,3 +103,26 @@ def test_oracle_distance_to_fp64_reference(golden_dir):
     got = pspnet_ref.forward_batch(sd, x, cfg).numpy().astype(np.float64)
     err = float(np.abs(got - z64["odd_100/logits64"]).max())
     assert err <= 1e-5 and abs(err - float(z64["odd_100/fp32_cpu_reference_max_abs"])) <= 1e-9
+
+
+def _variant_cfg(z, name):
+    over = {}
+    for k in z.files:
+        if k.startswith(f"{name}/cfg_"):
+            v = z[k]
+            over[k.split("cfg_", 1)[1]] = tuple(int(t) for t in v) if v.ndim else (bool(v) if v.dtype == bool else int(v))
+    return W.PredCfg(**over)
+
+
+@pytest.mark.parametrize("name", ["align_corners", "pool124_k9_c20", "os16_no_contract"])
+def test_oracle_reproduces_variant_config_goldens(golden_dir, name):
+    """nav/pred_model_cfg.py with some fields edited (align_corners = True; pool_scales (1, 2, 4) with 9 classes and 20
+    input channels; an output-stride-16 backbone without contracted dilation): logits from the reference's own model files
+    (oracle/gen_golden.py: gen_pspnet_variants) vs the restatement."""
+    z = np.load(os.path.join(golden_dir, "pspnet_golden_variants.npz"))
+    cfg = _variant_cfg(z, name)
+    sd = W.make_seeded_state_dict(cfg, int(z[f"{name}/weight_seed"]))
+    x = torch.from_numpy(z[f"{name}/input"].astype(np.float32))
+    got = pspnet_ref.forward_batch(sd, x, cfg).numpy()
+    assert got.shape == z[f"{name}/logits"].shape
+    assert np.abs(got - z[f"{name}/logits"]).max() <= 1e-5

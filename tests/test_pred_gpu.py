@@ -337,6 +337,27 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
             del mm
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("name", ["align_corners", "pool124_k9_c20", "os16_no_contract"])
+def test_variant_model_configs_match_reference_goldens(golden_dir, name, precision):
+    """The cfg fields the inference path reads (nav/pred_model_cfg.py:2-42) at values other than the committed ones:
+    align_corners = True (PPM resize, final resize), pool_scales (1, 2, 4) with 9 classes and 20 input channels, and an
+    output-stride-16 backbone (strides (1, 2, 2, 1), dilations (1, 1, 1, 2), no contracted dilation).  Golden logits from
+    the reference's own model files built from that file with the fields edited (tests/golden/pspnet_golden_variants.npz)."""
+    from test_oracle_cpu import _variant_cfg
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_golden_variants.npz"))
+    cfg = _variant_cfg(z, name)
+    sd = make_seeded_state_dict(cfg, int(z[f"{name}/weight_seed"]))
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
+    x = torch.from_numpy(z[f"{name}/input"].astype(np.float32)).cuda()
+    got = m.get_prediction_batch(x, apply_sigmoid=False).cpu().numpy()
+    err = np.abs(got - z[f"{name}/logits"]).max()
+    print(f"{name} {precision}: max-abs vs the reference golden {err:.3e}")
+    assert got.shape == z[f"{name}/logits"].shape and err <= TOL
+
+
 def test_distance_to_the_fp64_reference(golden_dir):
     """How far is each arithmetic mode from the EXACT result?  tests/golden/pspnet_fp64_golden.npz holds the logits of
     the reference's own model files run in float64 (oracle/gen_golden.py: gen_pspnet_fp64); the reference's fp32 CPU
