@@ -36,6 +36,8 @@ FLAG_VARIANTS = [
     ("du2", dict(du_scale=2), 4, 5),                                       # depth sub-sampled, semantics average-pooled 2x2
     ("vr64_map2400", dict(vision_range=64, map_size_cm=2400), 5, 5),       # smaller egocentric window, 240 x 240 local map
     ("f96x128", dict(frame_height=96, frame_width=128, hfov=90.0, camera_height=1.25), 6, 6),   # another camera
+    ("res4_thresholds", dict(map_resolution=4, map_size_cm=3840, cat_pred_threshold=2.0, exp_pred_threshold=2.0,
+                             map_pred_threshold=0.5, global_downscaling=1, vision_range=80), 7, 5),   # cell size, thresholds, no downscaling
 ]
 
 
