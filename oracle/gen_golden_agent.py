@@ -69,12 +69,11 @@ def drive(state, frames, goal_cat=2, record=None):
         state.inc_step()
 
 
-def generate(report):
-    Agent_State = load_reference_agent_state()
-    args = agent_args()
+def _episode(Agent_State, over, seed, n_frames, goal_cat):
+    args = agent_args(**over)
     st = Agent_State(args)
     st.prediction_model = FakePrediction(args.prediction_window)
-    frames = mapping_scenes.make_sequence(seed=7, n_frames=45)
+    frames = mapping_scenes.make_sequence(seed=seed, n_frames=n_frames)
     # make the agent travel: larger forward motion so that the local window is re-centred at step 19/39
     for f in frames:
         f["pose"][0] = np.float32(f["pose"][0] * 3.0)
@@ -94,19 +93,40 @@ def generate(report):
             last_pred["v"] = np.asarray(s.target_pred, np.float32).copy()
             last_pred["step"] = i
 
-    drive(st, frames, goal_cat=2, record=record)
+    drive(st, frames, goal_cat=goal_cat, record=record)
     full = st.full_map.cpu().numpy()
     idx = np.flatnonzero(full)
-    out = {"seed": np.int64(7), "n_frames": np.int64(45), "goal_cat": np.int64(2),
+    out = {"seed": np.int64(seed), "n_frames": np.int64(n_frames), "goal_cat": np.int64(goal_cat),
            "lmb": np.stack(rec["lmb"]), "loc": np.stack(rec["loc"]), "channel_sums": np.stack(rec["sums"]),
            "local_pose": np.stack(rec["poses"]), "pred_steps": np.array(rec["pred_steps"], np.int64),
            "pred_sum": np.array(rec["pred_sum"]), "pred_sq": np.array(rec["pred_sq"]),
            "last_target_pred": last_pred["v"],
            "last_pred_step": np.int64(last_pred["step"]),
            "full_idx": idx.astype(np.int32), "full_val": full.reshape(-1)[idx].astype(np.float32)}
+    stats = dict(frames=n_frames, prediction_steps=rec["pred_steps"],
+                 lmb_changes=int((np.diff(np.stack(rec["lmb"]), axis=0) != 0).any(1).sum()), full_nnz=int(idx.size))
+    print(f"[agent_state] {over or 'defaults'}: {n_frames} frames, predictions at {rec['pred_steps']}, lmb changed "
+          f"{stats['lmb_changes']}x, full-map nnz {idx.size}")
+    return out, stats
+
+
+# nav/arguments.py values other than the defaults (round 3): a prediction window SMALLER than the local map (crop instead
+# of pad, agent_state.py:355-361), shorter local / goal-update periods, another goal category
+VARIANT = dict(prediction_window=400, num_local_steps=10, update_goal_freq=7, goal_reached_dist=50)
+
+
+def generate(report):
+    Agent_State = load_reference_agent_state()
+    out, stats = _episode(Agent_State, {}, 7, 45, 2)
     np.savez_compressed(os.path.join(GOLDEN, "agent_state_golden.npz"), **out)
-    report["agent_state"] = dict(frames=45, prediction_steps=rec["pred_steps"],
-                                 lmb_changes=int((np.diff(np.stack(rec["lmb"]), axis=0) != 0).any(1).sum()),
-                                 full_nnz=int(idx.size))
-    print(f"[agent_state] 45 frames, predictions at {rec['pred_steps']}, lmb changed "
-          f"{report['agent_state']['lmb_changes']}x, full-map nnz {idx.size}")
+    report["agent_state"] = stats
+    generate_variant(report, Agent_State)
+
+
+def generate_variant(report, Agent_State=None):
+    Agent_State = Agent_State or load_reference_agent_state()
+    out, stats = _episode(Agent_State, VARIANT, 8, 36, 5)
+    for k, v in VARIANT.items():
+        out[f"arg_{k}"] = np.int64(v)
+    np.savez_compressed(os.path.join(GOLDEN, "agent_state_golden_v2.npz"), **out)
+    report["agent_state_v2"] = stats

@@ -335,7 +335,8 @@ int conv_pw_256_min_k() {
   return min_k;
 }
 bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin) {
-  return bn_tile == 128 && cin >= conv_pw_256_min_k() && mt_per_group % 2 == 0 && M * cout >= 256LL * 256 * 128;
+  static const long long min_tiles = [] { const char* e = getenv("PEANUT_PW256_MINTILES"); return e ? atoll(e) : 256LL; }();
+  return bn_tile == 128 && cin >= conv_pw_256_min_k() && mt_per_group % 2 == 0 && M * cout >= min_tiles * 256 * 128;
 }
 
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)

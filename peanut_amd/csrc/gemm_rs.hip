@@ -271,7 +271,8 @@ void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn
 // a tile's epilogue, which nobody computes under with one workgroup per CU; else 128 x 128 (two per CU) / 128 x 64.
 bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin) {
   static const int min_k = [] { const char* e = getenv("PEANUT_RS256_MINK"); return e ? atoi(e) : 512; }();
-  return cin >= min_k && bn_tile == 128 && cout % 256 == 0 && mt_per_group % 2 == 0 && M * cout >= 256LL * 256 * 256;
+  static const long long min_tiles = [] { const char* e = getenv("PEANUT_RS256_MINTILES"); return e ? atoll(e) : 256LL; }();
+  return cin >= min_k && bn_tile == 128 && cout % 256 == 0 && mt_per_group % 2 == 0 && M * cout >= min_tiles * 256 * 256;
 }
 
 // 64 x 64 tiles when the 128-row tiling would leave more than half of the CUs without a tile AND the k-loop is too short

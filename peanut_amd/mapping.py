@@ -51,9 +51,9 @@ class Semantic_Mapping(nn.Module):
         if h is not None and h.value:
             try:
                 self._lib.peanut_map_destroy(h)
+                h.value = None       # (no attribute assignment: nn.Module.__setattr__ is gone at interpreter shutdown)
             except Exception:  # pragma: no cover
                 pass
-            self._h = C.c_void_p()
 
     @staticmethod
     def _chk(t, shape, name):

@@ -21,12 +21,15 @@ class FakePredictionGPU:
         return torch.tanh(sel + self.pattern[None]) * 0.5 + 0.5
 
 
-def test_agent_state_episode_matches_reference(golden_dir):
+@pytest.mark.parametrize("golden", ["agent_state_golden.npz", "agent_state_golden_v2.npz"])
+def test_agent_state_episode_matches_reference(golden_dir, golden):
+    """Default nav/arguments.py values, and (v2) a prediction window smaller than the local map (the crop branch of
+    agent_state.py:355-361), 10-step local periods, goal updates every 7 steps, another goal category."""
     from oracle import mapping_scenes
     from oracle.agent_ref import agent_args, fake_pattern
     from peanut_amd.agent_state import Agent_State
-    z = np.load(os.path.join(golden_dir, "agent_state_golden.npz"))
-    args = agent_args()
+    z = np.load(os.path.join(golden_dir, golden))
+    args = agent_args(**{k[4:]: int(z[k]) for k in z.files if k.startswith("arg_")})
     st = Agent_State(args, prediction_model=FakePredictionGPU(fake_pattern(size=args.prediction_window)))
     frames = mapping_scenes.make_sequence(seed=int(z["seed"]), n_frames=int(z["n_frames"]))
     for f in frames:
@@ -57,12 +60,15 @@ def test_agent_state_episode_matches_reference(golden_dir):
     assert pred_steps == list(z["pred_steps"])
     assert int(z["last_pred_step"]) == pred_steps[-1]
     assert np.abs(last_pred - z["last_target_pred"]).max() <= 1e-4
-    # full_map has the same write history on both sides (update_full_map at l_step 19, update_prediction's
-    # write-back at every prediction step), so it is compared as is
+    # full_map has the same write history on both sides (update_full_map at the end of each local period,
+    # update_prediction's write-back at every prediction step), so it is compared as is
     full = st.full_map.cpu().numpy().reshape(-1)
     ref = np.zeros_like(full)
     ref[z["full_idx"]] = z["full_val"]
-    assert np.abs(full - ref).max() <= 5e-5
+    # 5e-5 is the per-step bound of tests/test_mapping_gpu.py (device sin/cos vs SLEEF in the pose); fractional cells
+    # that were warped again and again carry it forward: 6.0e-5 on 31 cells of the 36-frame v2 episode, whose poses move
+    # three times as far per step
+    assert np.abs(full - ref).max() <= (5e-5 if golden == "agent_state_golden.npz" else 1e-4)
 
 
 def test_preprocess_obs_matches_reference_loop():
