@@ -44,11 +44,15 @@ from peanut_amd.weights import PredCfg, conv_flops_per_map, make_seeded_state_di
 
 # MI355X_MICROARCH.md: fp32 MFMA 157.3 TF (v_mfma_f32_32x32x2_f32); dense bf16/f16 MFMA 2.5 PF, of which a
 # split-product mode can deliver at most one third as fp32-equivalent FLOPs (3 MFMAs per product).
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}
 DTYPE = {"fp32": "f32",
          "bf16x3": "f32 tensors; 1x1 / Winograd GEMM products from 2 bf16 pieces per value (3 MFMA products), f32 accumulate",
+         "fp16x3": "f32 tensors; conv products emulated from 2 fp16 pieces per value (3 MFMA products), f32 accumulate",
          "bf16x6": "f32 tensors; 1x1 / Winograd GEMM products emulated from 3 bf16 pieces per value (6 MFMA products), f32 accumulate"}
 MODE_NOTES = {
+    "fp16x3": "opt-in: 2 fp16 pieces per value (22 significand bits; activations split in registers, weights pre-split "
+              "after a per-layer power-of-two scale), 3 MFMA products per fp32 product, fp32 accumulate; needs the "
+              "activations of the emulated layers below 65504 in magnitude",
     "bf16x3": "opt-in speed mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; ~7e-5 max-abs "
               "on the logits vs the reference golden vectors (bound 1e-3); not fp32-class, not the headline value",
     "bf16x6": "fp32 emulation on the bf16 matrix cores (csrc/gemm_rs.hip): activations stay fp32 in HBM / LDS and are split "
@@ -148,6 +152,8 @@ FAMILY_KERNEL = {
     "gemm_rs3_256x256": "gemm_rs_kernel<256, 256, 4, 2, 2>",
     "gemm_rs6_128x128": "gemm_rs_kernel<128, 128, 2, 2, 3>",
     "gemm_rs3_128x128": "gemm_rs_kernel<128, 128, 2, 2, 2>",
+    "gemm_rs3h_256x256": "gemm_rs_kernel<256, 256, 4, 2, 4>",
+    "gemm_rs3h_128x128": "gemm_rs_kernel<128, 128, 2, 2, 4>",
 }
 
 
@@ -278,7 +284,7 @@ def main():
                                                "collect_maps.py format) used as input instead of synthetic maps")
     ap.add_argument("--precision", default=os.environ.get("PEANUT_PRECISION", "fp32"),
                     choices=sorted(PEAK_TFLOPS), help="conv arithmetic (include/peanut_hip.h PEANUT_PREC_*)")
-    ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO", "bf16x6,bf16x3"),
+    ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO", "bf16x6,fp16x3,bf16x3"),
                     help="comma list of extra precision modes measured after the main run and reported under "
                          "'modes' (empty string to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -80,9 +80,16 @@ typedef struct peanut_pred_cfg {
  * results, measured as close to a float64 run of the reference model as the reference's own fp32 CPU path.  The other
  * layers (3x3 direct convs, the stem) stay on the fp32 MFMA kernels.
  * BF16X3: the same with two pieces and three products (~2^-16 relative per product: ~7e-5 max-abs on the logits,
- * bound 1e-3); an opt-in speed mode, not fp32-class. */
+ * bound 1e-3); an opt-in speed mode, not fp32-class.
+ * FP16X3: two FP16 pieces per value (2 x 11 = 22 significand bits) and the three products hi*hi, hi*lo, lo*hi on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- the cost of BF16X3 at close to BF16X6's accuracy (dropped / rounded
+ * terms <= 2^-21.5 relative per product).  What it gives up is fp32's exponent range in the ACTIVATIONS of the emulated
+ * layers: they must stay below 65504 in magnitude (Winograd-domain values included), and the low piece of a value below
+ * 2^-3 is an fp16 subnormal (absolute error <= 3e-8, fp32's own rounding of a value near 0.5).  Weights are scaled by a
+ * per-layer power of two before the split (undone exactly in the epilogue), so their range does not matter.  Opt-in. */
 #define PEANUT_PREC_FP32 0
 #define PEANUT_PREC_BF16X3 1
+#define PEANUT_PREC_FP16X3 2
 #define PEANUT_PREC_BF16X6 3
 
 /* One entry of an mmcv/PyTorch state dict (HOST memory, fp32, contiguous, OIHW for convs). */

@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 8     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 9     # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -133,7 +133,7 @@ SIGNATURES = {
 
 
 CONV_ALGOS = {"auto": 0, "direct": 1}   # PEANUT_ALGO_*
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 3}   # PEANUT_PREC_* (bf16x6: prediction planner only)
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x3": 2, "bf16x6": 3}   # PEANUT_PREC_*
 
 
 def lib_path() -> str:

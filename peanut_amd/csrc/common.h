@@ -39,7 +39,9 @@ struct ConvDesc {
   // into bf16 pieces in registers, the weights' pieces pre-split in w_s
   int rs;                  // 1: pointwise layer on gemm_rs.hip; 2: any other conv on conv_rs.hip (k-tile = 16 channels of one tap)
   const void* w_s;         // device: pre-split weights [n-tile][k-tile of 16][plane][bn_tile][16 bf16] (pack_weights_sx), or null
-  int s_planes;            // bf16 pieces per value: 2 (bf16x3: three products) or 3 (bf16x6: six products)
+  int s_planes;            // emulation kind (rs_common.h): 2 = bf16x3 (two bf16 pieces, three products), 3 = bf16x6 (three
+                           // pieces, six products), 4 = fp16x3 (two fp16 pieces, three products)
+  float s_alpha;           // 1 / the power of two the weights were scaled by before the split (fp16 pieces), else 1
 };
 
 struct ConvArgs {
@@ -90,12 +92,15 @@ int launch_wino_output(const float* Mb, const float* scale, const float* shift, 
 // whether the 256 x 256 kernel runs a [M x cout] output (mt_per_group: 128-row tiles per Winograd position, 0 = plain)
 bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
 const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_tile, int cin, int planes);
-// the weights' bf16 pieces, packed per (n-tile of bn_tile rows, k-tile of 16 channels, plane)
+// the weights' pieces (planes = emulation kind), packed per (n-tile of bn_tile rows, k-tile of 16 channels, plane)
 size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes);
-void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out);
+void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, float wscale, void* out);
+// the power of two a layer's weights are scaled by before the split (fp16 pieces: largest |w| to 2^13..2^14; else 1)
+float sx_pack_scale(const float* w, size_t n, int planes);
 // conv_rs.hip: the same for a kh x kw layer, k-tiles ordered channel chunk outer / filter tap inner
 size_t sx_conv_packed_bytes(int cin_pad, int cout, int kh, int kw, int bn_tile, int planes);
-void pack_weights_sx_conv(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile, int planes, void* out);
+void pack_weights_sx_conv(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile, int planes,
+                          float wscale, void* out);
 
 // ---- auxiliary (HBM-bound) kernels: layout, pooling, resampling ----
 int launch_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cpad, hipStream_t s);

@@ -33,6 +33,7 @@ struct ConvKParams {
   int mtiles;                 // m-tiles of the launch (decode_work's n-chunked tile order)
   int nchunk;                 // n-tiles per chunk of that order; 0 = plain order (n fastest over all n-tiles)
   int res_prefetch;           // epilogue: request the first rows of the residual before the accumulators go through LDS
+  float alpha;                // y = relu(alpha * acc * scale + shift + res): 1 / the pack scale of fp16-piece weights, else 1
 };
 
 template <int I>
@@ -165,7 +166,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
   const int c4 = (tid % NV) * 4, r0 = tid / NV;
   const int n = n0 + c4;
   const int ss_off = (p.mt_per_group && p.ss_group_stride) ? (wk.mt / p.mt_per_group) * p.ss_group_stride : 0;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n);   // scale/shift are padded to cout_pad
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n) * p.alpha;   // scale/shift are padded to cout_pad
   const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);
   const bool vec_ok = (p.cout & 3) == 0;   // 16-byte aligned rows
   // the first PRE residual rows of this thread are requested early (conv_res_prefetch): their latency runs under the
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
     f32x4 v = *reinterpret_cast<const f32x4*>(base + row * BN + c4);
     for (int s = 1; s < p.split_p; ++s) v += *reinterpret_cast<const f32x4*>(base + (size_t)s * (BM * BN) + row * BN + c4);
     const int ss_off = (p.mt_per_group && p.ss_group_stride) ? (mt / p.mt_per_group) * p.ss_group_stride : 0;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n) * p.alpha;
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);
     v = v * sc + sh;
     const size_t o = (size_t)m * p.cout + n;

@@ -341,11 +341,13 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.nkt = (d.cin / d.bk) * p.ntaps;
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
+  p.alpha = 1.f;
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
   if (d.rs) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
     if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");
     p.w = static_cast<const float*>(d.w_s);
     p.nkt = (d.cin / 16) * p.ntaps;
+    p.alpha = d.s_alpha;
     if (d.rs == 2) return launch_conv_rs(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
     return launch_gemm_rs(p, d.bn_tile, d.s_planes, a.ws, a.ws_floats, stream);
   }

@@ -20,8 +20,9 @@ namespace peanut {
 
 namespace {
 
-template <int BN, int WM, int WN, int NP>
+template <int BN, int WM, int WN, int KIND>
 __global__ __launch_bounds__(256) void conv_rs_kernel(const ConvKParams p) {
+  constexpr int NP = rs_pieces(KIND);
   constexpr int BM = 128, BK = 16;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -142,85 +143,88 @@ __global__ __launch_bounds__(256) void conv_rs_kernel(const ConvKParams p) {
     const unsigned char* const cur = smem + (kt & 1) * STAGE;
     if (kt + 1 < nk) store_tile(smem + ((kt + 1) & 1) * STAGE);
     if (kt + 2 < nk) load_tile();
-    bf16x8 ap[MI][NP], bf[NP][NI];
+    u32x4 ap[MI][NP], bf[NP][NI];
 #pragma unroll
     for (int t = 0; t < MI; ++t) {
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(cur + a_off0 + t * 32 * 64);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(cur + a_off1 + t * 32 * 64);
-      split_frag<NP>(v0, v1, ap[t]);
+      split_frag<KIND>(v0, v1, ap[t]);
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q)
 #pragma unroll
-      for (int u = 0; u < NI; ++u) bf[q][u] = *reinterpret_cast<const bf16x8*>(cur + q * (BN * 32) + b_row + u * 32 * 32);
+      for (int u = 0; u < NI; ++u) bf[q][u] = *reinterpret_cast<const u32x4*>(cur + q * (BN * 32) + b_row + u * 32 * 32);
 #pragma unroll
     for (int t = 0; t < MI; ++t)
 #pragma unroll
       for (int u = 0; u < NI; ++u) {
         if constexpr (NP == 3) {
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][2], bf[0][u], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[2][u], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][1], bf[1][u], acc[t][u], 0, 0, 0);
+          acc[t][u] = mfma_pieces<KIND>(ap[t][2], bf[0][u], acc[t][u]);
+          acc[t][u] = mfma_pieces<KIND>(ap[t][0], bf[2][u], acc[t][u]);
+          acc[t][u] = mfma_pieces<KIND>(ap[t][1], bf[1][u], acc[t][u]);
         }
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][1], bf[0][u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[1][u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[0][u], acc[t][u], 0, 0, 0);
+        acc[t][u] = mfma_pieces<KIND>(ap[t][1], bf[0][u], acc[t][u]);
+        acc[t][u] = mfma_pieces<KIND>(ap[t][0], bf[1][u], acc[t][u]);
+        acc[t][u] = mfma_pieces<KIND>(ap[t][0], bf[0][u], acc[t][u]);
       }
     __syncthreads();
   }
   conv_epilogue<BM, BN, WM, WN, EP>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0);
 }
 
-template <int BN, int WM, int WN, int NP>
+template <int BN, int WM, int WN, int KIND>
 int launch_crs_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
   static SlotCache slots;
-  return launch_with_tail_split<decltype(&conv_rs_kernel<BN, WM, WN, NP>), 128, BN>(&conv_rs_kernel<BN, WM, WN, NP>, p, ws,
-                                                                                    ws_floats, stream, &slots);
+  return launch_with_tail_split<decltype(&conv_rs_kernel<BN, WM, WN, KIND>), 128, BN>(&conv_rs_kernel<BN, WM, WN, KIND>, p, ws,
+                                                                                      ws_floats, stream, &slots);
+}
+
+template <int KIND>
+int launch_conv_rs_kind(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
+  if (bn_tile == 128) return launch_crs_t<128, 2, 2, KIND>(p, ws, ws_floats, stream);
+  if (bn_tile == 64) return launch_crs_t<64, 2, 2, KIND>(p, ws, ws_floats, stream);
+  return launch_crs_t<32, 4, 1, KIND>(p, ws, ws_floats, stream);
 }
 
 
 }  // namespace
 
-// bytes of the pre-split weights of a kh x kw layer: [n-tile][k-tile = chunk * taps + tap][plane][bn_tile][16 bf16]
+// bytes of the pre-split weights of a kh x kw layer: [n-tile][k-tile = chunk * taps + tap][plane][bn_tile][16 pieces];
+// planes = the emulation kind (rs_common.h)
 size_t sx_conv_packed_bytes(int cin_pad, int cout, int kh, int kw, int bn_tile, int planes) {
   const size_t ntiles = (cout + bn_tile - 1) / bn_tile;
-  return ntiles * (size_t)(cin_pad / 16) * kh * kw * planes * bn_tile * 32;
+  return ntiles * (size_t)(cin_pad / 16) * kh * kw * rs_pieces(planes) * bn_tile * 32;
 }
 
-void pack_weights_sx_conv(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile, int planes, void* out) {
+void pack_weights_sx_conv(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw, int bn_tile, int planes,
+                          float wscale, void* out) {
   unsigned short* o = static_cast<unsigned short*>(out);
   const int ntaps = kh * kw, ntiles = (cout + bn_tile - 1) / bn_tile, nchunks = cin_pad / 16, nkt = nchunks * ntaps;
+  const int np = rs_pieces(planes);
   for (int nt = 0; nt < ntiles; ++nt)
     for (int ch = 0; ch < nchunks; ++ch)
       for (int tap = 0; tap < ntaps; ++tap) {
-        unsigned short* tile = o + ((size_t)nt * nkt + (size_t)ch * ntaps + tap) * planes * bn_tile * 16;
+        unsigned short* tile = o + ((size_t)nt * nkt + (size_t)ch * ntaps + tap) * np * bn_tile * 16;
         for (int r = 0; r < bn_tile; ++r)
           for (int e = 0; e < 16; ++e) {
             const int n = nt * bn_tile + r, c = ch * 16 + e;
-            float v = (n < cout && c < cin_real) ? w_oihw[((size_t)n * cin_real + c) * ntaps + tap] : 0.f;
-            for (int q = 0; q < planes; ++q) tile[((size_t)q * bn_tile + r) * 16 + e] = bf16_piece_host(v);
+            float v = (n < cout && c < cin_real) ? w_oihw[((size_t)n * cin_real + c) * ntaps + tap] * wscale : 0.f;
+            for (int q = 0; q < np; ++q) tile[((size_t)q * bn_tile + r) * 16 + e] = rs_piece_host(v, planes);
           }
       }
 }
 
 // p.x / p.x2: fp32 NHWC sources, p.w: pack_weights_sx_conv weights, p.nkt = (cin / 16) * taps
 int launch_conv_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream) {
-  if (p.c1 % 16 || p.c2 % 16 || (planes != 2 && planes != 3)) return fail(-2, "launch_conv_rs: 16-channel granularity, 2 or 3 planes");
-  static const char* const names[2][3] = {{"conv_rs3_128x128", "conv_rs3_128x64", "conv_rs3_128x32"},
-                                          {"conv_rs6_128x128", "conv_rs6_128x64", "conv_rs6_128x32"}};
-  if (bn_tile == 128) {
-    note_kernel(names[planes - 2][0]);
-    return planes == 3 ? launch_crs_t<128, 2, 2, 3>(p, ws, ws_floats, stream) : launch_crs_t<128, 2, 2, 2>(p, ws, ws_floats, stream);
-  }
-  if (bn_tile == 64) {
-    note_kernel(names[planes - 2][1]);
-    return planes == 3 ? launch_crs_t<64, 2, 2, 3>(p, ws, ws_floats, stream) : launch_crs_t<64, 2, 2, 2>(p, ws, ws_floats, stream);
-  }
-  if (bn_tile == 32) {
-    note_kernel(names[planes - 2][2]);
-    return planes == 3 ? launch_crs_t<32, 4, 1, 3>(p, ws, ws_floats, stream) : launch_crs_t<32, 4, 1, 2>(p, ws, ws_floats, stream);
-  }
-  return fail(-2, "launch_conv_rs: unsupported tile configuration");
+  if (p.c1 % 16 || p.c2 % 16 || planes < RS_BF16X3 || planes > RS_FP16X3 || (bn_tile != 128 && bn_tile != 64 && bn_tile != 32))
+    return fail(-2, "launch_conv_rs: 16-channel granularity, a known emulation kind, 128 / 64 / 32-row weight tiles");
+  static const char* const names[3][3] = {{"conv_rs3_128x128", "conv_rs3_128x64", "conv_rs3_128x32"},
+                                          {"conv_rs6_128x128", "conv_rs6_128x64", "conv_rs6_128x32"},
+                                          {"conv_rs3h_128x128", "conv_rs3h_128x64", "conv_rs3h_128x32"}};
+  note_kernel(names[planes - 2][bn_tile == 128 ? 0 : (bn_tile == 64 ? 1 : 2)]);
+  if (planes == RS_BF16X6) return launch_conv_rs_kind<RS_BF16X6>(p, bn_tile, ws, ws_floats, stream);
+  if (planes == RS_FP16X3) return launch_conv_rs_kind<RS_FP16X3>(p, bn_tile, ws, ws_floats, stream);
+  return launch_conv_rs_kind<RS_BF16X3>(p, bn_tile, ws, ws_floats, stream);
 }
 
 }  // namespace peanut

@@ -50,8 +50,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // PACK = rows of one packed weight tile (the layer's bn_tile: 128 or 64); the n-tile of the kernel may be wider (256 = two
 // packed tiles) or narrower (64 rows of a 128-row packed tile)
-template <int BM, int BN, int WM, int WN, int NP, int PACK>
+template <int BM, int BN, int WM, int WN, int KIND, int PACK>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams p) {
+  constexpr int NP = rs_pieces(KIND);
   constexpr int NT = 64 * WM * WN, NW = WM * WN, STAGES = 3;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   constexpr int ER = BM / EP;
   constexpr int SMEM_BYTES = (STAGES * STAGE > ER * CS * 4) ? STAGES * STAGE : ER * CS * 4;
   static_assert(TM % 32 == 0 && TN % 32 == 0 && (NP == 2 || NP == 3) && PER_WAVE <= 6, "tile configuration");
+  static_assert(KIND == RS_BF16X3 || KIND == RS_BF16X6 || KIND == RS_FP16X3, "emulation kind");
   static_assert(BN % PACK == 0 || PACK % BN == 0, "the n-tile is whole packed weight tiles, or a whole fraction of one");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM_BYTES];
 
@@ -175,23 +177,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
     _Pragma("unroll") for (int t = 0; t < MI; ++t) {                                                              \
       const f32x4 v0 = *reinterpret_cast<const f32x4*>((cur) + a_off0 + t * 32 * 64);                             \
       const f32x4 v1 = *reinterpret_cast<const f32x4*>((cur) + a_off1 + t * 32 * 64);                             \
-      split_frag<NP>(v0, v1, ap[t]);                                                                              \
+      split_frag<KIND>(v0, v1, ap[t]);                                                                              \
     }                                                                                                             \
     _Pragma("unroll") for (int q = 0; q < NP; ++q)                                                                \
       _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                              \
-        bf[q][u] = *reinterpret_cast<const bf16x8*>((cur) + q * (BN * 32) + b_row + u * 32 * 32);                 \
+        bf[q][u] = *reinterpret_cast<const u32x4*>((cur) + q * (BN * 32) + b_row + u * 32 * 32);                  \
   }
 #define RS_MFMA_ROWS(T0, T1)                                                                                      \
   _Pragma("unroll") for (int t = (T0); t < (T1); ++t)                                                             \
     _Pragma("unroll") for (int u = 0; u < NI; ++u) {                                                              \
       if constexpr (NP == 3) {                                                                                    \
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][2], bf[0][u], acc[t][u], 0, 0, 0);              \
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[2][u], acc[t][u], 0, 0, 0);              \
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][1], bf[1][u], acc[t][u], 0, 0, 0);              \
+        acc[t][u] = mfma_pieces<KIND>(ap[t][2], bf[0][u], acc[t][u]);                                        \
+        acc[t][u] = mfma_pieces<KIND>(ap[t][0], bf[2][u], acc[t][u]);                                        \
+        acc[t][u] = mfma_pieces<KIND>(ap[t][1], bf[1][u], acc[t][u]);                                        \
       }                                                                                                           \
-      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][1], bf[0][u], acc[t][u], 0, 0, 0);                \
-      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[1][u], acc[t][u], 0, 0, 0);                \
-      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[t][0], bf[0][u], acc[t][u], 0, 0, 0);                \
+      acc[t][u] = mfma_pieces<KIND>(ap[t][1], bf[0][u], acc[t][u]);                                          \
+      acc[t][u] = mfma_pieces<KIND>(ap[t][0], bf[1][u], acc[t][u]);                                          \
+      acc[t][u] = mfma_pieces<KIND>(ap[t][0], bf[0][u], acc[t][u]);                                          \
     }
   // the next k-tile must have landed; the one just requested may stay in flight across the barrier
 #define RS_NEXT_TILE_BARRIER(more)                                  \
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   ResPrefetch rp;
   rp.on = false;
   int o_cur = 0, o_fill = 2 * STAGE, o_mid = STAGE;
-  bf16x8 ap[MI][NP], bf[NP][NI];
+  u32x4 ap[MI][NP], bf[NP][NI];
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* const cur = smem + o_cur;
     const bool more = kt + 2 < nk;
@@ -233,36 +235,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   conv_epilogue<BM, BN, WM, WN, EP, NT>(p, wk, acc, reinterpret_cast<float*>(smem), m0, n0, NW < 8 ? &rp : nullptr);
 }
 
-template <int BM, int BN, int WM, int WN, int NP, int PACK>
+template <int BM, int BN, int WM, int WN, int KIND, int PACK>
 int launch_rs_t(ConvKParams p, float* ws, size_t ws_floats, hipStream_t stream) {
   static SlotCache slots;
   p.ntiles = (p.cout + BN - 1) / BN;                // n-tiles of THIS kernel (decode_work)
   if (p.mt_per_group) p.mt_per_group = p.mt_per_group * 128 / BM;   // BM-row tiles per weight group
-  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, NP, PACK>), BM, BN, 64 * WM * WN>(
-      &gemm_rs_kernel<BM, BN, WM, WN, NP, PACK>, p, ws, ws_floats, stream, &slots);
+  return launch_with_tail_split<decltype(&gemm_rs_kernel<BM, BN, WM, WN, KIND, PACK>), BM, BN, 64 * WM * WN>(
+      &gemm_rs_kernel<BM, BN, WM, WN, KIND, PACK>, p, ws, ws_floats, stream, &slots);
 }
 
 
 }  // namespace
 
-// bytes of the pre-split weights of a 1x1 layer: [n-tile][k-tile of 16][plane][bn_tile][16 bf16]
+// bytes of the pre-split weights of a 1x1 layer: [n-tile][k-tile of 16][plane][bn_tile][16 pieces of 16 bits];
+// planes = the emulation kind (rs_common.h: RS_BF16X3 / RS_BF16X6 / RS_FP16X3)
 size_t sx_packed_bytes(int cin_pad, int cout, int bn_tile, int planes) {
   const size_t ntiles = (cout + bn_tile - 1) / bn_tile;
-  return ntiles * (size_t)(cin_pad / 16) * planes * bn_tile * 32;
+  return ntiles * (size_t)(cin_pad / 16) * rs_pieces(planes) * bn_tile * 32;
 }
 
-// w: [cout][cin_real] fp32 (a 1x1 conv's OIHW weights, or one Winograd position of U)
-void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, void* out) {
+float sx_pack_scale(const float* w, size_t n, int planes) { return rs_pack_scale(w, n, planes); }
+
+// w: [cout][cin_real] fp32 (a 1x1 conv's OIHW weights, or one Winograd position of U); pieces of w * wscale
+void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn_tile, int planes, float wscale, void* out) {
   unsigned short* o = static_cast<unsigned short*>(out);
-  const int ntiles = (cout + bn_tile - 1) / bn_tile, nkt = cin_pad / 16;
+  const int ntiles = (cout + bn_tile - 1) / bn_tile, nkt = cin_pad / 16, np = rs_pieces(planes);
   for (int nt = 0; nt < ntiles; ++nt)
     for (int kt = 0; kt < nkt; ++kt) {
-      unsigned short* tile = o + ((size_t)nt * nkt + kt) * planes * bn_tile * 16;
+      unsigned short* tile = o + ((size_t)nt * nkt + kt) * np * bn_tile * 16;
       for (int r = 0; r < bn_tile; ++r)
         for (int e = 0; e < 16; ++e) {
           const int n = nt * bn_tile + r, c = kt * 16 + e;
-          float v = (n < cout && c < cin_real) ? w[(size_t)n * cin_real + c] : 0.f;
-          for (int q = 0; q < planes; ++q) tile[((size_t)q * bn_tile + r) * 16 + e] = bf16_piece_host(v);
+          float v = (n < cout && c < cin_real) ? w[(size_t)n * cin_real + c] * wscale : 0.f;
+          for (int q = 0; q < np; ++q) tile[((size_t)q * bn_tile + r) * 16 + e] = rs_piece_host(v, planes);
         }
     }
 }
@@ -287,29 +292,38 @@ bool gemm_rs_uses_64(int cout, long long M, int bn_tile, int cin) {
   return cout % 64 == 0 && cin <= max_k && t128 < max_tiles;
 }
 
+// family names: gemm_rs6_* (bf16, six products), gemm_rs3_* (bf16, three), gemm_rs3h_* (fp16, three)
 const char* gemm_rs_kernel_name(int cout, long long M, int mt_per_group, int bn_tile, int cin, int planes) {
-  if (gemm_rs_uses_64(cout, M, bn_tile, cin)) return planes == 3 ? "gemm_rs6_64x64" : "gemm_rs3_64x64";
-  if (gemm_rs_uses_256(cout, M, mt_per_group, bn_tile, cin)) return planes == 3 ? "gemm_rs6_256x256" : "gemm_rs3_256x256";
-  if (bn_tile == 128) return planes == 3 ? "gemm_rs6_128x128" : "gemm_rs3_128x128";
-  return planes == 3 ? "gemm_rs6_128x64" : "gemm_rs3_128x64";
+  static const char* const names[3][4] = {{"gemm_rs3_64x64", "gemm_rs3_256x256", "gemm_rs3_128x128", "gemm_rs3_128x64"},
+                                          {"gemm_rs6_64x64", "gemm_rs6_256x256", "gemm_rs6_128x128", "gemm_rs6_128x64"},
+                                          {"gemm_rs3h_64x64", "gemm_rs3h_256x256", "gemm_rs3h_128x128", "gemm_rs3h_128x64"}};
+  const int k = planes - 2;
+  if (k < 0 || k > 2) return "gemm_rs?";
+  if (gemm_rs_uses_64(cout, M, bn_tile, cin)) return names[k][0];
+  if (gemm_rs_uses_256(cout, M, mt_per_group, bn_tile, cin)) return names[k][1];
+  return names[k][bn_tile == 128 ? 2 : 3];
 }
+
+namespace {
+template <int KIND>
+int launch_gemm_rs_kind(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
+  if (gemm_rs_uses_64(p.cout, p.M, bn_tile, p.c1 + p.c2))
+    return bn_tile == 128 ? launch_rs_t<64, 64, 2, 2, KIND, 128>(p, ws, ws_floats, stream) : launch_rs_t<64, 64, 2, 2, KIND, 64>(p, ws, ws_floats, stream);
+  if (gemm_rs_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2)) return launch_rs_t<256, 256, 4, 2, KIND, 128>(p, ws, ws_floats, stream);
+  if (bn_tile == 128) return launch_rs_t<128, 128, 2, 2, KIND, 128>(p, ws, ws_floats, stream);
+  return launch_rs_t<128, 64, 2, 2, KIND, 64>(p, ws, ws_floats, stream);
+}
+}  // namespace
 
 // p.x / p.x2: fp32 A (two sources allowed), p.w: S-packed weights (bn_tile rows per packed tile), p.nkt = cin / 16
 int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream) {
   if (p.ntaps != 1 || p.pad != 0 || p.c1 % 16 || p.c2 % 16 || (p.c2 && p.stride != 1) || (bn_tile != 128 && bn_tile != 64) ||
-      (planes != 2 && planes != 3))
+      planes < RS_BF16X3 || planes > RS_FP16X3)
     return fail(-2, "launch_gemm_rs: needs a pointwise layer with 16-channel granularity and 64- or 128-row weight tiles");
   note_kernel(gemm_rs_kernel_name(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, planes));
-  if (gemm_rs_uses_64(p.cout, p.M, bn_tile, p.c1 + p.c2)) {
-    if (bn_tile == 128)
-      return planes == 3 ? launch_rs_t<64, 64, 2, 2, 3, 128>(p, ws, ws_floats, stream) : launch_rs_t<64, 64, 2, 2, 2, 128>(p, ws, ws_floats, stream);
-    return planes == 3 ? launch_rs_t<64, 64, 2, 2, 3, 64>(p, ws, ws_floats, stream) : launch_rs_t<64, 64, 2, 2, 2, 64>(p, ws, ws_floats, stream);
-  }
-  if (gemm_rs_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2))
-    return planes == 3 ? launch_rs_t<256, 256, 4, 2, 3, 128>(p, ws, ws_floats, stream) : launch_rs_t<256, 256, 4, 2, 2, 128>(p, ws, ws_floats, stream);
-  if (bn_tile == 128)
-    return planes == 3 ? launch_rs_t<128, 128, 2, 2, 3, 128>(p, ws, ws_floats, stream) : launch_rs_t<128, 128, 2, 2, 2, 128>(p, ws, ws_floats, stream);
-  return planes == 3 ? launch_rs_t<128, 64, 2, 2, 3, 64>(p, ws, ws_floats, stream) : launch_rs_t<128, 64, 2, 2, 2, 64>(p, ws, ws_floats, stream);
+  if (planes == RS_BF16X6) return launch_gemm_rs_kind<RS_BF16X6>(p, bn_tile, ws, ws_floats, stream);
+  if (planes == RS_FP16X3) return launch_gemm_rs_kind<RS_FP16X3>(p, bn_tile, ws, ws_floats, stream);
+  return launch_gemm_rs_kind<RS_BF16X3>(p, bn_tile, ws, ws_floats, stream);
 }
 
 }  // namespace peanut

@@ -98,8 +98,14 @@ struct ConvLayer {
   size_t wino_group_bytes = 0;
 };
 
-// bf16 pieces per value in the emulated-fp32 modes (gemm_rs.hip; 0: fp32 MFMA mode)
-inline int rs_planes_of(int precision) { return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : 0); }
+// emulation kind of a precision mode (rs_common.h: 2 = bf16x3, 3 = bf16x6, 4 = fp16x3; 0: fp32 MFMA mode)
+inline int rs_planes_of(int precision) {
+  return precision == PEANUT_PREC_BF16X6 ? 3 : (precision == PEANUT_PREC_BF16X3 ? 2 : (precision == PEANUT_PREC_FP16X3 ? 4 : 0));
+}
+inline bool precision_known(int precision) { return precision == PEANUT_PREC_FP32 || rs_planes_of(precision) != 0; }
+inline int precision_of_planes(int planes) {
+  return planes == 3 ? PEANUT_PREC_BF16X6 : (planes == 2 ? PEANUT_PREC_BF16X3 : (planes == 4 ? PEANUT_PREC_FP16X3 : PEANUT_PREC_FP32));
+}
 // PEANUT_RS_CONV=0 keeps the non-pointwise layers of the emulated modes on the fp32 MFMA kernel (A/B measurements)
 inline bool rs_conv_enabled() {
   static const bool on = [] { const char* e = getenv("PEANUT_RS_CONV"); return !(e && e[0] == '0'); }();
@@ -122,6 +128,7 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   // emulated-fp32 modes: the pointwise layers run on gemm_rs.hip (every other layer stays on the fp32 MFMA kernels)
   d.rs = 0;
   d.s_planes = 0;
+  d.s_alpha = 1.f;
   if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) {
     d.rs = 1;
     d.s_planes = rs_planes_of(precision);
@@ -153,8 +160,10 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   if (d.rs) {
     std::vector<unsigned char> ps(d.rs == 2 ? sx_conv_packed_bytes(cin_pad, cout, kh, kw, d.bn_tile, d.s_planes)
                                             : sx_packed_bytes(cin_pad, cout, d.bn_tile, d.s_planes));
-    if (d.rs == 2) pack_weights_sx_conv(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.s_planes, ps.data());
-    else pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, ps.data());
+    const float wscale = sx_pack_scale(w_oihw, (size_t)cout * cin * kh * kw, d.s_planes);
+    d.s_alpha = 1.f / wscale;                                                       // a power of two: exact
+    if (d.rs == 2) pack_weights_sx_conv(w_oihw, cout, cin, cin_pad, kh, kw, d.bn_tile, d.s_planes, wscale, ps.data());
+    else pack_weights_sx(w_oihw, cout, cin, cin_pad, d.bn_tile, d.s_planes, wscale, ps.data());
     if ((rc = L.w_s.ensure(ps.size()))) return rc;
     PEANUT_HIP_CHECK(hipMemcpy(L.w_s.p, ps.data(), ps.size(), hipMemcpyHostToDevice));
     d.w_s = L.w_s.p;
@@ -178,6 +187,7 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
   g.rs = 0;
   g.s_planes = 0;
+  g.s_alpha = 1.f;
   if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, 1, 1, 0)) {   // see upload_conv
     g.rs = 1;
     g.s_planes = rs_planes_of(precision);
@@ -208,8 +218,10 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   if (g.rs) {
     const size_t gb = sx_packed_bytes(cin_pad, cout, g.bn_tile, g.s_planes);
     std::vector<unsigned char> ps(36 * gb);
+    const float wscale = sx_pack_scale(U.data(), U.size(), g.s_planes);     // one scale for the 36 positions (one launch)
+    g.s_alpha = 1.f / wscale;
     for (int pos = 0; pos < 36; ++pos)
-      pack_weights_sx(U.data() + (size_t)pos * cout * cin, cout, cin, cin_pad, g.bn_tile, g.s_planes, ps.data() + pos * gb);
+      pack_weights_sx(U.data() + (size_t)pos * cout * cin, cout, cin, cin_pad, g.bn_tile, g.s_planes, wscale, ps.data() + pos * gb);
     if ((rc = L.wino_w_s.ensure(ps.size()))) return rc;
     PEANUT_HIP_CHECK(hipMemcpy(L.wino_w_s.p, ps.data(), ps.size(), hipMemcpyHostToDevice));
     g.w_s = L.wino_w_s.p;

@@ -218,7 +218,7 @@ std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, c
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
 std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long long M = 0, int mt_per_group = 0) {
-  if (d.rs == 2) return std::string(d.s_planes == 3 ? "conv_rs6_128x" : "conv_rs3_128x") + std::to_string(d.bn_tile);
+  if (d.rs == 2) return std::string(d.s_planes == 3 ? "conv_rs6_128x" : (d.s_planes == 4 ? "conv_rs3h_128x" : "conv_rs3_128x")) + std::to_string(d.bn_tile);
   if (d.rs) return gemm_rs_kernel_name(d.cout, M, mt_per_group, d.bn_tile, d.cin, d.s_planes);
   if (d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
     return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
@@ -551,7 +551,7 @@ extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
-int peanut_abi_version(void) { return 8; }
+int peanut_abi_version(void) { return 9; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 #ifndef PEANUT_SOURCE_HASH
 #define PEANUT_SOURCE_HASH ""
@@ -564,8 +564,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
   if (cfg->in_channels < 1 || cfg->num_classes < 1 || cfg->num_classes > 32)
     return fail(PEANUT_EINVAL, "in_channels >= 1 and 1 <= num_classes <= 32 required");
   if (cfg->head_channels % 32) return fail(PEANUT_EINVAL, "head_channels must be a multiple of 32");
-  if (cfg->precision != PEANUT_PREC_FP32 && cfg->precision != PEANUT_PREC_BF16X3 && cfg->precision != PEANUT_PREC_BF16X6)
-    return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,BF16X6}");
+  if (!precision_known(cfg->precision)) return fail(PEANUT_EINVAL, "precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT)
     return fail(PEANUT_EINVAL, "conv_algo must be PEANUT_ALGO_{AUTO,DIRECT}");
   auto h = std::make_unique<peanut_pred>();
@@ -811,8 +810,7 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
   if (!out || !w) return fail(PEANUT_EINVAL, "peanut_conv_create: null argument");
   if (cout < 1 || cin < 1 || kh < 1 || kw < 1 || stride < 1 || dil < 1 || pad < 0)
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
-  if (precision != PEANUT_PREC_FP32 && precision != PEANUT_PREC_BF16X3 && precision != PEANUT_PREC_BF16X6)
-    return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
+  if (!precision_known(precision)) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
   auto c = std::make_unique<peanut_conv>();
   c->L.name = "conv";
   if (conv_algo != PEANUT_ALGO_AUTO && conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "peanut_conv_create: bad conv_algo");
@@ -831,7 +829,7 @@ void peanut_conv_destroy(peanut_conv_t* c) { delete c; }
 int peanut_conv_precision(peanut_conv_t* c) {
   if (!c) return PEANUT_EINVAL;
   const ConvDesc& d = (c->L.has_wino && c->L.wino.rs) ? c->L.wino : c->L.d;
-  if (d.rs) return d.s_planes == 3 ? PEANUT_PREC_BF16X6 : PEANUT_PREC_BF16X3;
+  if (d.rs) return precision_of_planes(d.s_planes);
   return PEANUT_PREC_FP32;
 }
 

@@ -299,7 +299,7 @@ void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
 void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
   ROp op;
   op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = L->d.rs ? std::string(L->d.rs == 2 ? "conv_rs" : "gemm_rs") + (L->d.s_planes == 3 ? "6" : "3")
+  op.kernel = L->d.rs ? std::string(L->d.rs == 2 ? "conv_rs" : "gemm_rs") + (L->d.s_planes == 3 ? "6" : (L->d.s_planes == 4 ? "3h" : "3"))
                       : "conv_igemm_128x" + std::to_string(L->d.bn_tile) + "x" + std::to_string(L->d.bk);
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
@@ -444,8 +444,7 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
   if (cfg->depth != 50 && cfg->depth != 101 && cfg->depth != 152) return fail(PEANUT_EINVAL, "rcnn: depth must be 50/101/152");
   if (cfg->fpn_out % 32 || cfg->num_anchors < 1 || cfg->min_size < 32 || cfg->size_divisibility != 32)
     return fail(PEANUT_EINVAL, "rcnn: unsupported configuration");
-  if (cfg->precision != PEANUT_PREC_FP32 && cfg->precision != PEANUT_PREC_BF16X3 && cfg->precision != PEANUT_PREC_BF16X6)
-    return fail(PEANUT_EINVAL, "rcnn: precision must be PEANUT_PREC_{FP32,BF16X3,BF16X6}");
+  if (!precision_known(cfg->precision)) return fail(PEANUT_EINVAL, "rcnn: precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "rcnn: bad conv_algo");
   auto h = std::make_unique<peanut_rcnn>();
   h->cfg = *cfg;

@@ -163,7 +163,8 @@ def test_pw256_kernel_grouped_winograd_gemm():
 
 
 # ---- register-split emulated-fp32 GEMM (csrc/gemm_rs.hip): fp32 activations, bf16 pieces peeled off in registers ----
-RS_TOL = {"bf16x6": 2e-5, "bf16x3": 1e-4}     # bf16x6: fp32-class, held to the fp32 kernels' own tolerance
+RS_TOL = {"bf16x6": 2e-5, "fp16x3": 2e-5, "bf16x3": 1e-4}     # bf16x6 / fp16x3: fp32-class, held to the fp32 kernels' own tolerance
+RS_TAG = {"bf16x6": "rs6_", "bf16x3": "rs3_", "fp16x3": "rs3h_"}   # kernel family prefix after "gemm_" / "conv_"
 
 RS_CASES = [
     # (B, H, W, cin, cout, stride, relu, residual), kernel family without the piece count
@@ -188,15 +189,16 @@ RS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3", "fp16x3"])
 @pytest.mark.parametrize("case,family", RS_CASES, ids=lambda c: "x".join(map(str, c[:6])) if isinstance(c, tuple) else c)
 def test_register_split_gemm_matches_torch(case, family, precision):
-    _pw_case(case, precision, ("gemm_rs6_" if precision == "bf16x6" else "gemm_rs3_") + family, RS_TOL[precision])
+    _pw_case(case, precision, "gemm_" + RS_TAG[precision] + family, RS_TOL[precision])
 
 
 @pytest.mark.parametrize("case", [(2, 30, 30, 64, 64, 256), (1, 23, 17, 256, 512, 1024), (8, 64, 64, 512, 1024, 512),
                                   (1, 9, 9, 32, 2048, 128), (1, 9, 9, 16, 16, 64)], ids=lambda c: "x".join(map(str, c)))
-def test_register_split_gemm_two_sources(case):
+@pytest.mark.parametrize("precision", ["bf16x6", "fp16x3"])
+def test_register_split_gemm_two_sources(case, precision):
     """gemm_rs reading its A k-tiles from two fp32 tensors (fused conv3 + downsample layers), incl. a split-K launch whose
     parts start on either side of the source switch and the switch after the very first k-tile."""
     from peanut_amd.ops import FusedConv
@@ -206,18 +208,19 @@ def test_register_split_gemm_two_sources(case):
     w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
     shift = _rand((cout,), g, 0.1)
     ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) + shift[None, :, None, None])
-    conv = FusedConv(w, None, shift, relu=True, precision="bf16x6")
+    conv = FusedConv(w, None, shift, relu=True, precision=precision)
     y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
-    assert _last_kernel().startswith("gemm_rs6_"), _last_kernel()
+    assert _last_kernel().startswith("gemm_" + RS_TAG[precision]), _last_kernel()
     err = (y - ref).abs()
     assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
 
 @pytest.mark.parametrize("case", [(2, 88, 88, 512, 512, 1), (1, 15, 15, 512, 512, 4), (1, 15, 13, 256, 320, 1)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_register_split_winograd(case):
-    """Winograd form with the position GEMMs on gemm_rs (fp32 transforms, bf16x6 products): the first case pads to whole
-    256-row tiles per position and runs the 256 x 256 kernel grouped."""
+@pytest.mark.parametrize("precision", ["bf16x6", "fp16x3"])
+def test_register_split_winograd(case, precision):
+    """Winograd form with the position GEMMs on gemm_rs (fp32 transforms, bf16x6 / fp16x3 products): the first case pads to
+    whole 256-row tiles per position and runs the 256 x 256 kernel grouped."""
     from peanut_amd.ops import FusedConv
     B, H, W, cin, cout, d = case
     g = torch.Generator().manual_seed(sum(case))
@@ -225,10 +228,10 @@ def test_register_split_winograd(case):
     w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
     res = _rand((B, cout, H, W), g)
     ref = F.relu(F.conv2d(x, w, None, padding=d, dilation=d) + res)
-    conv = FusedConv(w, None, None, padding=d, dilation=d, relu=True, precision="bf16x6")
+    conv = FusedConv(w, None, None, padding=d, dilation=d, relu=True, precision=precision)
     y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda())
-    want = {(2, 88, 88, 512, 512, 1): "gemm_rs6_256x256", (1, 15, 15, 512, 512, 4): "gemm_rs6_128x128", (1, 15, 13, 256, 320, 1): "gemm_rs6_64x64"}
-    assert _last_kernel() == want[case], _last_kernel()
+    want = {(2, 88, 88, 512, 512, 1): "256x256", (1, 15, 15, 512, 512, 4): "128x128", (1, 15, 13, 256, 320, 1): "64x64"}
+    assert _last_kernel() == "gemm_" + RS_TAG[precision] + want[case], _last_kernel()
     err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
     assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
@@ -248,7 +251,7 @@ def test_conv_transpose_detecting():
     assert torch.equal(y, ref)
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3", "fp16x3"])
 @pytest.mark.parametrize("case", [c for c in CASES if c[5] == 3], ids=lambda c: "x".join(map(str, c[:9])))
 def test_register_split_conv_matches_torch(case, precision):
     """conv_rs.hip: 3x3 (stride 1 / 2, dilation 1 / 2 / 4, 14 -> 16 padded channels, cout 32 / 64 / 128 / 256 / 512) as an
@@ -266,12 +269,12 @@ def test_register_split_conv_matches_torch(case, precision):
     conv = FusedConv(w, scale, shift, stride=s, padding=p, dilation=d, relu=relu, precision=precision, conv_algo="direct")
     y = conv(to_nhwc_padded(x.cuda(), round_up(cin, 16))).permute(0, 3, 1, 2).cpu()
     bn = 128 if cout >= 128 else (64 if cout > 32 else 32)
-    assert _last_kernel() == ("conv_rs6_128x" if precision == "bf16x6" else "conv_rs3_128x") + str(bn), _last_kernel()
+    assert _last_kernel() == "conv_" + RS_TAG[precision] + "128x" + str(bn), _last_kernel()
     err = (y - ref).abs()
     assert bool((err <= RS_TOL[precision] * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3", "fp16x3"])
 def test_emulated_modes_report_what_they_run(precision):
     """peanut_conv_precision tells which arithmetic a handle really runs: a narrow 1x1 (cout < 64: conv_seg) stays exact
     fp32 -- bit-identical to the fp32 handle -- in every mode; wider pointwise layers and 3x3 convs report the mode."""
@@ -288,6 +291,43 @@ def test_emulated_modes_report_what_they_run(precision):
         assert _lib.load().peanut_conv_precision(c._h) == _lib.PRECISIONS[precision]
 
 
+@pytest.mark.parametrize("wmag", [2.0 ** -30, 2.0 ** -12, 1.0, 2.0 ** 20])
+def test_fp16_pieces_do_not_depend_on_the_weights_range(wmag):
+    """fp16x3: a layer's weights are scaled by a power of two before they are split into fp16 pieces and the scale is
+    undone in the epilogue, so weights of ANY magnitude (far outside fp16's range here) give the results of weights of
+    magnitude 1, times the magnitude -- bit for bit."""
+    from peanut_amd.ops import FusedConv
+    g = torch.Generator().manual_seed(11)
+    x = _rand((2, 20, 20, 256), g).cuda()
+    w = _rand((128, 256, 1, 1), g, (2.0 / 256) ** 0.5)
+    base = FusedConv(w, None, None, precision="fp16x3")(x)
+    assert _last_kernel().startswith("gemm_rs3h_"), _last_kernel()
+    assert torch.equal(FusedConv(w * wmag, None, None, precision="fp16x3")(x), base * wmag)
+    w3 = _rand((64, 256, 3, 3), g, (2.0 / (256 * 9)) ** 0.5)
+    for algo in ("direct", "auto"):
+        b3 = FusedConv(w3, None, None, padding=1, precision="fp16x3", conv_algo=algo)(x)
+        assert torch.equal(FusedConv(w3 * wmag, None, None, padding=1, precision="fp16x3", conv_algo=algo)(x), b3 * wmag), algo
+
+
+def test_fp16_pieces_activation_range_is_loud():
+    """fp16x3 keeps fp32 accuracy for activations inside fp16's exponent range and answers NaN -- never a wrong finite
+    number -- when one leaves it (|x| >= 65520: the high piece is inf, the low one -inf)."""
+    from peanut_amd.ops import FusedConv
+    g = torch.Generator().manual_seed(12)
+    x = _rand((1, 16, 16, 128), g)
+    w = _rand((64, 128, 1, 1), g, (2.0 / 128) ** 0.5)
+    conv = FusedConv(w, None, None, precision="fp16x3")
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double()).permute(0, 2, 3, 1)
+    floor = 2.0 ** -25 * float(w.abs().sum((1, 2, 3)).max())   # tiny values: low piece subnormal, |error| <= 2^-25 per value
+    for mag in (2.0 ** -20, 1.0, 1.0e4):
+        y = conv((x * mag).cuda()).cpu().double()
+        assert float((y - ref * mag).abs().max()) <= 2e-5 * mag * float(ref.abs().max()) + floor, mag
+    xb = x.clone()
+    xb[0, 3, 5, 7] = 7.0e4
+    y = conv(xb.cuda()).cpu()
+    assert bool(torch.isnan(y[0, 3, 5]).all()) and bool(torch.isfinite(y[0, 3, 4]).all())
+
+
 WINO_CASES = [
     # (B, H, W, cin, cout, dil, relu, residual)
     (2, 16, 16, 256, 256, 1, True, False),     # whole 4x4 tiles
@@ -300,7 +340,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-4), ("bf16x6", 1.5e-4), ("bf16x3", 1.5e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-4), ("bf16x6", 1.5e-4), ("fp16x3", 1.5e-4), ("bf16x3", 1.5e-3)])
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c[:6])))
 def test_winograd_conv_matches_torch(case, precision, tol):
     """conv_algo='auto' on a stride-1 3x3 layer with >= 256 input channels = Winograd F(4x4,3x3) (winograd.hip):

@@ -145,11 +145,12 @@ def test_golden_vectors(model_and_sd, golden_dir):
         assert err <= TOL, f"{case}: max err {err:.3e}"
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("bf16x6", 5e-5)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-4), ("bf16x6", 5e-5), ("fp16x3", 5e-5)])
 def test_split_precision_forward_within_contract(precision, tol, golden_dir):
     """The emulated modes (csrc/gemm_rs.hip) must stay inside the north_star bound (1e-3) with margin, on config 1
     (240x240 golden vector from the reference).  bf16x3 = two bf16 pieces per value, three MFMA products per fp32 product;
-    bf16x6 (three pieces, six products) is an fp32 emulation: it is held to the fp32 path's own level."""
+    bf16x6 (three pieces, six products) and fp16x3 (two fp16 pieces, three products) are fp32 emulations: they are held
+    to the fp32 path's own level."""
     from peanut_amd.prediction import PEANUT_Prediction_Model
     from peanut_amd.weights import PredCfg, make_seeded_state_dict
     z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
@@ -320,6 +321,8 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
                                           "bottleneck.conv[x][wino_gemm]"]),
         "bf16x6": ("gemm_rs6_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
                                         "layer4.1.conv2[wino_gemm]", "bottleneck.conv[x][wino_gemm]"]),
+        "fp16x3": ("gemm_rs3h_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
+                                         "layer4.1.conv2[wino_gemm]", "bottleneck.conv[x][wino_gemm]"]),
     }
     for precision, (family, layers) in want.items():
         mm = m if precision == "fp32" else PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
@@ -337,7 +340,7 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
             del mm
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x3"])
 @pytest.mark.parametrize("name", ["align_corners", "pool124_k9_c20", "os16_no_contract"])
 def test_variant_model_configs_match_reference_goldens(golden_dir, name, precision):
     """The cfg fields the inference path reads (nav/pred_model_cfg.py:2-42) at values other than the committed ones:
@@ -362,7 +365,7 @@ def test_distance_to_the_fp64_reference(golden_dir):
     """How far is each arithmetic mode from the EXACT result?  tests/golden/pspnet_fp64_golden.npz holds the logits of
     the reference's own model files run in float64 (oracle/gen_golden.py: gen_pspnet_fp64); the reference's fp32 CPU
     path is 5.4-5.7e-6 away from them.  'fp32-class' = the same order of magnitude: asserted for the fp32 MFMA modes
-    and for the bf16x6 emulation; bf16x3 is reported (and bounded)."""
+    and for the bf16x6 and fp16x3 emulations; bf16x3 is reported (and bounded)."""
     from peanut_amd.prediction import PEANUT_Prediction_Model
     from peanut_amd.weights import PredCfg, make_seeded_state_dict
     z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
@@ -371,7 +374,7 @@ def test_distance_to_the_fp64_reference(golden_dir):
     sd = make_seeded_state_dict(cfg, 0)
     dist = {}
     for label, kw in (("fp32 direct", dict(conv_algo="direct")), ("fp32 winograd (default)", {}), ("bf16x6", dict(precision="bf16x6")),
-                      ("bf16x3", dict(precision="bf16x3"))):
+                      ("fp16x3", dict(precision="fp16x3")), ("bf16x3", dict(precision="bf16x3"))):
         m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
         worst = 0.0
         for case in ("b2_96", "odd_100"):
@@ -385,6 +388,7 @@ def test_distance_to_the_fp64_reference(golden_dir):
           " | ".join(f"{k} {v:.2e}" for k, v in dist.items()))
     assert dist["fp32 direct"] <= 2e-5 and dist["fp32 winograd (default)"] <= 4e-5 and dist["bf16x6"] <= 3e-5
     assert dist["bf16x6"] <= 1.5 * dist["fp32 winograd (default)"]     # the emulation is not the less accurate of the two
+    assert dist["fp16x3"] <= 3e-5 and dist["fp16x3"] <= 1.5 * dist["fp32 winograd (default)"]
     assert dist["bf16x3"] <= 5e-4
 
 
@@ -398,7 +402,7 @@ def test_golden_c25_240(golden_dir):
     sd = make_seeded_state_dict(cfg, int(z["cin25_240/weight_seed"]))
     x = torch.from_numpy(z["cin25_240/input"].astype(np.float32)).cuda()
     ref = torch.from_numpy(z["cin25_240/logits"])
-    for kw, tol in ((dict(), TOL), (dict(conv_algo="direct"), 2e-5), (dict(precision="bf16x6"), TOL)):
+    for kw, tol in ((dict(), TOL), (dict(conv_algo="direct"), 2e-5), (dict(precision="bf16x6"), TOL), (dict(precision="fp16x3"), TOL)):
         m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
         err = (m.get_prediction_batch(x, apply_sigmoid=False).cpu() - ref).abs().max().item()
         assert err <= tol, f"{kw}: {err:.3e}"
@@ -458,7 +462,7 @@ def test_distance_to_the_fp64_reference_at_480(golden_dir):
     sd = make_seeded_state_dict(cfg, 0)
     dist = {}
     for label, kw in (("fp32 direct", dict(conv_algo="direct")), ("fp32 winograd (default)", {}), ("bf16x6", dict(precision="bf16x6")),
-                      ("bf16x3", dict(precision="bf16x3"))):
+                      ("fp16x3", dict(precision="fp16x3")), ("bf16x3", dict(precision="bf16x3"))):
         m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
         got = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu().numpy()[:, :, 1::4, 2::4]
         dist[label] = float(np.abs(got.astype(np.float64) - ref64).max())
@@ -469,6 +473,7 @@ def test_distance_to_the_fp64_reference_at_480(golden_dir):
           " | ".join(f"{k} {v:.2e}" for k, v in dist.items()))
     assert dist["fp32 direct"] <= 3e-5 and dist["fp32 winograd (default)"] <= 5e-5 and dist["bf16x6"] <= 4e-5
     assert dist["bf16x6"] <= 1.5 * dist["fp32 winograd (default)"] + 2e-6
+    assert dist["fp16x3"] <= 4e-5 and dist["fp16x3"] <= 1.5 * dist["fp32 winograd (default)"] + 2e-6
     assert dist["bf16x3"] <= 5e-4
 
 
