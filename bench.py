@@ -148,12 +148,13 @@ FAMILY_KERNEL = {
     "conv_pw_glds_128x128": "conv_pw_glds_kernel<128, 2, 2>",
     "conv_pw_glds_128x64": "conv_pw_glds_kernel<64, 2, 2>",
     "conv_pw_glds_128x32": "conv_pw_glds_kernel<32, 4, 1>",
-    "gemm_rs6_256x256": "gemm_rs_kernel<256, 256, 4, 2, 3>",
-    "gemm_rs3_256x256": "gemm_rs_kernel<256, 256, 4, 2, 2>",
-    "gemm_rs6_128x128": "gemm_rs_kernel<128, 128, 2, 2, 3>",
-    "gemm_rs3_128x128": "gemm_rs_kernel<128, 128, 2, 2, 2>",
-    "gemm_rs3h_256x256": "gemm_rs_kernel<256, 256, 4, 2, 4>",
-    "gemm_rs3h_128x128": "gemm_rs_kernel<128, 128, 2, 2, 4>",
+    # gemm_rs_kernel<BM, BN, WM, WN, KIND, PACK>: matched up to the emulation kind (3 = bf16x6, 2 = bf16x3, 4 = fp16x3)
+    "gemm_rs6_256x256": "gemm_rs_kernel<256, 256, 4, 2, 3,",
+    "gemm_rs3_256x256": "gemm_rs_kernel<256, 256, 4, 2, 2,",
+    "gemm_rs6_128x128": "gemm_rs_kernel<128, 128, 2, 2, 3,",
+    "gemm_rs3_128x128": "gemm_rs_kernel<128, 128, 2, 2, 2,",
+    "gemm_rs3h_256x256": "gemm_rs_kernel<256, 256, 4, 2, 4,",
+    "gemm_rs3h_128x128": "gemm_rs_kernel<128, 128, 2, 2, 4,",
 }
 
 

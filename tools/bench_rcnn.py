@@ -23,7 +23,7 @@ def main():
     cfg = RcnnCfg(score_thresh_test=0.5)
     sd = make_seeded_rcnn_state_dict(cfg, 0)
     img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device="cuda")
-    for prec in [q for q in os.environ.get("PRECS", "fp32,bf16x6,bf16x3").split(",") if q]:
+    for prec in [q for q in os.environ.get("PRECS", "fp32,bf16x6,fp16x3,bf16x3").split(",") if q]:
         m = MaskRCNN(cfg, sd, precision=prec, conv_algo=algo)
 
         def step_masks():      # instance masks materialised, then accumulated (what a caller that wants the masks pays)

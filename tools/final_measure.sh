@@ -7,9 +7,9 @@ mkdir -p $R/$OUT
 cd $R
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|max-abs|max \|GPU|final map|vs oracle|fp64|worst" > $OUT/pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 --op-table $OUT/op_table_fp32.json > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
-for m in bf16x6 bf16x3; do python bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --also "" --traffic measure --op-table $OUT/op_table_$m.json 2>/dev/null | grep "^{" ; done > $OUT/bench_modes.json
-python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --also "bf16x6" --traffic none 2>/dev/null | grep "^{" > $OUT/bench_config5.json
-for m in fp32 bf16x6; do
+for m in bf16x6 fp16x3 bf16x3; do python bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --also "" --traffic measure --op-table $OUT/op_table_$m.json 2>/dev/null | grep "^{" ; done > $OUT/bench_modes.json
+python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --also "bf16x6,fp16x3" --traffic none 2>/dev/null | grep "^{" > $OUT/bench_config5.json
+for m in fp32 bf16x6 fp16x3; do
 python bench.py --batch 1 --size 240 --precision $m --steps 50 --warmup 5 --no-cpu-baseline --also "" --traffic none --no-probe 2>/dev/null | grep "^{"
 python bench.py --batch 1 --size 720 --precision $m --steps 50 --warmup 5 --no-cpu-baseline --also "" --traffic none --no-probe 2>/dev/null | grep "^{"
 done > $OUT/bench_b1.jsonl
@@ -20,9 +20,10 @@ python tools/bench_pipeline.py --episodes 2 --frames 60 2>/dev/null | grep "^{" 
 python tools/bench_pipeline.py --episodes 2 --frames 60 --precision bf16x6 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision bf16x6 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
+python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision fp16x3 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision bf16x3 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 cd /tmp; export TMPDIR=/tmp
-for m in fp32 bf16x6; do
+for m in fp32 bf16x6 fp16x3; do
 rm -rf /tmp/fm_trace
 rocprofv3 --kernel-trace --stats -d /tmp/fm_trace -- python $R/bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --no-probe --also "" --traffic none > /tmp/fm_trace.log 2>&1
 db=$(find /tmp/fm_trace -name '*.db' | head -1); [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $R/$OUT/trace_$m.txt
@@ -33,4 +34,5 @@ db=$(find /tmp/fm_trace2 -name '*.db' | head -1); [ -n "$db" ] && python $R/tool
 cd $R
 tools/pmc_passes.sh $OUT/pmc_fp32 --precision fp32
 tools/pmc_passes.sh $OUT/pmc_bf16x6 --precision bf16x6
+tools/pmc_passes.sh $OUT/pmc_fp16x3 --precision fp16x3
 ls $OUT
