@@ -11,6 +11,13 @@ namespace peanut {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: no struct memcpy, stays in VGPRs
 
+// ReLU that lets NaN through, like torch.relu (fmaxf returns the other operand): an overflow of the fp16-piece mode, or
+// a NaN in the input, must reach the output instead of turning into a plausible zero
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ f32x4 relu_keep_nan(f32x4 v) {
+  return f32x4{relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z), relu_keep_nan(v.w)};
+}
+
 struct ConvKParams {
   const float* x;
   const float* x2;
@@ -203,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
             f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * CS + c4);
             v = v * sc + sh;
             v += rpre[i];
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.relu) v = relu_keep_nan(v);
             const size_t o = (size_t)m * p.cout + n;
             *reinterpret_cast<f32x4*>(p.y + o) = v;
           }
@@ -220,7 +227,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
         if (vec_ok) {
           if (n < p.cout) {
             if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.relu) v = relu_keep_nan(v);
             *reinterpret_cast<f32x4*>(p.y + o) = v;
           }
         } else {
@@ -229,7 +236,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
             if (n + e < p.cout) {
               float x = v[e];
               if (p.res) x += p.res[o + e];
-              if (p.relu) x = fmaxf(x, 0.f);
+              if (p.relu) x = relu_keep_nan(x);
               p.y[o + e] = x;
             }
           }
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
     if (vec_ok) {
       if (n < p.cout) {
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.relu) v = relu_keep_nan(v);
         *reinterpret_cast<f32x4*>(p.y + o) = v;
       }
     } else {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
         if (n + e < p.cout) {
           float x = v[e];
           if (p.res) x += p.res[o + e];
-          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.relu) x = relu_keep_nan(x);
           p.y[o + e] = x;
         }
       }

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
         const int ix = ox * 2 - 1 + dx;
         if ((unsigned)ix >= (unsigned)W) continue;
         const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + iy) * W + ix) * C + g * 4);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        // NaN goes through, like torch's max_pool2d (fmaxf would drop it)
+        m.x = (v.x > m.x || v.x != v.x) ? v.x : m.x; m.y = (v.y > m.y || v.y != v.y) ? v.y : m.y;
+        m.z = (v.z > m.z || v.z != v.z) ? v.z : m.z; m.w = (v.w > m.w || v.w != v.w) ? v.w : m.w;
       }
     }
     *reinterpret_cast<float4*>(y + i * 4) = m;

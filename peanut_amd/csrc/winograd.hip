@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 4;
         f32x4 v = o[a] * sc + sh;
         if (res) v += *reinterpret_cast<const f32x4*>(res + off);
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (relu) v = relu_keep_nan(v);
         *reinterpret_cast<f32x4*>(y + off) = v;
       }
     }

@@ -104,6 +104,16 @@ class HipSegmentor:
         _lib.check(rc, "peanut_pred_forward")
         return out
 
+    def check_range(self, y: torch.Tensor) -> torch.Tensor:
+        """fp16x3 only: an activation outside fp16's exponent range turns the output into NaN (include/peanut_hip.h);
+        the host-facing entry points (``get_prediction``, ``run_inference``: they synchronise anyway) call this and raise
+        instead of handing NaN probabilities to the planner.  ``forward_logits`` / ``get_prediction_batch`` stay
+        asynchronous and unchecked."""
+        if self.precision == "fp16x3" and not bool(torch.isfinite(y).all()):
+            raise FloatingPointError("precision='fp16x3': an activation left fp16's range (|x| >= 65520) and the output is "
+                                     "NaN; run this model with precision='bf16x6' (fp32's exponent range) or 'fp32'")
+        return y
+
     def workspace_bytes(self, b: int, h: int, w: int) -> int:
         return int(self._lib.peanut_pred_workspace_bytes(self._h, b, h, w))
 
@@ -192,7 +202,7 @@ def run_inference(model: HipSegmentor, full_map: np.ndarray) -> List[np.ndarray]
     if full_map.ndim != 3:
         raise ValueError(f"full_map must be [C,H,W], got shape {full_map.shape}")
     x = torch.from_numpy(np.ascontiguousarray(full_map, dtype=np.float32))[None].to(model.device)
-    y = model.forward_logits(x, apply_sigmoid=False)
+    y = model.check_range(model.forward_logits(x, apply_sigmoid=False))
     return list(y.cpu().numpy())               # .cpu() synchronises, like simple_test's
 
 
@@ -225,7 +235,7 @@ class PEANUT_Prediction_Model():
         """np.float32 [C,H,W] partial map -> np.float32 [num_classes,H,W] probabilities
         (``sigmoid(result[0])``, prediction.py:157-158; the sigmoid runs fused on the device)."""
         x = torch.from_numpy(np.ascontiguousarray(full_map, dtype=np.float32))[None].to(self.model.device)
-        y = self.model.forward_logits(x, apply_sigmoid=True)
+        y = self.model.check_range(self.model.forward_logits(x, apply_sigmoid=True))
         return y[0].cpu().numpy()
 
     def get_prediction_batch(self, maps: torch.Tensor, apply_sigmoid: bool = True,

@@ -326,6 +326,22 @@ def test_fp16_pieces_activation_range_is_loud():
     xb[0, 3, 5, 7] = 7.0e4
     y = conv(xb.cuda()).cpu()
     assert bool(torch.isnan(y[0, 3, 5]).all()) and bool(torch.isfinite(y[0, 3, 4]).all())
+    # ... also through a fused ReLU (a plain max(x, 0) would turn the NaN into a plausible 0)
+    y = FusedConv(w, None, None, relu=True, precision="fp16x3")(xb.cuda()).cpu()
+    assert bool(torch.isnan(y[0, 3, 5]).all()) and bool(torch.isfinite(y[0, 3, 4]).all())
+
+
+def test_relu_and_maxpool_let_nan_through():
+    """torch.relu / max_pool2d propagate NaN; so do the fused epilogues (every precision mode), so that a NaN in a map or an
+    overflow never comes out as a finite number."""
+    from peanut_amd.ops import FusedConv
+    g = torch.Generator().manual_seed(13)
+    x = _rand((1, 8, 8, 64), g)
+    x[0, 2, 2, 5] = float("nan")
+    w = _rand((64, 64, 1, 1), g, 0.1)
+    for precision in ("fp32", "bf16x6"):
+        y = FusedConv(w, None, None, relu=True, precision=precision)(x.cuda()).cpu()
+        assert bool(torch.isnan(y[0, 2, 2]).all()) and int(torch.isnan(y).sum()) == 64, precision
 
 
 WINO_CASES = [

@@ -169,6 +169,26 @@ def test_split_precision_forward_within_contract(precision, tol, golden_dir):
     print(f"{precision}: worst logits max-abs {worst:.3e} (contract {CONTRACT})")
 
 
+def test_fp16x3_range_violation_raises(golden_dir):
+    """fp16x3 gives up fp32's exponent range in the activations: an input that drives them past
+    65504 makes the logits NaN, and the host-facing entry point raises instead of returning them; bf16x6 and fp32 take the
+    same input in their stride."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    x = z["odd_100/input"][0].astype(np.float32)
+    big = x * np.float32(3.0e6)
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="fp16x3")
+    ok = m.get_prediction(x)
+    assert ok.shape == (cfg.num_classes,) + x.shape[1:] and np.isfinite(ok).all()
+    with pytest.raises(FloatingPointError, match="fp16x3"):
+        m.get_prediction(big)
+    m6 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="bf16x6")
+    assert np.isfinite(m6.get_prediction(big)).all()
+
+
 def test_folded_and_plain_bottleneck_agree(model_and_sd):
     """fold_ppm=True (pyramid half of the 3x3 bottleneck evaluated through linearity, default) and
     fold_ppm=False (plain conv over cat([x, up(ppm)])) are the same function up to fp32
