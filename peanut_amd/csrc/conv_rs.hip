@@ -1,7 +1,7 @@
 // Implicit-GEMM convolution (3x3 and every other non-pointwise layer, any stride / dilation, one or two sources) emulated
 // on the bf16 matrix cores: the register-split arithmetic of gemm_rs.hip with conv_igemm.hip's im2col-free staging.
 //
-// In the emulated-fp32 modes (bf16x6 / bf16x3) round 2 left these layers -- the deep stem (resnet.py:591-624), layer1's and
+// In the emulated-fp32 modes (bf16x6 / bf16x3 / fp16x3) round 2 left these layers -- the deep stem (resnet.py:591-624), layer1's and
 // layer2.0's 3x3 convs (resnet.py:267-307; the wider stride-1 3x3 convs run as Winograd) -- on the fp32 MFMA kernel, where
 // they are matrix-core-bound at ~100 TF/s: 2.8 ms of a 29 ms batch-32 step for 5 % of its FLOPs.  Here a k-tile is 16
 // input channels of one filter tap: every thread gathers two 16-byte pieces of the shifted input pixels (out-of-image taps
@@ -10,6 +10,7 @@
 // the 16-byte chunk c of row r at position c ^ ((r >> 2) & 3), B [plane][BN rows][16 bf16] with the halves of a row
 // swapped for rows with bit 3 set -- then fragment read, split (rs_common.h: split_frag), 6 (3) MFMAs per product tile.
 // Two LDS stages, one barrier per k-tile.  Weights: pack_weights_sx_conv, k-tile order = channel chunk outer, tap inner.
+// KIND (rs_common.h) selects bf16 pieces (three: bf16x6, two: bf16x3) or two fp16 pieces (fp16x3).
 #include <stdlib.h>
 
 #include "common.h"

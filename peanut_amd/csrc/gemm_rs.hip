@@ -17,6 +17,11 @@
 //
 // Product terms: NP = 3 -> hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (bf16x6, dropped terms
 // <= 2^-24 |ab|: fp32-class), NP = 2 -> hi*hi + hi*lo + lo*hi (bf16x3), smallest terms first, fp32 accumulation.
+// KIND = RS_FP16X3 (rs_common.h): the NP = 2 loop on FP16 pieces and v_mfma_f32_32x32x16_f16 -- 2 x 11 significand bits,
+// fp32-class results from three products as long as the activations stay inside fp16's exponent range; the weights are
+// scaled per layer before the split and ConvKParams::alpha undoes it in the epilogue.  Same cost as bf16x3 (1 520 vs
+// 1 103 maps/s for bf16x6, profiles/r3r); on real data 7 % slower than the bf16 three-product kernel and equal on zeros:
+// wider significands toggle more, and the launch is power-bound like the six-product one.
 //
 // LDS image of a stage: A [BM rows][16 floats], 16-byte chunk c of row r stored at chunk position c ^ ((r >> 2) & 3)
 // (applied to the DMA source address and to the ds_read_b128 address alike): the 16 lanes of a ds_read_b128 lane group
