@@ -291,6 +291,61 @@ def test_emulated_modes_report_what_they_run(precision):
         assert _lib.load().peanut_conv_precision(c._h) == _lib.PRECISIONS[precision]
 
 
+def _fuzz_cases(n, seed):
+    """Seeded random operator shapes: (B, H, W, cin, cout, k, stride, dil, relu, residual, two_sources)."""
+    import random
+    r = random.Random(seed)
+    out = []
+    for _ in range(n):
+        k = r.choice([1, 1, 1, 3])
+        cin = 16 * r.randint(1, 40 if k == 1 else 12)
+        cout = 4 * r.randint(16, 160) if k == 1 else r.choice([32, 64, 96, 128, 192, 256])
+        B, H, W = r.randint(1, 3), r.randint(5, 40), r.randint(5, 40)
+        stride = r.choice([1, 1, 2])
+        dil = 1 if k == 1 else r.choice([1, 2, 4])
+        two = k == 1 and stride == 1 and cin >= 32 and r.random() < 0.3
+        out.append((B, H, W, cin, cout, k, stride, dil, r.random() < 0.5, r.random() < 0.5, two))
+    return out
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "fp16x3", "bf16x3"])
+def test_register_split_kernels_fuzz(precision):
+    """40 seeded random shapes per mode through gemm_rs.hip / conv_rs.hip (1x1 with ragged cout / K from 16 to 640 / two
+    sources / stride 2, 3x3 with dilation and stride) against F.conv2d, at the mode's operator tolerance; the kernel family
+    must be a register-split one every time."""
+    from peanut_amd.ops import FusedConv
+    worst = 0.0
+    for case in _fuzz_cases(40, {"bf16x6": 1, "fp16x3": 2, "bf16x3": 3}[precision]):
+        B, H, W, cin, cout, k, stride, dil, relu, residual, two = case
+        g = torch.Generator().manual_seed(hash(case) & 0xffff)
+        x = _rand((B, cin, H, W), g)
+        w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = _rand((cout,), g, 0.1)
+        pad = dil * (k // 2)
+        ref = F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil) * scale[None, :, None, None] + shift[None, :, None, None]
+        res = _rand(tuple(ref.shape), g) if residual else None
+        if residual:
+            ref = ref + res
+        if relu:
+            ref = F.relu(ref)
+        conv = FusedConv(w, scale, shift, stride=stride, padding=pad, dilation=dil, relu=relu, precision=precision, conv_algo="direct")
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+        if two:
+            c1 = 16 * max(1, (cin // 16) // 3)
+            y = conv(xd[..., :c1].contiguous(), x2=xd[..., c1:].contiguous(), residual=rd)
+        else:
+            y = conv(xd, residual=rd)
+        fam = _last_kernel()
+        assert fam.startswith(("gemm_" if k == 1 else "conv_") + RS_TAG[precision]), (case, fam)
+        err = ((y.permute(0, 3, 1, 2).cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        worst = max(worst, err)
+        # bf16x3: 2 x its tolerance -- with K = 16 nothing averages out and a product is only good to ~2^-16 (1.0e-4 seen)
+        assert err <= RS_TOL[precision] * (2 if precision == "bf16x3" else 1), f"{case} on {fam}: {err:.3e}"
+    print(f"{precision}: worst relative error over 40 random shapes {worst:.3e}")
+
+
 @pytest.mark.parametrize("wmag", [2.0 ** -30, 2.0 ** -12, 1.0, 2.0 ** 20])
 def test_fp16_pieces_do_not_depend_on_the_weights_range(wmag):
     """fp16x3: a layer's weights are scaled by a power of two before they are split into fp16 pieces and the scale is
