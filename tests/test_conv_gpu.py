@@ -346,6 +346,72 @@ def test_register_split_kernels_fuzz(precision):
     print(f"{precision}: worst relative error over 40 random shapes {worst:.3e}")
 
 
+def test_fp32_kernels_fuzz():
+    """The same 40-shape fuzz on the fp32 MFMA kernels (conv_pw.hip LDS-DMA pointwise kernels, conv_igemm.hip for the rest),
+    one and two sources, at the fp32 operator tolerance."""
+    from peanut_amd.ops import FusedConv, to_nhwc_padded, round_up
+    worst = 0.0
+    for case in _fuzz_cases(40, 4):
+        B, H, W, cin, cout, k, stride, dil, relu, residual, two = case
+        g = torch.Generator().manual_seed(hash(case) & 0xffff)
+        x = _rand((B, cin, H, W), g)
+        w = _rand((cout, cin, k, k), g, (2.0 / (cin * k * k)) ** 0.5)
+        shift = _rand((cout,), g, 0.1)
+        pad = dil * (k // 2)
+        ref = F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil) + shift[None, :, None, None]
+        res = _rand(tuple(ref.shape), g) if residual else None
+        if residual:
+            ref = ref + res
+        if relu:
+            ref = F.relu(ref)
+        conv = FusedConv(w, None, shift, stride=stride, padding=pad, dilation=dil, relu=relu, conv_algo="direct")
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+        c1 = 32 * max(1, (cin // 32) // 3)
+        if two and cin % 32 == 0 and cin > c1:
+            y = conv(xd[..., :c1].contiguous(), x2=xd[..., c1:].contiguous(), residual=rd)
+        else:
+            y = conv(xd, residual=rd)
+        err = ((y.permute(0, 3, 1, 2).cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        worst = max(worst, err)
+        assert err <= 2e-5, f"{case} on {_last_kernel()}: {err:.3e}"
+    print(f"fp32: worst relative error over 40 random shapes {worst:.3e}")
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1.5e-4), ("bf16x6", 1.5e-4), ("fp16x3", 1.5e-4)])
+def test_winograd_fuzz(precision, tol):
+    """24 seeded random stride-1 3x3 layers (128-640 input channels, ragged cout, dilation 1 / 2 / 4, maps that do not divide
+    into 4x4 tiles) through the Winograd form (conv_algo = auto) against F.conv2d."""
+    import random
+    from peanut_amd.ops import FusedConv
+    r = random.Random(5)
+    worst = 0.0
+    for _ in range(24):
+        B, H, W = r.randint(1, 3), r.randint(4, 33), r.randint(4, 33)
+        cin, cout, d = 32 * r.randint(4, 20), 4 * r.randint(16, 140), r.choice([1, 1, 2, 4])
+        relu, residual = r.random() < 0.5, r.random() < 0.5
+        g = torch.Generator().manual_seed(B * 1000003 + H * 1009 + W * 31 + cin + cout)
+        x = _rand((B, cin, H, W), g)
+        w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = _rand((cout,), g, 0.1)
+        ref = F.conv2d(x, w, None, padding=d, dilation=d) * scale[None, :, None, None] + shift[None, :, None, None]
+        res = _rand(tuple(ref.shape), g) if residual else None
+        if residual:
+            ref = ref + res
+        if relu:
+            ref = F.relu(ref)
+        conv = FusedConv(w, scale, shift, padding=d, dilation=d, relu=relu, precision=precision)
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+        y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=rd)
+        fam = _last_kernel()
+        assert fam.startswith("gemm_" + RS_TAG[precision] if precision != "fp32" else "conv_pw_glds_"), ((B, H, W, cin, cout, d), fam)
+        err = ((y.permute(0, 3, 1, 2).cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        worst = max(worst, err)
+        assert err <= tol, f"{(B, H, W, cin, cout, d, relu, residual)} on {fam}: {err:.3e}"
+    print(f"winograd {precision}: worst relative error over 24 random layers {worst:.3e}")
+
+
 @pytest.mark.parametrize("wmag", [2.0 ** -30, 2.0 ** -12, 1.0, 2.0 ** 20])
 def test_fp16_pieces_do_not_depend_on_the_weights_range(wmag):
     """fp16x3: a layer's weights are scaled by a power of two before they are split into fp16 pieces and the scale is
