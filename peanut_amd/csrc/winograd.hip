@@ -17,6 +17,8 @@
 // resnet.py:267-307, dilations 1/2/4) and the PSP bottleneck conv (models/decode_heads/psp_head.py:86-93).
 // Numerics: fp32 throughout; on the seeded PSPNet the logits are as far from the fp64 reference as with direct
 // convolutions (5e-6, |logit| <= 6.4); contract 1e-3.
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_common.h"
 
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
       f32x4 t0, t1, t2, t3, t4, t5;
       bt6(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], t0, t1, t2, t3, t4, t5);
       float* o = vb + (size_t)(i * 6) * pos_stride;
+      // (plain stores: non-temporal ones measured 2.5 % slower here, profiles/r3t)
       *reinterpret_cast<f32x4*>(o) = t0;
       *reinterpret_cast<f32x4*>(o + pos_stride) = t1;
       *reinterpret_cast<f32x4*>(o + 2 * pos_stride) = t2;
@@ -143,12 +146,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const float* s = mb + (size_t)(i * 6) * pos_stride;
-      const f32x4 m0 = *reinterpret_cast<const f32x4*>(s);
-      const f32x4 m1 = *reinterpret_cast<const f32x4*>(s + pos_stride);
-      const f32x4 m2 = *reinterpret_cast<const f32x4*>(s + 2 * pos_stride);
-      const f32x4 m3 = *reinterpret_cast<const f32x4*>(s + 3 * pos_stride);
-      const f32x4 m4 = *reinterpret_cast<const f32x4*>(s + 4 * pos_stride);
-      const f32x4 m5 = *reinterpret_cast<const f32x4*>(s + 5 * pos_stride);
+      // M is read exactly once: non-temporal loads (1.36 -> 1.20 ms per batch-32 forward, profiles/r3t)
+      const f32x4 m0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s));
+      const f32x4 m1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s + pos_stride));
+      const f32x4 m2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s + 2 * pos_stride));
+      const f32x4 m3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s + 3 * pos_stride));
+      const f32x4 m4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s + 4 * pos_stride));
+      const f32x4 m5 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s + 5 * pos_stride));
       at6(m0, m1, m2, m3, m4, m5, q[i][0], q[i][1], q[i][2], q[i][3]);
     }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ng * 4);
