@@ -30,12 +30,45 @@ inline unsigned short bf16_piece_host(float& v) {
 }
 
 // host side: next fp16 piece of v (round to nearest even, subnormals kept), v <- the remainder (exact)
+// (integer arithmetic: a host _Float16 cast goes through a libgcc soft-float call per value without F16C)
 inline unsigned short f16_piece_host(float& v) {
-  const _Float16 h = (_Float16)v;
-  v -= (float)h;
-  unsigned short bits;
-  __builtin_memcpy(&bits, &h, 2);
-  return bits;
+  unsigned x;
+  __builtin_memcpy(&x, &v, 4);
+  const unsigned sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  unsigned short h;
+  float back;
+  if (ax >= 0x7f800000u) {                       // inf / NaN
+    h = (unsigned short)(sign | 0x7c00u | (ax > 0x7f800000u ? 0x200u : 0u));
+    __builtin_memcpy(&back, &x, 4);
+  } else if (ax >= 0x477ff000u) {                // >= 65520: rounds to inf
+    h = (unsigned short)(sign | 0x7c00u);
+    back = sign ? -__builtin_inff() : __builtin_inff();
+  } else {
+    unsigned m;
+    if (ax >= 0x38800000u) {                     // normal fp16: drop 13 mantissa bits, round to nearest even
+      m = ax - 0x38000000u;                      // rebias the exponent (127 -> 15)
+      m = (m + 0xfffu + ((m >> 13) & 1u)) >> 13;
+    } else if (ax >= 0x33000000u) {              // subnormal fp16: value / 2^-24 rounded to nearest even
+      const int sh = 126 - (int)(ax >> 23);      // 14 .. 24: one more dropped bit per binade below 2^-14
+      const unsigned mant = (ax & 0x7fffffu) | 0x800000u;
+      const unsigned q = mant >> sh, rem = mant & ((1u << sh) - 1u), half = 1u << (sh - 1);
+      m = q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
+    } else {
+      m = 0;                                     // below half the smallest subnormal
+    }
+    h = (unsigned short)(sign | m);
+    // the piece as a float: exponent / mantissa back in place (exact)
+    const unsigned e = (m >> 10) & 0x1fu, f = m & 0x3ffu;
+    if (e == 0) {
+      back = (float)f * 5.9604644775390625e-8f;            // f * 2^-24
+      if (sign) back = -back;
+    } else {
+      const unsigned fb = (sign << 16) | ((e + 112u) << 23) | (f << 13);
+      __builtin_memcpy(&back, &fb, 4);
+    }
+  }
+  v -= back;
+  return h;
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
