@@ -370,6 +370,13 @@ def main():
                             "launch stream, recorded over a second pass of the same steps right after the timed region",
                     "gflop_per_map_executed": round(executed, 3),
                     "whole_forward_tflops_executed": round(executed * 1e9 * B * steps / elapsed / 1e12, 2)}
+            # the HBM-bound sub-kernels are reported against bandwidth -- algorithmic bytes (operands read
+            # once, result written once) / summed launch time of the family; peak ~8 TB/s (MI355X_MICROARCH.md)
+            hbm = {kk: {"gb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9), "frac_of_8tbs": round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 3),
+                        "ms_per_step": round(v["ms"] / max(nf, 1), 3)}
+                   for kk, v in fam.items() if v["flops"] == 0 and v["bytes"] > 0 and v["ms"] > 0}
+            if hbm:
+                roof["hbm_bound_kernels"] = hbm
             if op_table and rank == 0:
                 with open(op_table, "w") as fh:
                     json.dump({"forwards": nf, "B": B, "S": S, "precision": precision,

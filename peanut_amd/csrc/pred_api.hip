@@ -283,7 +283,11 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   pl->splitk.B = pl->splitk.H = pl->splitk.W = 1; pl->splitk.C = 0;
   // input layout change: NCHW -> NHWC, channels zero-padded to a multiple of 16
   Act x = make_act(ar, B, H, W, h->cin_pad);
-  { Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.kernel = "nchw_to_nhwc"; op.out = x; pl->ops.push_back(op); }
+  {
+    Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.kernel = "nchw_to_nhwc"; op.out = x;
+    op.bytes = (double)B * H * W * h->cfg.in_channels * 4.0 + (double)x.bytes;      // HBM-bound: read NCHW, write padded NHWC
+    pl->ops.push_back(op);
+  }
 
   // deep stem (resnet.py:591-624) + maxpool (:638)
   for (int i = 0; i < 3; ++i) {
@@ -297,7 +301,9 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   }
   {
     Act y = make_act(ar, B, conv_out_dim(x.H, 3, 2, 1, 1), conv_out_dim(x.W, 3, 2, 1, 1), x.C);
-    Op op; op.kind = OP_MAXPOOL; op.name = "maxpool"; op.kernel = "maxpool"; op.in = x; op.out = y; pl->ops.push_back(op);
+    Op op; op.kind = OP_MAXPOOL; op.name = "maxpool"; op.kernel = "maxpool"; op.in = x; op.out = y;
+    op.bytes = (double)x.bytes + (double)y.bytes;
+    pl->ops.push_back(op);
     pl->named["pool"] = y;
     rel(x);
     x = y;
@@ -370,6 +376,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   Act pooled = make_act(ar, 1, 1, prow, x.C);
   {
     Op op; op.kind = OP_PPM_POOL; op.name = "ppm_pool"; op.kernel = "ppm_pool"; op.in = x; op.out = pooled; op.ppm_scale_rows = srows;
+    op.bytes = (double)x.bytes + (double)pooled.bytes;
     const size_t sf = ppm_pool_scratch_floats(B, x.H, x.C, h->cfg.pool_scales, h->cfg.n_pool_scales);
     if (sf) {   // per-row partial sums of the two-pass pooling
       Act scr; scr.B = 1; scr.H = 1; scr.W = 1; scr.C = 0; scr.bytes = sf * sizeof(float); scr.off = ar.alloc(scr.bytes);
@@ -431,7 +438,11 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     }
     rel_side(table);
     Act r = make_act(ar, B, x.H, x.W, hc);
-    { Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; op.ppm_scale_rows = term_scale_rows; pl->ops.push_back(op); }
+    {
+      Op op; op.kind = OP_PPM_TERM; op.name = "ppm_conv_term"; op.kernel = "ppm_conv_term"; op.in = q; op.out = r; op.ppm_scale_rows = term_scale_rows;
+      op.bytes = (double)q.bytes + (double)r.bytes;
+      pl->ops.push_back(op);
+    }
     rel_side(q);
     const size_t side_end = pl->ops.size();
     bt = make_act(ar, B, x.H, x.W, h->bottleneck_x->d.cout);
@@ -458,7 +469,11 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   push_conv(*pl, h->conv_seg, bt, nullptr, nullptr, lo);
   pl->named["logits_lowres"] = lo;
   rel(bt);
-  { Op op; op.kind = OP_UPSAMPLE; op.name = "upsample_logits"; op.kernel = "upsample_logits"; op.in = lo; pl->ops.push_back(op); }
+  {
+    Op op; op.kind = OP_UPSAMPLE; op.name = "upsample_logits"; op.kernel = "upsample_logits"; op.in = lo;
+    op.bytes = (double)lo.bytes + (double)B * H * W * h->conv_seg->d.cout * 4.0;
+    pl->ops.push_back(op);
+  }
   rel(lo);
   return pl;   // pl->bytes (high-water mark) is filled in by get_plan
 }
