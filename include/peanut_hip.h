@@ -36,6 +36,11 @@ const char* peanut_build_arch(void);
 /* hash of the sources this library was compiled from (peanut_amd/build.py: source_hash), "" when built by other means: the
  * Python binding compares it with the sources lying next to it and rebuilds or refuses a stale library */
 const char* peanut_source_hash(void);
+/* Host-side test hook (no GPU needed): the pieces the weight packer of an emulated mode makes of n host values that
+ * form ONE layer -- precision = PEANUT_PREC_BF16X3 / FP16X3 (two pieces) or BF16X6 (three).  pieces: [3][n] 16-bit
+ * patterns (bf16 or fp16; plane 2 zero for the two-piece modes); *pack_scale = the power of two the values were multiplied
+ * by first (1 for the bf16 modes).  tests/test_abi.py compares them with numpy's / torch's own roundings. */
+int peanut_debug_weight_pieces(const float* values, int n, int precision, unsigned short* pieces, float* pack_scale);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 3 -- map-completion forward (PSPNet: ResNet-50-V1c-D8 + PSP head)

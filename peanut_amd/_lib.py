@@ -71,6 +71,7 @@ SIGNATURES = {
     "peanut_abi_version": (C.c_int, []),
     "peanut_build_arch": (C.c_char_p, []),
     "peanut_source_hash": (C.c_char_p, []),
+    "peanut_debug_weight_pieces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "peanut_pred_create": (C.c_int, [C.POINTER(_P), C.POINTER(PredCfgC), C.POINTER(TensorC), C.c_int]),
     "peanut_pred_destroy": (None, [_P]),
     "peanut_pred_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -872,4 +872,19 @@ int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c
   return launch_conv_layer(c->L, a, (float*)c->wino_v.p, (float*)c->wino_m.p, (hipStream_t)stream);
 }
 
+int peanut_debug_weight_pieces(const float* values, int n, int precision, unsigned short* pieces, float* pack_scale) {
+  const int planes = rs_planes_of(precision);
+  if (!values || !pieces || !pack_scale || n < 1 || !planes) return fail(PEANUT_EINVAL, "peanut_debug_weight_pieces: bad arguments");
+  // one 1 x n "layer" through the real packer (tile 0, k-tiles of 16 values), then gathered back per plane
+  const int cin_pad = (n + 15) / 16 * 16, bn = 64, np = planes == 4 ? 2 : planes;
+  *pack_scale = sx_pack_scale(values, (size_t)n, planes);
+  std::vector<unsigned char> packed(sx_packed_bytes(cin_pad, 1, bn, planes));
+  pack_weights_sx(values, 1, n, cin_pad, bn, planes, *pack_scale, packed.data());
+  const unsigned short* o = reinterpret_cast<const unsigned short*>(packed.data());
+  for (int q = 0; q < 3; ++q)
+    for (int c = 0; c < n; ++c)
+      pieces[(size_t)q * n + c] = q < np ? o[((size_t)(c / 16) * np + q) * bn * 16 + (c % 16)] : (unsigned short)0;
+  return 0;
+}
+
 }  // extern "C"

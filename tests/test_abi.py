@@ -128,3 +128,45 @@ def test_library_carries_the_hash_of_its_sources(monkeypatch):
     monkeypatch.setattr(build, "source_hash", lambda: "0" * 16)          # "the sources changed"
     assert _lib._stale_reason(lib, build.LIB_PATH)
     assert _lib._stale_reason(lib, "/elsewhere/libpeanut_hip.so") == ""   # a library given by path is taken as it is
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3", "fp16x3"])
+def test_weight_pieces_of_the_emulated_modes_match_independent_roundings(precision):
+    """Host arithmetic of the weight packer (csrc/rs_common.h), no GPU: the pieces of a layer's weights against torch's
+    bfloat16 / numpy's float16 round-to-nearest-even, piece by piece -- including the power-of-two pack scale of the fp16
+    mode, fp16 subnormals and the edge of its range."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    v = (rng.standard_normal(4096) * np.exp(rng.uniform(-12, 3, 4096))).astype(np.float32)
+    v[:8] = [0.0, -0.0, 1.0, -1.0, 3.0e-7, 65504.0 / 2 ** 14, 1.17549435e-38, 0.333333343]
+    pieces = np.zeros((3, v.size), np.uint16)
+    scale = C.c_float(0)
+    _lib.check(lib.peanut_debug_weight_pieces(v.ctypes.data, v.size, _lib.PRECISIONS[precision], pieces.ctypes.data, C.byref(scale)),
+               "peanut_debug_weight_pieces")
+    if precision == "fp16x3":
+        s = np.float32(scale.value)
+        m, e = np.frexp(np.abs(v).max())
+        assert s == np.float32(2.0) ** (14 - e) and 2.0 ** 13 <= np.abs(v).max() * s < 2.0 ** 14
+        r = v * s                                            # exact: power of two, no overflow / underflow here
+        for q in range(2):
+            h = r.astype(np.float16)                         # numpy: round to nearest even, subnormals kept
+            assert np.array_equal(pieces[q], h.view(np.uint16)), f"piece {q}"
+            r = r - h.astype(np.float32)                     # exact
+        assert not pieces[2].any()
+        # what the two pieces leave: <= 2^-23 relative, or fp16's subnormal spacing
+        assert bool((np.abs(r) <= np.maximum(np.abs(v * s) * 2.0 ** -22, 2.0 ** -25)).all())
+    else:
+        assert scale.value == 1.0
+        r = torch.from_numpy(v.copy())
+        n = 3 if precision == "bf16x6" else 2
+        for q in range(n):
+            h = r.to(torch.bfloat16)
+            assert np.array_equal(pieces[q], h.view(torch.int16).numpy().view(np.uint16)), f"piece {q}"
+            r = r - h.float()
+        if n == 3:
+            assert float(r.abs().max()) == 0.0 or bool((r.abs() <= torch.from_numpy(np.abs(v)) * 2.0 ** -24).all())
+        else:
+            assert not pieces[2].any()
