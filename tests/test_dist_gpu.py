@@ -85,3 +85,33 @@ def test_bench_spawns_its_own_ranks_or_refuses():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["survey_config"] == 5 and "25-channel" in line["config"]["workload"]
     assert "allgather_maps_ms" in line
+
+
+def test_bench_line_carries_the_contract_fields():
+    """The ONE JSON line of bench.py (small shape, short run): the driver's fields, the roofline object with the HBM-bound
+    families reported against bandwidth, a cpu_baseline object (bounded sample), and every requested mode with its own
+    roofline."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "96",
+           "--also", "bf16x6,fp16x3", "--traffic", "none"]
+    r = subprocess.run(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "modes"):
+        assert k in line, k
+    assert line["unit"] == "maps/s" and line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3 and "traffic" in roof
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    hbm = roof["hbm_bound_kernels"]
+    assert {"nchw_to_nhwc", "maxpool", "ppm_pool", "upsample_logits"} <= set(hbm) and all(v["gb_s"] > 0 for v in hbm.values())
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "maps/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert set(line["modes"]) == {"bf16x6", "fp16x3"}
+    for m in line["modes"].values():
+        assert m["value"] > 0 and m["roofline"]["peak"] in (416.7, 833.3) and "speedup_vs_cpu_baseline" in m
