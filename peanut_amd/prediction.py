@@ -226,6 +226,14 @@ class PEANUT_Prediction_Model():
             fold_ppm = os.environ.get("PEANUT_FOLD_PPM", "1") != "0"
         if conv_algo is None:
             conv_algo = os.environ.get("PEANUT_CONV_ALGO", "auto")
+        # precision="auto": the fastest fp32-class arithmetic that is safe for THIS model -- fp16x3, escalated once and for
+        # good to bf16x6 (fp32's exponent range, six products) the first time an activation leaves fp16's range.  The
+        # escalation happens at the host-facing entry point, where the result is checked anyway; it is announced.
+        self._escalate = None
+        if precision == "auto":
+            precision = "fp16x3"
+            self._escalate = dict(config=cfg, checkpoint=ckpt, device=device, state_dict=state_dict, precision="bf16x6",
+                                  fold_ppm=fold_ppm, conv_algo=conv_algo)
         self.model = init_segmentor(cfg, checkpoint=ckpt, device=device, state_dict=state_dict,
                                     precision=precision, fold_ppm=fold_ppm, conv_algo=conv_algo)
         self.model.eval()
@@ -235,11 +243,28 @@ class PEANUT_Prediction_Model():
         """np.float32 [C,H,W] partial map -> np.float32 [num_classes,H,W] probabilities
         (``sigmoid(result[0])``, prediction.py:157-158; the sigmoid runs fused on the device)."""
         x = torch.from_numpy(np.ascontiguousarray(full_map, dtype=np.float32))[None].to(self.model.device)
-        y = self.model.check_range(self.model.forward_logits(x, apply_sigmoid=True))
-        return y[0].cpu().numpy()
+        return self._checked_forward(x, True, None)[0].cpu().numpy()
+
+    def _checked_forward(self, x, apply_sigmoid, out):
+        try:
+            return self.model.check_range(self.model.forward_logits(x, apply_sigmoid=apply_sigmoid, out=out))
+        except FloatingPointError:
+            if self._escalate is None:
+                raise
+            import warnings
+            warnings.warn("precision='auto': an activation left fp16's exponent range; this model runs in bf16x6 from now on")
+            kw, self._escalate = self._escalate, None
+            cfg = kw.pop("config")
+            self.model = init_segmentor(cfg, **kw)
+            self.model.eval()
+            self.model.cfg = cfg
+            return self.model.forward_logits(x, apply_sigmoid=apply_sigmoid, out=out)
 
     def get_prediction_batch(self, maps: torch.Tensor, apply_sigmoid: bool = True,
                              out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Batched, device-resident variant: [B,C,H,W] float32 on the HIP device -> [B,K,H,W]
-        (no host round trip, enqueued on the current stream)."""
+        (no host round trip, enqueued on the current stream).  With ``precision="auto"`` -- until the model has escalated
+        to bf16x6 -- the result is range-checked, which synchronises; every explicit precision stays asynchronous."""
+        if self._escalate is not None:
+            return self._checked_forward(maps, apply_sigmoid, out)
         return self.model.forward_logits(maps, apply_sigmoid=apply_sigmoid, out=out)

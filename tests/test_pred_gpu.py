@@ -189,6 +189,35 @@ def test_fp16x3_range_violation_raises(golden_dir):
     assert np.isfinite(m6.get_prediction(big)).all()
 
 
+def test_precision_auto_escalates_to_bf16x6(golden_dir):
+    """precision='auto' = fp16x3 until an activation leaves fp16's range, then (announced) bf16x6 for good: the call that
+    trips it already returns the bf16x6 result."""
+    import warnings
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    x = z["odd_100/input"][0].astype(np.float32)
+    big = x * np.float32(3.0e6)
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="auto")
+    h = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="fp16x3")
+    m6 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="bf16x6")
+    assert m.model.precision == "fp16x3" and np.array_equal(m.get_prediction(x), h.get_prediction(x))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m.get_prediction(big)
+    assert any("bf16x6" in str(i.message) for i in w)
+    assert m.model.precision == "bf16x6" and np.array_equal(got, m6.get_prediction(big))
+    assert np.array_equal(m.get_prediction(x), m6.get_prediction(x))            # latched
+    # the device-resident entry point escalates the same way
+    m2 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision="auto")
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        y = m2.get_prediction_batch(torch.from_numpy(big)[None].cuda())
+    assert m2.model.precision == "bf16x6" and bool(torch.isfinite(y).all())
+
+
 def test_folded_and_plain_bottleneck_agree(model_and_sd):
     """fold_ppm=True (pyramid half of the 3x3 bottleneck evaluated through linearity, default) and
     fold_ppm=False (plain conv over cat([x, up(ppm)])) are the same function up to fp32
