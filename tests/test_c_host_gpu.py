@@ -25,7 +25,7 @@ def _write_state_dict(path, tensors):
             f.write(np.ascontiguousarray(a, np.float32).tobytes())
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x3"])
 def test_cpp_host_reproduces_python_path(tmp_path, precision):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
