@@ -218,6 +218,42 @@ def test_precision_auto_escalates_to_bf16x6(golden_dir):
     assert m2.model.precision == "bf16x6" and bool(torch.isfinite(y).all())
 
 
+def test_error_behaviour(model_and_sd):
+    """Bad calls fail loudly and leave the handle usable: wrong channel count / dtype / device / out shape (ValueError, like
+    the reference's own shape errors), maps too small for the stride-8 backbone and null pointers (PEANUT_EINVAL through the
+    C ABI), unknown precision / conv_algo strings, a state dict with a tensor missing or mis-shaped (PEANUT_EWEIGHTS)."""
+    from peanut_amd import _lib
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    good = torch.zeros((1, cfg.in_channels, 64, 64), device="cuda")
+    ref = m.get_prediction_batch(good).clone()
+    with pytest.raises(ValueError):
+        m.get_prediction_batch(torch.zeros((1, cfg.in_channels + 1, 64, 64), device="cuda"))
+    with pytest.raises(ValueError):
+        m.get_prediction_batch(good.double())
+    with pytest.raises(ValueError):
+        m.get_prediction_batch(good.cpu())
+    with pytest.raises(ValueError):
+        m.get_prediction_batch(good, out=torch.empty((1, cfg.num_classes, 32, 32), device="cuda"))
+    with pytest.raises(_lib.PeanutHipError):
+        m.get_prediction_batch(torch.zeros((1, cfg.in_channels, 8, 64), device="cuda"))
+    lib = _lib.load()
+    assert lib.peanut_pred_forward(m.model._h, None, None, 1, 64, 64, 0, None) < 0 and lib.peanut_last_error()
+    assert lib.peanut_pred_forward(None, good.data_ptr(), ref.data_ptr(), 1, 64, 64, 0, None) < 0
+    for kw in (dict(precision="fp64"), dict(conv_algo="fft")):
+        with pytest.raises(ValueError):
+            PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, **kw)
+    broken = dict(sd)
+    del broken["backbone.layer2.1.conv2.weight"]
+    with pytest.raises((KeyError, _lib.PeanutHipError)):
+        PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=broken, cfg=cfg)
+    broken = dict(sd)
+    broken["decode_head.conv_seg.weight"] = sd["decode_head.conv_seg.weight"][:, :-1].contiguous()
+    with pytest.raises((ValueError, KeyError, _lib.PeanutHipError)):
+        PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=broken, cfg=cfg)
+    assert torch.equal(m.get_prediction_batch(good), ref)          # the handle survived all of it
+
+
 def test_folded_and_plain_bottleneck_agree(model_and_sd):
     """fold_ppm=True (pyramid half of the 3x3 bottleneck evaluated through linearity, default) and
     fold_ppm=False (plain conv over cat([x, up(ppm)])) are the same function up to fp32
