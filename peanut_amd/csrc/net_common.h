@@ -96,6 +96,9 @@ struct ConvLayer {
   // pointwise (d.w_s), of the 36 Winograd position matrices (wino.w_s, wino_group_bytes apart)
   DevBuf w_s, wino_w_s;
   size_t wino_group_bytes = 0;
+  // output tile of the Winograd form: 4 (F(4x4,3x3), 36 positions) or 6 (F(6x6,3x3), 64 positions)
+  int wino_m = 4;
+  int wino_np() const { return (wino_m + 2) * (wino_m + 2); }
 };
 
 // emulation kind of a precision mode (rs_common.h: 2 = bf16x3, 3 = bf16x6, 4 = fp16x3; 0: fp32 MFMA mode)
@@ -181,8 +184,28 @@ inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int
   return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 && cout >= 64;
 }
 
-inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int cin_pad, int precision) {
+// Tile size of a layer's Winograd form (requested = 0: this policy; 4 / 6: the caller's choice; PEANUT_WINO_M = 4 / 6
+// overrides both, read at every upload).  F(6x6,3x3) executes 1.78 multiplies per output instead of 2.25 and its V / M
+// tensors are that much smaller, at about 3 x the rounding error of the F(4x4) form (winograd.hip).  Measured on the
+// headline forward (profiles/r3y): every eligible layer as F(6x6) +5.3 % throughput but 7.9e-6 -> 3.5e-5 on the golden
+// logits -- nearly all of it from the PSP bottleneck, whose K = 2048 accumulation error goes through A^T's factors of up to
+// 32 (1024 in 2-D) straight into conv_seg; the BACKBONE layers alone: +3.5 %, 7.9e-6 -> 7.2e-6 .. 1.26e-5 (distance to
+// the float64 run 5.3e-6 -> 7.6e-6).  So: the prediction planner asks for F(6x6) in the backbone and F(4x4) in the head.
+// With dilation 4 a 60 x 60 map's sub-grids are 15 x 15: 3 x 3 tiles of 6 (18 rows) or 4 x 4 tiles of 4 (16) are 576
+// position-tiles either way, hence F(6x6) only up to dilation 2.
+inline int wino_tile_for(int dil, int requested) {
+  const char* e = getenv("PEANUT_WINO_M");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 4 || forced == 6) return forced;
+  if (requested == 4 || requested == 6) return requested;
+  return dil <= 2 ? 6 : 4;
+}
+
+// wino_m: 4 or 6, or 0 = wino_tile_for's choice
+inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int cin_pad, int precision, int wino_m = 4) {
   ConvDesc& g = L.wino;
+  L.wino_m = wino_tile_for(L.d.dil, wino_m);
+  const int np = L.wino_np();
   g.cin = cin_pad; g.cout = cout; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
   conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
   g.rs = 0;
@@ -197,10 +220,10 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
   g.w_s = nullptr;
   const size_t gf = conv_packed_floats(cin_pad, cout, 1, 1, g.bn_tile);
-  std::vector<float> U((size_t)36 * cout * cin);
-  wino_transform_weights(w_oihw, cout, cin, U.data());
-  std::vector<float> packed(36 * gf);
-  for (int pos = 0; pos < 36; ++pos) {
+  std::vector<float> U((size_t)np * cout * cin);
+  wino_transform_weights(w_oihw, cout, cin, U.data(), L.wino_m);
+  std::vector<float> packed((size_t)np * gf);
+  for (int pos = 0; pos < np; ++pos) {
     const float* u = U.data() + (size_t)pos * cout * cin;
     pack_conv_weights(u, cout, cin, cin_pad, 1, 1, g.bn_tile, g.bk, packed.data() + pos * gf);
   }
@@ -217,10 +240,10 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   L.wino_group_floats = gf;
   if (g.rs) {
     const size_t gb = sx_packed_bytes(cin_pad, cout, g.bn_tile, g.s_planes);
-    std::vector<unsigned char> ps(36 * gb);
-    const float wscale = sx_pack_scale(U.data(), U.size(), g.s_planes);     // one scale for the 36 positions (one launch)
+    std::vector<unsigned char> ps((size_t)np * gb);
+    const float wscale = sx_pack_scale(U.data(), U.size(), g.s_planes);     // one scale for all positions (one launch)
     g.s_alpha = 1.f / wscale;
-    for (int pos = 0; pos < 36; ++pos)
+    for (int pos = 0; pos < np; ++pos)
       pack_weights_sx(U.data() + (size_t)pos * cout * cin, cout, cin, cin_pad, g.bn_tile, g.s_planes, wscale, ps.data() + pos * gb);
     if ((rc = L.wino_w_s.ensure(ps.size()))) return rc;
     PEANUT_HIP_CHECK(hipMemcpy(L.wino_w_s.p, ps.data(), ps.size(), hipMemcpyHostToDevice));
@@ -236,19 +259,20 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
 inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
   int th, tw;
   long long n_tiles, m_pad;
-  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, 256);
+  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, 256, L.wino_m);
   const ConvDesc& g = L.wino;
-  if (g.rs) return gemm_rs_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;
-  return (conv_pw_enabled() && conv_pw_uses_256(g.cout, 36 * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
+  const long long np = L.wino_np();
+  if (g.rs) return gemm_rs_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;
+  return (conv_pw_enabled() && conv_pw_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
 }
 
 // floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]
 inline void wino_scratch_floats(const ConvLayer& L, int B, int H, int W, size_t* v, size_t* m) {
   int th, tw;
   long long n_tiles, m_pad;
-  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, wino_gran_for(L, B, H, W));
-  *v = (size_t)36 * m_pad * L.d.cin;
-  *m = (size_t)36 * m_pad * L.d.cout;
+  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, wino_gran_for(L, B, H, W), L.wino_m);
+  *v = (size_t)L.wino_np() * m_pad * L.d.cin;
+  *m = (size_t)L.wino_np() * m_pad * L.d.cout;
 }
 
 // One conv layer, as Winograd (input transform -> grouped GEMM -> output transform) when the layer carries
@@ -258,16 +282,17 @@ inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_
   int th, tw, rc;
   long long n_tiles, m_pad;
   const int gran = wino_gran_for(L, a.B, a.H, a.W);
-  wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad, gran);
-  if (36 * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
-  if ((rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran))) return rc;
+  wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad, gran, L.wino_m);
+  const long long np = L.wino_np();
+  if (np * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
+  if ((rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran, L.wino_m))) return rc;
   ConvArgs g{};
   g.x = wino_v; g.y = wino_m;
-  g.B = 1; g.H = 1; g.W = (int)(36 * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
+  g.B = 1; g.H = 1; g.W = (int)(np * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
   g.ws = a.ws; g.ws_floats = a.ws_floats;
   g.mt_per_group = (int)(m_pad / 128); g.w_group_stride = L.wino.rs ? L.wino_group_bytes : L.wino_group_floats;
   if ((rc = launch_conv(L.wino, g, s))) return rc;
-  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s, gran);
+  return launch_wino_output(wino_m, L.d.scale, L.d.shift, a.res, a.y, a.B, a.H, a.W, L.d.cout, L.d.dil, L.d.relu, s, gran, L.wino_m);
 }
 
 // ---- workspace arena with liveness-based reuse (offsets are planned on the host) ----

@@ -146,7 +146,7 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
                    h->cfg.precision);
   if (rc) return rc;
   if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, dil, h->cfg.precision) &&
-      (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision)))
+      (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision, 0)))   // backbone: wino_tile_for's choice
     return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
@@ -235,23 +235,25 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     long long n_tiles, m_pad;
     const bool rs_gemm = L->wino.rs != 0;
     const int gran = wino_gran_for(*L, in.B, in.H, in.W);
-    wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran);
-    Act v = make_act(*ar, 1, 1, (int)(36 * m_pad), in.C);
-    Act m = make_act(*ar, 1, 1, (int)(36 * m_pad), L->d.cout);
+    wino_geometry(in.B, in.H, in.W, L->d.dil, &th, &tw, &n_tiles, &m_pad, gran, L->wino_m);
+    const double np = (double)L->wino_np();
+    const long long npl = L->wino_np();
+    Act v = make_act(*ar, 1, 1, (int)(npl * m_pad), in.C);
+    Act m = make_act(*ar, 1, 1, (int)(npl * m_pad), L->d.cout);
     Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
     a.wino_gran = gran;
-    a.bytes = (double)in.bytes + 36.0 * (double)n_tiles * in.C * 4.0;
+    a.bytes = (double)in.bytes + np * (double)n_tiles * in.C * 4.0;
     pl.ops.push_back(a);
-    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, 36 * m_pad, (int)(m_pad / 128)); g.conv = L;
-    g.in = v; g.in.W = (int)(36 * m_pad); g.in.C = in.C; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
-    g.flops = 2.0 * 36.0 * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
-    g.bytes = 36.0 * (double)m_pad * (in.C * 4.0 + L->d.cout * 4.0) +
-              36.0 * (rs_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
+    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, npl * m_pad, (int)(m_pad / 128)); g.conv = L;
+    g.in = v; g.in.W = (int)(npl * m_pad); g.in.C = in.C; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
+    g.flops = 2.0 * np * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
+    g.bytes = np * (double)m_pad * (in.C * 4.0 + L->d.cout * 4.0) +
+              np * (rs_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
     pl.ops.push_back(g);
     Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
     o.wino_gran = gran;
-    o.bytes = 36.0 * (double)n_tiles * L->d.cout * 4 + (double)out.bytes + (res ? (double)out.bytes : 0.0);
+    o.bytes = np * (double)n_tiles * L->d.cout * 4 + (double)out.bytes + (res ? (double)out.bytes : 0.0);
     pl.ops.push_back(o);
     ar->release(v.off, v.bytes);
     ar->release(m.off, m.bytes);
@@ -531,7 +533,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       return launch_conv(op.conv->d, a, s);
     }
     case OP_WINO_IN:
-      return launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran);
+      return launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran, op.conv->wino_m);
     case OP_WINO_GEMM: {
       ConvArgs a{};
       a.x = P(op.in); a.y = P(op.out);
@@ -543,7 +545,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
     }
     case OP_WINO_OUT:
       return launch_wino_output(P(op.in), op.conv->d.scale, op.conv->d.shift, op.has_res ? P(op.res) : nullptr, P(op.out),
-                                op.out.B, op.out.H, op.out.W, op.out.C, op.conv->d.dil, op.conv->d.relu, s, op.wino_gran);
+                                op.out.B, op.out.H, op.out.W, op.out.C, op.conv->d.dil, op.conv->d.relu, s, op.wino_gran, op.conv->wino_m);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s);
     case OP_PPM_POOL:
@@ -650,7 +652,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
       L->name = "decode_head.bottleneck.conv[x]";
       if ((rc = upload_conv(*L, wx.data(), scale.data(), shift.data(), hc, inplanes, inplanes, 3, 3, 1, 1, 1, 1, cfg->precision))) return rc;
       if (cfg->conv_algo == PEANUT_ALGO_AUTO && wino_eligible(inplanes, hc, 3, 3, 1, 1, 1, cfg->precision) &&
-          (rc = upload_wino(*L, wx.data(), hc, inplanes, inplanes, cfg->precision)))
+          (rc = upload_wino(*L, wx.data(), hc, inplanes, inplanes, cfg->precision, 4)))   // F(4x4): see wino_tile_for
         return rc;
       h->bottleneck_x = L.get();
       h->convs.push_back(std::move(L));

@@ -179,6 +179,134 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// F(6x6, 3x3): 8x8 input tiles, 64 positions, 36 outputs per tile -- 1.78 multiplies per output instead of 2.25, and
+// V / M are 1.78 x the activations instead of 2.25 x.  Interpolation points 0, +-1/2, +-1, +-2, inf (the constants are
+// dyadic: exact in fp32); position order [0, 1/2, -1/2, 1, -1, 2, -2, inf].
+//   B^T = [-1 0 21/4 0 -21/4 0 1 0; 0 2 4 -5/2 -5 1/2 1 0; 0 -2 4 5/2 -5 -1/2 1 0; 0 1 1 -17/4 -17/4 1 1 0;
+//          0 -1 1 17/4 -17/4 -1 1 0; 0 1/2 1/4 -5/2 -5/4 2 1 0; 0 -1/2 1/4 5/2 -5/4 -2 1 0; 0 -1 0 21/4 0 -21/4 0 1]
+//   A^T = [1 1 1 1 1 1 1 0; 0 1/2 -1/2 1 -1 2 -2 0; 0 1/4 1/4 1 1 4 4 0; 0 1/8 -1/8 1 -1 8 -8 0;
+//          0 1/16 1/16 1 1 16 16 0; 0 1/32 -1/32 1 -1 32 -32 1]
+//   G   = [-1 0 0; 32/45 16/45 8/45; 32/45 -16/45 8/45; -2/9 -2/9 -2/9; -2/9 2/9 -2/9; 1/90 1/45 2/45; 1/90 -1/45 2/45; 0 0 1]
+// Operator-level rounding error about 3 x that of the F(4x4) form above with its 0, +-3/4, +-3/2 points and about that of
+// F(4x4) with the classic 0, +-1, +-2 points (cin = 512, post-ReLU data: rms 3-5e-6 vs 1.1e-6 vs 2.7e-6 relative).
+// One thread per (tile, 2-channel group): an 8x8 patch of 4-channel pieces would need 256 registers.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void bt8(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
+                                    const f32x2 d6, const f32x2 d7, f32x2& t0, f32x2& t1, f32x2& t2, f32x2& t3, f32x2& t4,
+                                    f32x2& t5, f32x2& t6, f32x2& t7) {
+  const f32x2 e1 = 4.f * d2 - 5.f * d4 + d6, o1 = 2.f * d1 - 2.5f * d3 + 0.5f * d5;
+  const f32x2 e2 = d2 - 4.25f * d4 + d6, o2 = d1 - 4.25f * d3 + d5;
+  const f32x2 e3 = 0.25f * d2 - 1.25f * d4 + d6, o3 = 0.5f * d1 - 2.5f * d3 + 2.f * d5;
+  const f32x2 r0 = (d6 - d0) + 5.25f * (d2 - d4), r7 = (d7 - d1) + 5.25f * (d3 - d5);
+  t0 = r0; t1 = e1 + o1; t2 = e1 - o1; t3 = e2 + o2; t4 = e2 - o2; t5 = e3 + o3; t6 = e3 - o3; t7 = r7;
+}
+
+__device__ __forceinline__ void at8(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
+                                    const f32x2 m6, const f32x2 m7, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3, f32x2& y4, f32x2& y5) {
+  const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4, s3 = m5 + m6, d3 = m5 - m6;
+  y0 = m0 + s1 + s2 + s3;
+  y1 = 0.5f * d1 + d2 + 2.f * d3;
+  y2 = 0.25f * s1 + s2 + 4.f * s3;
+  y3 = 0.125f * d1 + d2 + 8.f * d3;
+  y4 = 0.0625f * s1 + s2 + 16.f * s3;
+  y5 = 0.03125f * d1 + d2 + 32.f * d3 + m7;
+}
+
+// V[(i*8+j)][tile][c] = (B^T d B)[i][j]
+__global__ __launch_bounds__(256) void wino6_input_kernel(const float* __restrict__ x, float* __restrict__ V, const WinoGeom g) {
+  const int groups = g.C >> 1;
+  const long long total = g.n_tiles * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int cg;
+    long long tile;
+    if (!decode_thread(idx, groups, g.n_tiles, cg, tile)) continue;
+    int b, oy, ox, ty, tx;
+    decode_tile(g, tile, b, oy, ox, ty, tx);
+    const int r0 = oy + g.d * (6 * ty - 1), c0 = ox + g.d * (6 * tx - 1);
+    const float* xb = x + (size_t)b * g.H * g.W * g.C + cg * 2;
+    f32x2 p[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + i * g.d;
+      const bool rok = (unsigned)r < (unsigned)g.H;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j * g.d;
+        f32x2 v = {0.f, 0.f};
+        if (rok && (unsigned)c < (unsigned)g.W) v = *reinterpret_cast<const f32x2*>(xb + ((size_t)r * g.W + c) * g.C);
+        p[i][j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)   // columns: p <- B^T p
+      bt8(p[0][j], p[1][j], p[2][j], p[3][j], p[4][j], p[5][j], p[6][j], p[7][j],
+          p[0][j], p[1][j], p[2][j], p[3][j], p[4][j], p[5][j], p[6][j], p[7][j]);
+    float* vb = V + (size_t)tile * g.C + cg * 2;
+    const size_t pos_stride = (size_t)g.m_pad * g.C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // rows: (p B)[i][:]
+      f32x2 t[8];
+      bt8(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], p[i][6], p[i][7], t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+      float* o = vb + (size_t)(i * 8) * pos_stride;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x2*>(o + j * pos_stride) = t[j];
+    }
+  }
+}
+
+// y[pixel][n] = relu(scale[n] * (A^T M A)[a][b] + shift[n] + res[pixel][n]),  M: 64 positions
+__global__ __launch_bounds__(256) void wino6_output_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ res,
+                                                           float* __restrict__ y, const WinoGeom g, int relu) {
+  const int groups = g.C >> 1;
+  const long long total = g.n_tiles * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int ng;
+    long long tile;
+    if (!decode_thread(idx, groups, g.n_tiles, ng, tile)) continue;
+    int b, oy, ox, ty, tx;
+    decode_tile(g, tile, b, oy, ox, ty, tx);
+    const int r0 = oy + g.d * 6 * ty, c0 = ox + g.d * 6 * tx;
+    if (r0 >= g.H || c0 >= g.W) continue;   // tile entirely outside its sub-grid
+    const float* mb = Mb + (size_t)tile * g.C + ng * 2;
+    const size_t pos_stride = (size_t)g.m_pad * g.C;
+    f32x2 q[8][6];   // M A  (rows i, output columns)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float* s = mb + (size_t)(i * 8) * pos_stride;
+      f32x2 m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(s + j * pos_stride));
+      at8(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], q[i][0], q[i][1], q[i][2], q[i][3], q[i][4], q[i][5]);
+    }
+    const f32x2 sc = *reinterpret_cast<const f32x2*>(scale + ng * 2);
+    const f32x2 sh = *reinterpret_cast<const f32x2*>(shift + ng * 2);
+    const size_t img = (size_t)b * g.H * g.W;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x2 o[6];
+      at8(q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], o[0], o[1], o[2], o[3], o[4], o[5]);
+      const int c = c0 + j * g.d;
+      if (c >= g.W) continue;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int r = r0 + a * g.d;
+        if (r >= g.H) continue;
+        const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 2;
+        f32x2 v = o[a] * sc + sh;
+        if (res) v += *reinterpret_cast<const f32x2*>(res + off);
+        if (relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); }
+        *reinterpret_cast<f32x2*>(y + off) = v;
+      }
+    }
+  }
+}
+
 int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256LL * 64) blocks = 256LL * 64;
@@ -188,54 +316,66 @@ int grid_for(long long total) {
 
 }  // namespace
 
-void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad, int gran) {
+void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_tiles, long long* m_pad, int gran, int m) {
   const int hs = (H + dil - 1) / dil, wsub = (W + dil - 1) / dil;   // largest sub-grid
-  *th = (hs + 3) / 4;
-  *tw = (wsub + 3) / 4;
+  *th = (hs + m - 1) / m;
+  *tw = (wsub + m - 1) / m;
   *n_tiles = (long long)B * dil * dil * *th * *tw;
   *m_pad = (*n_tiles + gran - 1) / gran * gran;                      // whole GEMM tiles per position
 }
 
 // U[(i*6+l)][n][c] = (G g G^T)[i][l], accumulated in double and rounded once
-void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out) {
-  static const double G[6][3] = {{64.0 / 81, 0, 0},
-                                 {-128.0 / 243, -32.0 / 81, -8.0 / 27},
-                                 {-128.0 / 243, 32.0 / 81, -8.0 / 27},
-                                 {32.0 / 243, 16.0 / 81, 8.0 / 27},
-                                 {32.0 / 243, -16.0 / 81, 8.0 / 27},
-                                 {0, 0, 1}};
+void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, int m) {
+  static const double G4[6][3] = {{64.0 / 81, 0, 0},
+                                  {-128.0 / 243, -32.0 / 81, -8.0 / 27},
+                                  {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                                  {32.0 / 243, 16.0 / 81, 8.0 / 27},
+                                  {32.0 / 243, -16.0 / 81, 8.0 / 27},
+                                  {0, 0, 1}};
+  static const double G6[8][3] = {{-1, 0, 0},
+                                  {32.0 / 45, 16.0 / 45, 8.0 / 45},
+                                  {32.0 / 45, -16.0 / 45, 8.0 / 45},
+                                  {-2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                  {-2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                  {1.0 / 90, 1.0 / 45, 2.0 / 45},
+                                  {1.0 / 90, -1.0 / 45, 2.0 / 45},
+                                  {0, 0, 1}};
+  const int n_in = m + 2;                                       // 6 (F(4x4)) or 8 (F(6x6)) points per dimension
+  const double (*G)[3] = m == 6 ? G6 : G4;
   const size_t plane = (size_t)cout * cin;
   for (int n = 0; n < cout; ++n)
     for (int c = 0; c < cin; ++c) {
       const float* g = w_oihw + ((size_t)n * cin + c) * 9;
-      double t[6][3];
-      for (int i = 0; i < 6; ++i)
+      double t[8][3];
+      for (int i = 0; i < n_in; ++i)
         for (int k = 0; k < 3; ++k) t[i][k] = G[i][0] * g[0 * 3 + k] + G[i][1] * g[1 * 3 + k] + G[i][2] * g[2 * 3 + k];
-      for (int i = 0; i < 6; ++i)
-        for (int l = 0; l < 6; ++l)
-          out[(size_t)(i * 6 + l) * plane + (size_t)n * cin + c] =
+      for (int i = 0; i < n_in; ++i)
+        for (int l = 0; l < n_in; ++l)
+          out[(size_t)(i * n_in + l) * plane + (size_t)n * cin + c] =
               (float)(t[i][0] * G[l][0] + t[i][1] * G[l][1] + t[i][2] * G[l][2]);
     }
 }
 
-int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran) {
-  if (C % 4) return fail(-2, "wino_input: channels must be a multiple of 4");
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran, int m) {
+  if (C % 4 || (m != 4 && m != 6)) return fail(-2, "wino_input: channels must be a multiple of 4, tiles 4x4 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
-  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran);
-  const long long total = g.n_tiles * (C / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
+  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
+  const long long total = g.n_tiles * (m == 6 ? C / 2 : C / 4);
+  if (m == 6) hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
+  else hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_input launch: ") + hipGetErrorString(e));
   return 0;
 }
 
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
-                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran) {
-  if (C % 4) return fail(-2, "wino_output: channels must be a multiple of 4");
+                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran, int m) {
+  if (C % 4 || (m != 4 && m != 6)) return fail(-2, "wino_output: channels must be a multiple of 4, tiles 4x4 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
-  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran);
-  const long long total = g.n_tiles * (C / 4);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
+  const long long total = g.n_tiles * (m == 6 ? C / 2 : C / 4);
+  if (m == 6) hipLaunchKernelGGL(wino6_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  else hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_output launch: ") + hipGetErrorString(e));
   return 0;

@@ -513,6 +513,55 @@ def test_winograd_conv_matches_torch(case, precision, tol):
         assert not torch.equal(direct(xd, residual=rd), y)     # the two algorithms really are different code paths
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x3"])
+def test_winograd_6x6_tiles_match_torch(precision, monkeypatch):
+    """F(6x6,3x3) (csrc/winograd.hip: wino6_* kernels, 64 positions; what the prediction planner uses in the backbone):
+    the Winograd operator cases plus 16 seeded random layers -- dilation 1 / 2 / 4, maps that do not divide into 6 x 6
+    tiles, ragged cout -- against F.conv2d.  PEANUT_WINO_M = 6 selects the form at operator level (read at upload time).
+    About 3 x the rounding error of the F(4x4) form on N(0,1) data: asserted 4e-4 * (1 + |ref|) (measured <= 2.9e-4)."""
+    import random
+    from peanut_amd.ops import FusedConv
+    monkeypatch.setenv("PEANUT_WINO_M", "6")
+    r = random.Random(6)
+    cases = list(WINO_CASES)
+    for _ in range(16):
+        cases.append((r.randint(1, 3), r.randint(4, 40), r.randint(4, 40), 32 * r.randint(4, 20), 4 * r.randint(16, 140),
+                      r.choice([1, 1, 2, 4]), r.random() < 0.5, r.random() < 0.5))
+    worst = 0.0
+    for case in cases:
+        B, H, W, cin, cout, d, relu, residual = case
+        g = torch.Generator().manual_seed(B * 1000003 + H * 1009 + W * 31 + cin + cout + d)
+        x = _rand((B, cin, H, W), g)
+        w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = _rand((cout,), g, 0.1)
+        ref = F.conv2d(x, w, None, padding=d, dilation=d) * scale[None, :, None, None] + shift[None, :, None, None]
+        res = _rand(tuple(ref.shape), g) if residual else None
+        if residual:
+            ref = ref + res
+        if relu:
+            ref = F.relu(ref)
+        conv = FusedConv(w, scale, shift, padding=d, dilation=d, relu=relu, precision=precision)
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        y = conv(xd, residual=rd)
+        assert torch.equal(y, conv(xd, residual=rd))
+        err = ((y.permute(0, 3, 1, 2).cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        worst = max(worst, err)
+        assert err <= 4e-4, f"{case}: {err:.3e}"
+    monkeypatch.setenv("PEANUT_WINO_M", "4")
+    B, H, W, cin, cout, d, relu, residual = WINO_CASES[0]
+    g = torch.Generator().manual_seed(1)
+    x = _rand((B, H, W, cin), g).cuda()
+    w = _rand((cout, cin, 3, 3), g, 0.02)
+    monkeypatch.setenv("PEANUT_WINO_M", "6")
+    y6 = FusedConv(w, None, None, padding=d, dilation=d, precision=precision)(x)
+    monkeypatch.setenv("PEANUT_WINO_M", "4")
+    y4 = FusedConv(w, None, None, padding=d, dilation=d, precision=precision)(x)
+    assert not torch.equal(y4, y6) and float((y4 - y6).abs().max()) < 1e-3       # two different algorithms, same operator
+    print(f"F(6x6,3x3) {precision}: worst relative error over {len(cases)} layers {worst:.3e}")
+
+
 def test_pointwise_kernels_agree_with_and_without_lds_dma():
     """1x1 convs and the Winograd GEMMs run on conv_pw.hip's LDS-DMA kernel by default; PEANUT_PW_GLDS=0 (read once
     per process) sends them through the register-staged conv_igemm kernel.  Both are exact fp32 MFMA sums in the
