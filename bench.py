@@ -52,13 +52,14 @@ DTYPE = {"fp32": "f32",
 MODE_NOTES = {
     "fp16x3": "opt-in: 2 fp16 pieces per value (22 significand bits; activations split in registers, weights pre-split "
               "after a per-layer power-of-two scale), 3 MFMA products per fp32 product, fp32 accumulate; needs the "
-              "activations of the emulated layers below 65504 in magnitude",
-    "bf16x3": "opt-in speed mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; ~7e-5 max-abs "
+              "activations of the emulated layers below 65504 in magnitude; 1.19e-5 max-abs on the logits vs the reference "
+              "golden vectors, 5.4e-6 from the float64 run",
+    "bf16x3": "opt-in speed mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; ~1.4e-4 max-abs "
               "on the logits vs the reference golden vectors (bound 1e-3); not fp32-class, not the headline value",
     "bf16x6": "fp32 emulation on the bf16 matrix cores (csrc/gemm_rs.hip): activations stay fp32 in HBM / LDS and are split "
               "into 3 bf16 pieces in registers (exact split), weights pre-split, 6 MFMA products per fp32 product, fp32 "
-              "accumulate; 9.1e-6 max-abs on the logits vs the reference golden vectors, 5-6e-6 from a float64 run of the "
-              "reference model -- the level of the fp32 MFMA path (7.9e-6 / 5.3e-6) and of the reference's own fp32 CPU path "
+              "accumulate; 1.05e-5 max-abs on the logits vs the reference golden vectors, 6.9e-6 from a float64 run of the "
+              "reference model -- the level of the fp32 MFMA path (1.26e-5 / 8.3e-6) and of the reference's own fp32 CPU path "
               "(5.7e-6); reported next to the headline, which stays on fp32 MFMA instructions",
 }
 METRIC = "maps/sec for 480x480x(4+N_cat) prediction fwd, batch 32"
@@ -467,8 +468,9 @@ def main():
                        "parallelism": f"dp{world} (map shards, no data-path collective)"},
             "gflop_per_map_nominal": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
             "whole_forward_tflops_nominal": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
-            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 128 input channels (>= 256 in the emulated modes) as Winograd "
-                          "F(4x4,3x3) with fp32 transforms; pyramid half of the PSP bottleneck folded through linearity "
+            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 128 input channels as Winograd with fp32 "
+                          "transforms -- F(6x6,3x3) in the backbone up to dilation 2, F(4x4,3x3) in the PSP bottleneck and the "
+                          "dilation-4 layers; pyramid half of the PSP bottleneck folded through linearity "
                           "(nominal GFLOP/map counts the reference's 61 direct convs, so nominal TFLOP/s can exceed the MFMA peak)",
             "roofline": roof, "cpu_baseline": cpu,
         }

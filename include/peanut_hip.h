@@ -65,9 +65,10 @@ typedef struct peanut_pred_cfg {
   int conv_algo;         /* PEANUT_ALGO_*: algorithm of the stride-1 3x3 convs with >= 256 input channels */
 } peanut_pred_cfg;
 
-/* PEANUT_ALGO_AUTO: Winograd F(4x4,3x3) with fp32 transforms (what cuDNN/MIOpen pick for these layers in the
- * reference's own GPU runs): 4x fewer multiplies; interpolation points 0, +-3/4, +-3/2, inf keep the logits as close to the exact result
- * as the direct form (8e-6 max-abs vs the reference golden vectors, bound 1e-3).
+/* PEANUT_ALGO_AUTO: Winograd with fp32 transforms -- F(6x6,3x3) for the prediction backbone's layers up to dilation 2,
+ * F(4x4,3x3) for the PSP bottleneck, the dilation-4 layers, the detector and single convs -- (what cuDNN/MIOpen pick for these layers in the
+ * reference's own GPU runs): 4x / 5.1x fewer multiplies; well-conditioned interpolation points (0, +-3/4, +-3/2, inf; 0, +-1/2, +-1, +-2, inf)
+ * and the F(4x4) form next to the logits keep them within 1.3e-5 max-abs of the reference golden vectors (direct form 9e-6, bound 1e-3).
  * AUTO also runs conv3 and a stride-1 downsample / shortcut conv of a bottleneck block as ONE GEMM over [conv2 output | block
  * input] with the two BatchNorm scales folded into the weights (same function, another rounding order).
  * PEANUT_ALGO_DIRECT: every conv as the direct implicit GEMM (products summed exactly as an fmaf chain), every block in

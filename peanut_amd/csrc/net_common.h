@@ -99,6 +99,8 @@ struct ConvLayer {
   // output tile of the Winograd form: 4 (F(4x4,3x3), 36 positions) or 6 (F(6x6,3x3), 64 positions)
   int wino_m = 4;
   int wino_np() const { return (wino_m + 2) * (wino_m + 2); }
+  // the same layer with the F(4x4) form, kept next to an F(6x6) one: the planner picks per shape (wino_pick_form)
+  std::unique_ptr<ConvLayer> alt;
 };
 
 // emulation kind of a precision mode (rs_common.h: 2 = bf16x3, 3 = bf16x6, 4 = fp16x3; 0: fp32 MFMA mode)
@@ -264,6 +266,21 @@ inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
   const long long np = L.wino_np();
   if (g.rs) return gemm_rs_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;
   return (conv_pw_enabled() && conv_pw_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
+}
+
+// position-rows the Winograd GEMMs of this layer execute on an input [B,H,W,*]: positions x padded tiles
+inline long long wino_padded_rows(const ConvLayer& L, int B, int H, int W) {
+  int th, tw;
+  long long n_tiles, m_pad;
+  wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, wino_gran_for(L, B, H, W), L.wino_m);
+  return (long long)L.wino_np() * m_pad;
+}
+
+// F(6x6) layer with an F(4x4) twin: on small maps the 64 positions each pad their few tiles to a whole GEMM tile and the
+// 36-position form executes less (one 240 x 240 map: 25 tiles per position -> 64 x 128 rows against 36 x 128)
+inline const ConvLayer* wino_pick_form(const ConvLayer* L, int B, int H, int W) {
+  if (!L->has_wino || !L->alt || !L->alt->has_wino) return L;
+  return wino_padded_rows(*L->alt, B, H, W) * 10 <= wino_padded_rows(*L, B, H, W) * 9 ? L->alt.get() : L;
 }
 
 // floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]

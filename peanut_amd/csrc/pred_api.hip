@@ -148,6 +148,14 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, dil, h->cfg.precision) &&
       (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision, 0)))   // backbone: wino_tile_for's choice
     return rc;
+  if (L->has_wino && L->wino_m == 6) {      // the F(4x4) form of the same layer for the shapes where it executes less
+    L->alt = std::make_unique<ConvLayer>();
+    L->alt->name = conv;
+    if ((rc = upload_conv(*L->alt, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu, h->cfg.precision)) ||
+        (rc = upload_wino(*L->alt, w->data, cout, cin, cin_pad, h->cfg.precision, 4)))
+      return rc;
+    if (L->alt->wino_m != 4) L->alt.reset();                    // PEANUT_WINO_M forces one form
+  }
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
@@ -229,6 +237,7 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long lo
 // One conv layer into the plan.  `ar` is only needed for layers that carry a Winograd form (scratch for the transformed
 // tensors).
 void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr) {
+  if (L->has_wino && !in2 && ar) L = wino_pick_form(L, in.B, in.H, in.W);
   if (L->has_wino && !in2 && ar) {
     // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
     int th, tw;
@@ -240,17 +249,18 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     const long long npl = L->wino_np();
     Act v = make_act(*ar, 1, 1, (int)(npl * m_pad), in.C);
     Act m = make_act(*ar, 1, 1, (int)(npl * m_pad), L->d.cout);
-    Op a; a.kind = OP_WINO_IN; a.name = L->name + "[wino_in]"; a.kernel = "wino_input"; a.conv = L; a.in = in; a.out = v;
+    const std::string tag = L->wino_m == 6 ? "[wino6_" : "[wino_";       // op names / kernel families tell the two forms apart
+    Op a; a.kind = OP_WINO_IN; a.name = L->name + tag + "in]"; a.kernel = L->wino_m == 6 ? "wino6_input" : "wino_input"; a.conv = L; a.in = in; a.out = v;
     a.wino_gran = gran;
     a.bytes = (double)in.bytes + np * (double)n_tiles * in.C * 4.0;
     pl.ops.push_back(a);
-    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + "[wino_gemm]"; g.kernel = conv_kernel_name(L->wino, false, npl * m_pad, (int)(m_pad / 128)); g.conv = L;
+    Op g; g.kind = OP_WINO_GEMM; g.name = L->name + tag + "gemm]"; g.kernel = conv_kernel_name(L->wino, false, npl * m_pad, (int)(m_pad / 128)); g.conv = L;
     g.in = v; g.in.W = (int)(npl * m_pad); g.in.C = in.C; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
     g.flops = 2.0 * np * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
     g.bytes = np * (double)m_pad * (in.C * 4.0 + L->d.cout * 4.0) +
               np * (rs_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
     pl.ops.push_back(g);
-    Op o; o.kind = OP_WINO_OUT; o.name = L->name + "[wino_out]"; o.kernel = "wino_output"; o.conv = L; o.in = m; o.out = out;
+    Op o; o.kind = OP_WINO_OUT; o.name = L->name + tag + "out]"; o.kernel = L->wino_m == 6 ? "wino6_output" : "wino_output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
     o.wino_gran = gran;
     o.bytes = np * (double)n_tiles * L->d.cout * 4 + (double)out.bytes + (res ? (double)out.bytes : 0.0);

@@ -1,4 +1,5 @@
-// Winograd F(4x4, 3x3) for the stride-1 3x3 convolutions (fp32 transforms around the MFMA GEMM kernel).
+// Winograd F(4x4, 3x3) -- and, further down, F(6x6, 3x3) -- for the stride-1 3x3 convolutions (fp32 transforms around the
+// MFMA GEMM kernel).
 //
 //   Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A        (Lavin & Gray 2016; interpolation points 0, +-3/4, +-3/2, inf)
 //

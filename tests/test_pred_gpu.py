@@ -418,6 +418,12 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
         print(f"{precision}: B=10 480x480 vs oracle max-abs {err:.3e} (|logit| max {ref.abs().max().item():.2f}); "
               f"{len(on_family)} ops on {family}")
         assert err <= TOL, f"{precision}: logits max err {err:.3e}"
+        # the backbone's Winograd layers up to dilation 2 run the F(6x6) form at this size, the bottleneck and the dilation-4
+        # layers F(4x4) (csrc/net_common.h: wino_tile_for / wino_pick_form) -- so this comparison with the oracle covers both
+        for layer in ("layer2.1.conv2", "layer3.0.conv2", "layer3.3.conv2", "layer4.0.conv2"):
+            assert any(n.endswith(layer + "[wino6_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
+        for layer in ("layer4.1.conv2", "layer4.2.conv2", "bottleneck.conv[x]"):
+            assert any(n.endswith(layer + "[wino_gemm]") for n in ops), (precision, layer)
         for layer in layers:
             hit = [n for n in on_family if n.endswith(layer)]
             assert hit, f"{precision}: {layer} did not run on {family}: {[(n, k) for n, k in ops.items() if n.endswith(layer)]}"
