@@ -52,15 +52,15 @@ DTYPE = {"fp32": "f32",
 MODE_NOTES = {
     "fp16x3": "opt-in: 2 fp16 pieces per value (22 significand bits; activations split in registers, weights pre-split "
               "after a per-layer power-of-two scale), 3 MFMA products per fp32 product, fp32 accumulate; needs the "
-              "activations of the emulated layers below 65504 in magnitude; 1.19e-5 max-abs on the logits vs the reference "
-              "golden vectors, 5.4e-6 from the float64 run",
-    "bf16x3": "opt-in speed mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; ~1.4e-4 max-abs "
+              "activations of the emulated layers below 65504 in magnitude; 9.5e-6 max-abs on the logits vs the reference "
+              "golden vectors, 5-7e-6 from the float64 run",
+    "bf16x3": "opt-in speed mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; ~9e-5 max-abs "
               "on the logits vs the reference golden vectors (bound 1e-3); not fp32-class, not the headline value",
     "bf16x6": "fp32 emulation on the bf16 matrix cores (csrc/gemm_rs.hip): activations stay fp32 in HBM / LDS and are split "
               "into 3 bf16 pieces in registers (exact split), weights pre-split, 6 MFMA products per fp32 product, fp32 "
-              "accumulate; 1.05e-5 max-abs on the logits vs the reference golden vectors, 6.9e-6 from a float64 run of the "
-              "reference model -- the level of the fp32 MFMA path (1.26e-5 / 8.3e-6) and of the reference's own fp32 CPU path "
-              "(5.7e-6); reported next to the headline, which stays on fp32 MFMA instructions",
+              "accumulate; 9.1e-6 max-abs on the logits vs the reference golden vectors, 5-9e-6 from a float64 run of the "
+              "reference model (8.9e-6 at 480x480) -- the level of the fp32 MFMA path (7.9e-6 / 5-7e-6) and of the reference's own "
+              "fp32 CPU path (5.7e-6 / 7.7e-6); reported next to the headline, which stays on fp32 MFMA instructions",
 }
 METRIC = "maps/sec for 480x480x(4+N_cat) prediction fwd, batch 32"
 
