@@ -193,14 +193,16 @@ inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int
 // logits -- nearly all of it from the PSP bottleneck, whose K = 2048 accumulation error goes through A^T's factors of up to
 // 32 (1024 in 2-D) straight into conv_seg; the BACKBONE layers alone: +3.5 %, 7.9e-6 -> 7.2e-6 .. 1.26e-5 (distance to
 // the float64 run 5.3e-6 -> 7.6e-6).  So: the prediction planner asks for F(6x6) in the backbone and F(4x4) in the head.
-// With dilation 4 a 60 x 60 map's sub-grids are 15 x 15: 3 x 3 tiles of 6 (18 rows) or 4 x 4 tiles of 4 (16) are 576
-// position-tiles either way, hence F(6x6) only up to dilation 2.
+// Which of the two forms a backbone layer runs is decided per shape (wino_pick_form): with dilation 4 a 60 x 60 map's
+// sub-grids are 15 x 15 -- 3 x 3 tiles of 6 (18 rows) or 4 x 4 tiles of 4 (16): 576 position-tiles either way, F(4x4) stays
+// -- while a 720 x 720 map's 23 x 23 sub-grids take 4 x 4 tiles of 6 or 6 x 6 tiles of 4, and F(6x6) executes 0.71 of it.
 inline int wino_tile_for(int dil, int requested) {
   const char* e = getenv("PEANUT_WINO_M");
   const int forced = e ? atoi(e) : 0;
   if (forced == 4 || forced == 6) return forced;
   if (requested == 4 || requested == 6) return requested;
-  return dil <= 2 ? 6 : 4;
+  const char* md = getenv("PEANUT_WINO6_MAXDIL");            // A/B knob: largest dilation that gets an F(6x6) form at all
+  return dil <= (md ? atoi(md) : 4) ? 6 : 4;
 }
 
 // wino_m: 4 or 6, or 0 = wino_tile_for's choice
@@ -277,10 +279,12 @@ inline long long wino_padded_rows(const ConvLayer& L, int B, int H, int W) {
 }
 
 // F(6x6) layer with an F(4x4) twin: on small maps the 64 positions each pad their few tiles to a whole GEMM tile and the
-// 36-position form executes less (one 240 x 240 map: 25 tiles per position -> 64 x 128 rows against 36 x 128)
+// 36-position form executes less (one 240 x 240 map: 25 tiles per position -> 64 x 128 rows against 36 x 128); with
+// dilation 4 it depends on how the sub-grids divide into tiles
 inline const ConvLayer* wino_pick_form(const ConvLayer* L, int B, int H, int W) {
   if (!L->has_wino || !L->alt || !L->alt->has_wino) return L;
-  return wino_padded_rows(*L->alt, B, H, W) * 10 <= wino_padded_rows(*L, B, H, W) * 9 ? L->alt.get() : L;
+  // F(6x6) has to pay for its larger rounding error: only where it executes at least a tenth less
+  return wino_padded_rows(*L, B, H, W) * 10 <= wino_padded_rows(*L->alt, B, H, W) * 9 ? L : L->alt.get();
 }
 
 // floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]
