@@ -96,10 +96,11 @@ struct ConvLayer {
   // pointwise (d.w_s), of the 36 Winograd position matrices (wino.w_s, wino_group_bytes apart)
   DevBuf w_s, wino_w_s;
   size_t wino_group_bytes = 0;
-  // output tile of the Winograd form: 4 (F(4x4,3x3), 36 positions) or 6 (F(6x6,3x3), 64 positions)
+  // output tile of the Winograd form: 4 (F(4x4,3x3), 36 positions), 5 (F(5x5,3x3), 49) or 6 (F(6x6,3x3), 64)
   int wino_m = 4;
   int wino_np() const { return (wino_m + 2) * (wino_m + 2); }
-  // the same layer with the F(4x4) form, kept next to an F(6x6) one: the planner picks per shape (wino_pick_form)
+  // the same layer with another Winograd form (a chain: an F(6x6) layer keeps an F(4x4) twin and, where wino5_wanted says
+  // so, an F(5x5) one behind it): the planner picks per shape (wino_pick_form)
   std::unique_ptr<ConvLayer> alt;
 };
 
@@ -199,13 +200,24 @@ inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int
 inline int wino_tile_for(int dil, int requested) {
   const char* e = getenv("PEANUT_WINO_M");
   const int forced = e ? atoi(e) : 0;
-  if (forced == 4 || forced == 6) return forced;
-  if (requested == 4 || requested == 6) return requested;
+  if (forced >= 4 && forced <= 6) return forced;
+  if (requested >= 4 && requested <= 6) return requested;
   const char* md = getenv("PEANUT_WINO6_MAXDIL");            // A/B knob: largest dilation that gets an F(6x6) form at all
   return dil <= (md ? atoi(md) : 4) ? 6 : 4;
 }
 
-// wino_m: 4 or 6, or 0 = wino_tile_for's choice
+// Does a backbone layer also carry the F(5x5,3x3) form (winograd.hip)?  Its point is divisibility: the dilation-4 layers
+// of a 480 x 480 map work on 15 x 15 sub-grids, which 5 x 5 tiles cover exactly (441 position-tiles against 576 with
+// either other form: the position GEMMs and both transforms of layer4.1 / layer4.2 conv2 shrink to 0.77).  At dilation 1 / 2
+// F(6x6) executes less on every map size the agent uses, so those layers do not pay the upload for a third form
+// (PEANUT_WINO5_MINDIL: smallest dilation that gets one; 0 = none, 1 = every backbone layer).
+inline bool wino5_wanted(int dil) {
+  const char* e = getenv("PEANUT_WINO5_MINDIL");
+  const int mindil = e ? atoi(e) : 4;
+  return mindil > 0 && dil >= mindil;
+}
+
+// wino_m: 4, 5 or 6, or 0 = wino_tile_for's choice
 inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int cin_pad, int precision, int wino_m = 4) {
   ConvDesc& g = L.wino;
   L.wino_m = wino_tile_for(L.d.dil, wino_m);
@@ -283,8 +295,19 @@ inline long long wino_padded_rows(const ConvLayer& L, int B, int H, int W) {
 // dilation 4 it depends on how the sub-grids divide into tiles
 inline const ConvLayer* wino_pick_form(const ConvLayer* L, int B, int H, int W) {
   if (!L->has_wino || !L->alt || !L->alt->has_wino) return L;
-  // F(6x6) has to pay for its larger rounding error: only where it executes at least a tenth less
-  return wino_padded_rows(*L, B, H, W) * 10 <= wino_padded_rows(*L->alt, B, H, W) * 9 ? L : L->alt.get();
+  // the F(4x4) twin, and the cheapest of the larger-tile forms (a tie goes to the smaller tile: less rounding error)
+  const ConvLayer* f4 = nullptr;
+  const ConvLayer* big = nullptr;
+  long long big_rows = 0;
+  for (const ConvLayer* c = L; c && c->has_wino; c = c->alt.get()) {
+    if (c->wino_m == 4) { f4 = c; continue; }
+    const long long r = wino_padded_rows(*c, B, H, W);
+    if (!big || r < big_rows || (r == big_rows && c->wino_m < big->wino_m)) { big = c; big_rows = r; }
+  }
+  if (!f4) return big ? big : L;
+  if (!big) return f4;
+  // a larger tile has to pay for its larger rounding error: only where it executes at least a tenth less
+  return big_rows * 10 <= wino_padded_rows(*f4, B, H, W) * 9 ? big : f4;
 }
 
 // floats of the two Winograd scratch tensors (V: transformed input, M: GEMM output) for an input [B,H,W,*]

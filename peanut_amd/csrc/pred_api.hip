@@ -155,6 +155,14 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
         (rc = upload_wino(*L->alt, w->data, cout, cin, cin_pad, h->cfg.precision, 4)))
       return rc;
     if (L->alt->wino_m != 4) L->alt.reset();                    // PEANUT_WINO_M forces one form
+    if (L->alt && wino5_wanted(dil)) {                          // ... and the F(5x5) one (net_common.h: wino5_wanted)
+      auto& A5 = L->alt->alt;
+      A5 = std::make_unique<ConvLayer>();
+      A5->name = conv;
+      if ((rc = upload_conv(*A5, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu, h->cfg.precision)) ||
+          (rc = upload_wino(*A5, w->data, cout, cin, cin_pad, h->cfg.precision, 5)))
+        return rc;
+    }
   }
   *out = L.get();
   h->convs.push_back(std::move(L));
@@ -249,8 +257,9 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     const long long npl = L->wino_np();
     Act v = make_act(*ar, 1, 1, (int)(npl * m_pad), in.C);
     Act m = make_act(*ar, 1, 1, (int)(npl * m_pad), L->d.cout);
-    const std::string tag = L->wino_m == 6 ? "[wino6_" : "[wino_";       // op names / kernel families tell the two forms apart
-    Op a; a.kind = OP_WINO_IN; a.name = L->name + tag + "in]"; a.kernel = L->wino_m == 6 ? "wino6_input" : "wino_input"; a.conv = L; a.in = in; a.out = v;
+    const std::string fam = L->wino_m == 6 ? "wino6_" : (L->wino_m == 5 ? "wino5_" : "wino_");   // op names / kernel families tell the forms apart
+    const std::string tag = "[" + fam;
+    Op a; a.kind = OP_WINO_IN; a.name = L->name + tag + "in]"; a.kernel = fam + "input"; a.conv = L; a.in = in; a.out = v;
     a.wino_gran = gran;
     a.bytes = (double)in.bytes + np * (double)n_tiles * in.C * 4.0;
     pl.ops.push_back(a);
@@ -260,7 +269,7 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     g.bytes = np * (double)m_pad * (in.C * 4.0 + L->d.cout * 4.0) +
               np * (rs_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
     pl.ops.push_back(g);
-    Op o; o.kind = OP_WINO_OUT; o.name = L->name + tag + "out]"; o.kernel = L->wino_m == 6 ? "wino6_output" : "wino_output"; o.conv = L; o.in = m; o.out = out;
+    Op o; o.kind = OP_WINO_OUT; o.name = L->name + tag + "out]"; o.kernel = fam + "output"; o.conv = L; o.in = m; o.out = out;
     if (res) { o.res = *res; o.has_res = true; }
     o.wino_gran = gran;
     o.bytes = np * (double)n_tiles * L->d.cout * 4 + (double)out.bytes + (res ? (double)out.bytes : 0.0);

@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) -- and, further down, F(6x6, 3x3) -- for the stride-1 3x3 convolutions (fp32 transforms around the
+// Winograd F(4x4, 3x3) -- and, further down, F(6x6, 3x3) and F(5x5, 3x3) -- for the stride-1 3x3 convolutions (fp32 transforms around the
 // MFMA GEMM kernel).
 //
 //   Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A        (Lavin & Gray 2016; interpolation points 0, +-3/4, +-3/2, inf)
@@ -308,6 +308,134 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// F(5x5, 3x3): 7x7 input tiles, 49 positions, 25 outputs per tile -- 1.96 multiplies per output.  Between the other two
+// in cost and in rounding error (operator level, cin = 512, post-ReLU data: rms 4.9e-6 relative against 1.8e-6 for the
+// F(4x4) form and 6.4e-6 for F(6x6) in the same fp32 simulation); what it is FOR is divisibility: with dilation 4 a
+// 60 x 60 map's sub-grids are 15 x 15 = 3 x 3 tiles of 5 with no padding at all -- 9 x 49 = 441 position-tiles against
+// 16 x 36 = 576 (F(4x4), 16 of 15 rows used) or 9 x 64 = 576 (F(6x6), 18 of 15).
+// Seven points cannot all be paired: 0, +-1/2, +-1, 3, inf (position order [0, 1/2, -1/2, 1, -1, 3, inf]); of the
+// dyadic / small-integer choices for the unpaired point (+-1/4 .. +-3 with pairs +-1/2,+-1 / +-5/8,+-5/4 / +-3/4,+-3/2 /
+// +-1,+-2) this one had the smallest rms error; all constants exact in fp32.
+//   B^T = [-3/4 1/4 15/4 -5/4 -3 1 0; 0 3/2 5/2 -5/2 -5/2 1 0; 0 -3/2 7/2 1/2 -7/2 1 0; 0 3/4 1/2 -13/4 -2 1 0;
+//          0 -3/4 1 11/4 -4 1 0; 0 1/4 0 -5/4 0 1 0; 0 -3/4 1/4 15/4 -5/4 -3 1]
+//   A^T = [1 1 1 1 1 1 0; 0 1/2 -1/2 1 -1 3 0; 0 1/4 1/4 1 1 9 0; 0 1/8 -1/8 1 -1 27 0; 0 1/16 1/16 1 1 81 1]
+//   G   = [-4/3 0 0; 16/15 8/15 4/15; 16/21 -8/21 4/21; -1/3 -1/3 -1/3; -1/6 1/6 -1/6; 1/210 1/70 3/70; 0 0 1]
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bt7(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
+                                    const f32x2 d6, f32x2& t0, f32x2& t1, f32x2& t2, f32x2& t3, f32x2& t4, f32x2& t5, f32x2& t6) {
+  const f32x2 r0 = d5 - 0.75f * d0 + 0.25f * d1 + 3.75f * d2 - 1.25f * d3 - 3.f * d4;
+  const f32x2 r1 = d5 + 1.5f * d1 + 2.5f * (d2 - d3 - d4);
+  const f32x2 r2 = d5 - 1.5f * d1 + 3.5f * (d2 - d4) + 0.5f * d3;
+  const f32x2 r3 = d5 + 0.75f * d1 + 0.5f * d2 - 3.25f * d3 - 2.f * d4;
+  const f32x2 r4 = d5 - 0.75f * d1 + d2 + 2.75f * d3 - 4.f * d4;
+  const f32x2 r5 = d5 + 0.25f * d1 - 1.25f * d3;
+  const f32x2 r6 = d6 - 0.75f * d1 + 0.25f * d2 + 3.75f * d3 - 1.25f * d4 - 3.f * d5;
+  t0 = r0; t1 = r1; t2 = r2; t3 = r3; t4 = r4; t5 = r5; t6 = r6;
+}
+
+__device__ __forceinline__ void at7(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
+                                    const f32x2 m6, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3, f32x2& y4) {
+  const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  y0 = m0 + s1 + s2 + m5;
+  y1 = 0.5f * d1 + d2 + 3.f * m5;
+  y2 = 0.25f * s1 + s2 + 9.f * m5;
+  y3 = 0.125f * d1 + d2 + 27.f * m5;
+  y4 = 0.0625f * s1 + s2 + 81.f * m5 + m6;
+}
+
+// V[(i*7+j)][tile][c] = (B^T d B)[i][j]
+__global__ __launch_bounds__(256) void wino5_input_kernel(const float* __restrict__ x, float* __restrict__ V, const WinoGeom g) {
+  const int groups = g.C >> 1;
+  const long long total = g.n_tiles * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int cg;
+    long long tile;
+    if (!decode_thread(idx, groups, g.n_tiles, cg, tile)) continue;
+    int b, oy, ox, ty, tx;
+    decode_tile(g, tile, b, oy, ox, ty, tx);
+    const int r0 = oy + g.d * (5 * ty - 1), c0 = ox + g.d * (5 * tx - 1);
+    const float* xb = x + (size_t)b * g.H * g.W * g.C + cg * 2;
+    f32x2 p[7][7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int r = r0 + i * g.d;
+      const bool rok = (unsigned)r < (unsigned)g.H;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int c = c0 + j * g.d;
+        f32x2 v = {0.f, 0.f};
+        if (rok && (unsigned)c < (unsigned)g.W) v = *reinterpret_cast<const f32x2*>(xb + ((size_t)r * g.W + c) * g.C);
+        p[i][j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j)   // columns: p <- B^T p
+      bt7(p[0][j], p[1][j], p[2][j], p[3][j], p[4][j], p[5][j], p[6][j],
+          p[0][j], p[1][j], p[2][j], p[3][j], p[4][j], p[5][j], p[6][j]);
+    float* vb = V + (size_t)tile * g.C + cg * 2;
+    const size_t pos_stride = (size_t)g.m_pad * g.C;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {  // rows: (p B)[i][:]
+      f32x2 t[7];
+      bt7(p[i][0], p[i][1], p[i][2], p[i][3], p[i][4], p[i][5], p[i][6], t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
+      float* o = vb + (size_t)(i * 7) * pos_stride;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) *reinterpret_cast<f32x2*>(o + j * pos_stride) = t[j];
+    }
+  }
+}
+
+// y[pixel][n] = relu(scale[n] * (A^T M A)[a][b] + shift[n] + res[pixel][n]),  M: 49 positions
+__global__ __launch_bounds__(256) void wino5_output_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ res,
+                                                           float* __restrict__ y, const WinoGeom g, int relu) {
+  const int groups = g.C >> 1;
+  const long long total = g.n_tiles * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int ng;
+    long long tile;
+    if (!decode_thread(idx, groups, g.n_tiles, ng, tile)) continue;
+    int b, oy, ox, ty, tx;
+    decode_tile(g, tile, b, oy, ox, ty, tx);
+    const int r0 = oy + g.d * 5 * ty, c0 = ox + g.d * 5 * tx;
+    if (r0 >= g.H || c0 >= g.W) continue;   // tile entirely outside its sub-grid
+    const float* mb = Mb + (size_t)tile * g.C + ng * 2;
+    const size_t pos_stride = (size_t)g.m_pad * g.C;
+    f32x2 q[7][5];   // M A  (rows i, output columns)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float* s = mb + (size_t)(i * 7) * pos_stride;
+      f32x2 m[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(s + j * pos_stride));
+      at7(m[0], m[1], m[2], m[3], m[4], m[5], m[6], q[i][0], q[i][1], q[i][2], q[i][3], q[i][4]);
+    }
+    const f32x2 sc = *reinterpret_cast<const f32x2*>(scale + ng * 2);
+    const f32x2 sh = *reinterpret_cast<const f32x2*>(shift + ng * 2);
+    const size_t img = (size_t)b * g.H * g.W;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      f32x2 o[5];
+      at7(q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], o[0], o[1], o[2], o[3], o[4]);
+      const int c = c0 + j * g.d;
+      if (c >= g.W) continue;
+#pragma unroll
+      for (int a = 0; a < 5; ++a) {
+        const int r = r0 + a * g.d;
+        if (r >= g.H) continue;
+        const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 2;
+        f32x2 v = o[a] * sc + sh;
+        if (res) v += *reinterpret_cast<const f32x2*>(res + off);
+        if (relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); }
+        *reinterpret_cast<f32x2*>(y + off) = v;
+      }
+    }
+  }
+}
+
 int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256LL * 64) blocks = 256LL * 64;
@@ -341,8 +469,15 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, 
                                   {1.0 / 90, 1.0 / 45, 2.0 / 45},
                                   {1.0 / 90, -1.0 / 45, 2.0 / 45},
                                   {0, 0, 1}};
-  const int n_in = m + 2;                                       // 6 (F(4x4)) or 8 (F(6x6)) points per dimension
-  const double (*G)[3] = m == 6 ? G6 : G4;
+  static const double G5[7][3] = {{-4.0 / 3, 0, 0},
+                                  {16.0 / 15, 8.0 / 15, 4.0 / 15},
+                                  {16.0 / 21, -8.0 / 21, 4.0 / 21},
+                                  {-1.0 / 3, -1.0 / 3, -1.0 / 3},
+                                  {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                  {1.0 / 210, 1.0 / 70, 3.0 / 70},
+                                  {0, 0, 1}};
+  const int n_in = m + 2;                                       // 6 (F(4x4)), 7 (F(5x5)) or 8 (F(6x6)) points per dimension
+  const double (*G)[3] = m == 6 ? G6 : (m == 5 ? G5 : G4);
   const size_t plane = (size_t)cout * cin;
   for (int n = 0; n < cout; ++n)
     for (int c = 0; c < cin; ++c) {
@@ -358,11 +493,12 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, 
 }
 
 int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran, int m) {
-  if (C % 4 || (m != 4 && m != 6)) return fail(-2, "wino_input: channels must be a multiple of 4, tiles 4x4 or 6x6");
+  if (C % 4 || m < 4 || m > 6) return fail(-2, "wino_input: channels must be a multiple of 4, tiles 4x4, 5x5 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
-  const long long total = g.n_tiles * (m == 6 ? C / 2 : C / 4);
+  const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
   if (m == 6) hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
+  else if (m == 5) hipLaunchKernelGGL(wino5_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   else hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_input launch: ") + hipGetErrorString(e));
@@ -371,11 +507,12 @@ int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int 
 
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
                        int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran, int m) {
-  if (C % 4 || (m != 4 && m != 6)) return fail(-2, "wino_output: channels must be a multiple of 4, tiles 4x4 or 6x6");
+  if (C % 4 || m < 4 || m > 6) return fail(-2, "wino_output: channels must be a multiple of 4, tiles 4x4, 5x5 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
-  const long long total = g.n_tiles * (m == 6 ? C / 2 : C / 4);
+  const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
   if (m == 6) hipLaunchKernelGGL(wino6_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  else if (m == 5) hipLaunchKernelGGL(wino5_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   else hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_output launch: ") + hipGetErrorString(e));

@@ -513,16 +513,18 @@ def test_winograd_conv_matches_torch(case, precision, tol):
         assert not torch.equal(direct(xd, residual=rd), y)     # the two algorithms really are different code paths
 
 
+@pytest.mark.parametrize("tile", [6, 5])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x3"])
-def test_winograd_6x6_tiles_match_torch(precision, monkeypatch):
-    """F(6x6,3x3) (csrc/winograd.hip: wino6_* kernels, 64 positions; what the prediction planner uses in the backbone):
-    the Winograd operator cases plus 16 seeded random layers -- dilation 1 / 2 / 4, maps that do not divide into 6 x 6
-    tiles, ragged cout -- against F.conv2d.  PEANUT_WINO_M = 6 selects the form at operator level (read at upload time).
+def test_winograd_6x6_tiles_match_torch(precision, tile, monkeypatch):
+    """F(6x6,3x3) (csrc/winograd.hip: wino6_* kernels, 64 positions; what the prediction planner uses in the backbone) and
+    F(5x5,3x3) (wino5_*, 49 positions: the dilation-4 layers of a 480 x 480 map, whose 15 x 15 sub-grids it tiles exactly):
+    the Winograd operator cases plus 16 seeded random layers -- dilation 1 / 2 / 4, maps that do not divide into whole
+    tiles, ragged cout -- against F.conv2d.  PEANUT_WINO_M = 6 / 5 selects the form at operator level (read at upload time).
     About 3 x the rounding error of the F(4x4) form on N(0,1) data: asserted 4e-4 * (1 + |ref|) (measured <= 2.9e-4)."""
     import random
     from peanut_amd.ops import FusedConv
-    monkeypatch.setenv("PEANUT_WINO_M", "6")
-    r = random.Random(6)
+    monkeypatch.setenv("PEANUT_WINO_M", str(tile))
+    r = random.Random(tile)
     cases = list(WINO_CASES)
     for _ in range(16):
         cases.append((r.randint(1, 3), r.randint(4, 40), r.randint(4, 40), 32 * r.randint(4, 20), 4 * r.randint(16, 140),
@@ -554,12 +556,12 @@ def test_winograd_6x6_tiles_match_torch(precision, monkeypatch):
     g = torch.Generator().manual_seed(1)
     x = _rand((B, H, W, cin), g).cuda()
     w = _rand((cout, cin, 3, 3), g, 0.02)
-    monkeypatch.setenv("PEANUT_WINO_M", "6")
+    monkeypatch.setenv("PEANUT_WINO_M", str(tile))
     y6 = FusedConv(w, None, None, padding=d, dilation=d, precision=precision)(x)
     monkeypatch.setenv("PEANUT_WINO_M", "4")
     y4 = FusedConv(w, None, None, padding=d, dilation=d, precision=precision)(x)
     assert not torch.equal(y4, y6) and float((y4 - y6).abs().max()) < 1e-3       # two different algorithms, same operator
-    print(f"F(6x6,3x3) {precision}: worst relative error over {len(cases)} layers {worst:.3e}")
+    print(f"F({tile}x{tile},3x3) {precision}: worst relative error over {len(cases)} layers {worst:.3e}")
 
 
 def test_pointwise_kernels_agree_with_and_without_lds_dma():

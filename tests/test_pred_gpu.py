@@ -405,9 +405,9 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
         "fp32": ("conv_pw_glds_256x128", ["layer3.1.conv1", "layer4.0.conv1", "layer4.0.conv3+downsample", "layer4.2.conv1",
                                           "bottleneck.conv[x][wino_gemm]"]),
         "bf16x6": ("gemm_rs6_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
-                                        "layer4.1.conv2[wino_gemm]", "bottleneck.conv[x][wino_gemm]"]),
+                                        "layer4.1.conv2[wino5_gemm]", "bottleneck.conv[x][wino_gemm]"]),
         "fp16x3": ("gemm_rs3h_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
-                                         "layer4.1.conv2[wino_gemm]", "bottleneck.conv[x][wino_gemm]"]),
+                                         "layer4.1.conv2[wino5_gemm]", "bottleneck.conv[x][wino_gemm]"]),
     }
     for precision, (family, layers) in want.items():
         mm = m if precision == "fp32" else PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
@@ -418,12 +418,14 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
         print(f"{precision}: B=10 480x480 vs oracle max-abs {err:.3e} (|logit| max {ref.abs().max().item():.2f}); "
               f"{len(on_family)} ops on {family}")
         assert err <= TOL, f"{precision}: logits max err {err:.3e}"
-        # the backbone's Winograd layers up to dilation 2 run the F(6x6) form at this size, the bottleneck and the dilation-4
-        # layers F(4x4) (csrc/net_common.h: wino_tile_for / wino_pick_form) -- so this comparison with the oracle covers both
+        # the backbone's Winograd layers up to dilation 2 run the F(6x6) form at this size, the dilation-4 layers F(5x5) (their
+        # 15 x 15 sub-grids are 3 x 3 tiles of 5) and the bottleneck F(4x4) (csrc/net_common.h: wino_tile_for / wino5_wanted /
+        # wino_pick_form) -- so this comparison with the oracle covers all three forms
         for layer in ("layer2.1.conv2", "layer3.0.conv2", "layer3.3.conv2", "layer4.0.conv2"):
             assert any(n.endswith(layer + "[wino6_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
-        for layer in ("layer4.1.conv2", "layer4.2.conv2", "bottleneck.conv[x]"):
-            assert any(n.endswith(layer + "[wino_gemm]") for n in ops), (precision, layer)
+        for layer in ("layer4.1.conv2", "layer4.2.conv2"):
+            assert any(n.endswith(layer + "[wino5_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
+        assert any(n.endswith("bottleneck.conv[x][wino_gemm]") for n in ops), precision
         for layer in layers:
             hit = [n for n in on_family if n.endswith(layer)]
             assert hit, f"{precision}: {layer} did not run on {family}: {[(n, k) for n, k in ops.items() if n.endswith(layer)]}"
