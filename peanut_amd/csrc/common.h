@@ -42,6 +42,8 @@ struct ConvDesc {
   int s_planes;            // emulation kind (rs_common.h): 2 = bf16x3 (two bf16 pieces, three products), 3 = bf16x6 (three
                            // pieces, six products), 4 = fp16x3 (two fp16 pieces, three products)
   float s_alpha;           // 1 / the power of two the weights were scaled by before the split (fp16 pieces), else 1
+  int flush_ch;            // fp32 pointwise kernels (conv_pw.hip): channels per partial sum of the two-level fp32 accumulation (conv_common.h:
+                           // PEANUT_FLUSH_*), 0 = one running sum over all of K
 };
 
 struct ConvArgs {

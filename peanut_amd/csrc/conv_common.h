@@ -41,6 +41,7 @@ struct ConvKParams {
   int nchunk;                 // n-tiles per chunk of that order; 0 = plain order (n fastest over all n-tiles)
   int res_prefetch;           // epilogue: request the first rows of the residual before the accumulators go through LDS
   float alpha;                // y = relu(alpha * acc * scale + shift + res): 1 / the pack scale of fp16-piece weights, else 1
+  int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*
 };
 
 template <int I>
@@ -246,6 +247,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvKParams& p, const Work& 
     if (ep + 1 < EP) __syncthreads();
   }
 }
+
+// Two-level fp32 accumulation (ConvKParams::flush = F > 0; conv_pw.hip): the matrix cores add a k-tile's 32 products per output onto
+// one running sum, so the rounding error of a K-long contraction grows with the magnitude of that running sum (~ K in
+// units of one product's spread).  Every F k-tiles the running sums are moved into a second accumulator set and restarted
+// from zero: the partial sums stay small, and the error of a K = 2048 contraction drops about three-fold (fp32
+// simulation of the Winograd position GEMMs, post-ReLU data: F(4x4) 4.1e-6 -> 0.95e-6 rms, F(6x6) 1.2e-5 -> 3.0e-6 with
+// F = 2) -- which is what lets the larger-tile Winograd forms in where their A^T amplifies that error.  Cost per flush
+// and wave: one v_add + one v_mov per accumulator register, against F * 64 MFMAs.
+#define PEANUT_FLUSH_DECL()                                                        \
+  f32x16 acc2[MI][NI];                                                             \
+  _Pragma("unroll") for (int t = 0; t < MI; ++t)                                   \
+    _Pragma("unroll") for (int u = 0; u < NI; ++u)                                 \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc2[t][u][r] = 0.f;          \
+  int flush_left = p.flush > 0 ? p.flush : 0x7fffffff;
+#define PEANUT_FLUSH_STEP()                                                        \
+  if (--flush_left == 0) {                                                         \
+    flush_left = p.flush;                                                          \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                 \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u) {                             \
+        acc2[t][u] += acc[t][u];                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;         \
+      }                                                                            \
+  }
+#define PEANUT_FLUSH_FINISH()                                                      \
+  if (p.flush > 0) {                                                               \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                 \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u) acc[t][u] += acc2[t][u];      \
+  }
 
 // host side: pick split_p for T tiles over S resident workgroup slots on `cus` CUs; returns the number of tail tiles
 // (0 = no split).  The tail's t tiles cut p ways put ceil(t * p / cus) workgroups on the busiest CU, and co-resident

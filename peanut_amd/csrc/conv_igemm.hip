@@ -342,6 +342,7 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
   p.alpha = 1.f;
+  p.flush = d.rs ? 0 : d.flush_ch / d.bk;   // k-tiles per partial sum (conv_pw.hip; every other kernel keeps one running sum)
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
   if (d.rs) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
     if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");

@@ -31,7 +31,8 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 2 : (BN == 64 ? 3 : 4))))
+void conv_pw_glds_kernel(const ConvKParams p) {
   constexpr int BM = 128, BK = 32;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
     for (int u = 0; u < NI; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  PEANUT_FLUSH_DECL();
 
   constexpr int KH = BK / 16;   // 8-k groups per half
   f32x4 afA[KH][MI], bfA[KH][NI], afB[KH][MI], bfB[KH][NI];
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
     __builtin_amdgcn_sched_barrier(0);
     PEANUT_MFMA_HALF(afB, bfB);
     __builtin_amdgcn_sched_barrier(0);
+    PEANUT_FLUSH_STEP();
   }
   const ResPrefetch rp = conv_res_prefetch<BM, BN, EP, 256>(p, wk, m0, n0);   // under the last k-tile's MFMAs
   {   // last k-tile
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_pw_glds_kernel(const ConvKParams p) 
     PEANUT_MFMA_HALF(afA, bfA);
     PEANUT_MFMA_HALF(afB, bfB);
   }
+  PEANUT_FLUSH_FINISH();
   __syncthreads();
 #undef PEANUT_LOAD_FRAGS
 #undef PEANUT_MFMA_HALF
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
     for (int u = 0; u < NI; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  PEANUT_FLUSH_DECL();
 
   // prologue: two k-tiles in flight
   PW256_DMA_TILE(smem);
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
 #pragma unroll
           for (int u = 0; u < NI; ++u)
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+    PEANUT_FLUSH_STEP();
     // the next k-tile must have landed; the one just requested may stay in flight across the barrier
     if (more) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   }
 #undef PW256_DMA_TILE
 #undef PW256_BARRIER
+  PEANUT_FLUSH_FINISH();
   conv_epilogue<BM, BN, WM, WN, 1, NT>(p, wk, acc, smem, m0, n0);
 }
 

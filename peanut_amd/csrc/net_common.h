@@ -135,6 +135,7 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   d.rs = 0;
   d.s_planes = 0;
   d.s_alpha = 1.f;
+  d.flush_ch = 0;
   if (rs_planes_of(precision) && rs_bn_tile(cin_pad, cout, kh, kw, pad)) {
     d.rs = 1;
     d.s_planes = rs_planes_of(precision);
@@ -206,6 +207,33 @@ inline int wino_tile_for(int dil, int requested) {
   return dil <= (md ? atoi(md) : 4) ? 6 : 4;
 }
 
+// Winograd form of the PSP bottleneck over x: 0 = the backbone's policy (F(6x6) with an F(4x4) twin, chosen per shape) on
+// the fp32 MFMA kernels, whose position GEMMs accumulate in two levels (wino_flush_channels); F(4x4) in the emulated
+// modes, where gemm_rs.hip keeps one running sum (its 256 x 256 kernel has no registers for a second accumulator set, and
+// measured with the second level on the 128 x 128 kernel -- profiles/r4f -- F(6x6) bought no throughput there and cost
+// accuracy: 8.9e-6 -> 1.15e-5 / 7.0e-6 -> 9.3e-6 from the float64 run at 480 x 480 in bf16x6 / fp16x3).
+// PEANUT_WINO_HEAD_M = 4 / 5 / 6 pins one form.
+inline int wino_head_tile(int precision) {
+  const char* e = getenv("PEANUT_WINO_HEAD_M");
+  const int m = e ? atoi(e) : 0;
+  if (m >= 4 && m <= 6) return m;
+  return rs_planes_of(precision) ? 4 : 0;
+}
+
+// Channels per partial sum of the position GEMMs' two-level fp32 accumulation (conv_common.h: PEANUT_FLUSH_*; 0 = one
+// running sum).  The rounding error of a Winograd layer is the accumulation error of its position GEMMs times the
+// amplification of A^T (up to 32 per dimension for F(6x6)): with partial sums of 64 channels that error drops about
+// three-fold at K = 2048 (fp32 simulation: F(4x4) 4.1e-6 -> 0.95e-6 rms, F(6x6) 1.2e-5 -> 3.0e-6), and F(6x6) in the PSP
+// bottleneck lands at 6.1e-6 .. 8.6e-6 on the golden logits -- the level of F(4x4) with one running sum (6.7-7.9e-6);
+// F(6x6) with one running sum: 3.0-4.0e-5 (profiles/r4e, r4f).  Every Winograd GEMM of the fp32 MFMA kernels does it
+// (measured cost: within noise); PEANUT_WINO_FLUSH_CH overrides the 64 (a multiple of 32; 0 = off).
+inline int wino_flush_channels(bool rs) {
+  if (rs) return 0;
+  const char* e = getenv("PEANUT_WINO_FLUSH_CH");
+  const int ch = e ? atoi(e) : 64;
+  return (ch > 0 && ch % 32 == 0) ? ch : 0;
+}
+
 // Does a backbone layer also carry the F(5x5,3x3) form (winograd.hip)?  Its point is divisibility: the dilation-4 layers
 // of a 480 x 480 map work on 15 x 15 sub-grids, which 5 x 5 tiles cover exactly (441 position-tiles against 576 with
 // either other form: the position GEMMs and both transforms of layer4.1 / layer4.2 conv2 shrink to 0.77).  At dilation 1 / 2
@@ -235,6 +263,7 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   g.bk = 32;
   g.cout_pad = (cout + g.bn_tile - 1) / g.bn_tile * g.bn_tile;
   g.w_s = nullptr;
+  g.flush_ch = wino_flush_channels(g.rs != 0);
   const size_t gf = conv_packed_floats(cin_pad, cout, 1, 1, g.bn_tile);
   std::vector<float> U((size_t)np * cout * cin);
   wino_transform_weights(w_oihw, cout, cin, U.data(), L.wino_m);
@@ -267,6 +296,31 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
     L.wino_group_bytes = gb;
   }
   L.has_wino = true;
+  return 0;
+}
+
+// The Winograd forms of one stride-1 3x3 layer as the prediction planner wants them: the policy's form (wino_tile_for) and,
+// when that is F(6x6), an F(4x4) twin plus -- where wino5_wanted says so -- an F(5x5) one, each a full ConvLayer of its own
+// behind L.alt (wino_pick_form chooses per shape).  `requested`: 0 = policy, 4 / 5 / 6 = that form only.
+inline int upload_wino_forms(ConvLayer& L, const float* w_oihw, const float* scale, const float* shift, int cout, int cin,
+                             int cin_pad, int pad, int dil, int relu, int precision, int requested) {
+  int rc;
+  if ((rc = upload_wino(L, w_oihw, cout, cin, cin_pad, precision, requested))) return rc;
+  if (requested != 0 || L.wino_m != 6) return 0;
+  L.alt = std::make_unique<ConvLayer>();
+  L.alt->name = L.name;
+  if ((rc = upload_conv(*L.alt, w_oihw, scale, shift, cout, cin, cin_pad, 3, 3, 1, pad, dil, relu, precision)) ||
+      (rc = upload_wino(*L.alt, w_oihw, cout, cin, cin_pad, precision, 4)))
+    return rc;
+  if (L.alt->wino_m != 4) { L.alt.reset(); return 0; }           // PEANUT_WINO_M forces one form
+  if (wino5_wanted(dil)) {
+    auto& A5 = L.alt->alt;
+    A5 = std::make_unique<ConvLayer>();
+    A5->name = L.name;
+    if ((rc = upload_conv(*A5, w_oihw, scale, shift, cout, cin, cin_pad, 3, 3, 1, pad, dil, relu, precision)) ||
+        (rc = upload_wino(*A5, w_oihw, cout, cin, cin_pad, precision, 5)))
+      return rc;
+  }
   return 0;
 }
 

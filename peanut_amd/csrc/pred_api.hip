@@ -146,24 +146,8 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
                    h->cfg.precision);
   if (rc) return rc;
   if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, dil, h->cfg.precision) &&
-      (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision, 0)))   // backbone: wino_tile_for's choice
+      (rc = upload_wino_forms(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, pad, dil, relu, h->cfg.precision, 0)))
     return rc;
-  if (L->has_wino && L->wino_m == 6) {      // the F(4x4) form of the same layer for the shapes where it executes less
-    L->alt = std::make_unique<ConvLayer>();
-    L->alt->name = conv;
-    if ((rc = upload_conv(*L->alt, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu, h->cfg.precision)) ||
-        (rc = upload_wino(*L->alt, w->data, cout, cin, cin_pad, h->cfg.precision, 4)))
-      return rc;
-    if (L->alt->wino_m != 4) L->alt.reset();                    // PEANUT_WINO_M forces one form
-    if (L->alt && wino5_wanted(dil)) {                          // ... and the F(5x5) one (net_common.h: wino5_wanted)
-      auto& A5 = L->alt->alt;
-      A5 = std::make_unique<ConvLayer>();
-      A5->name = conv;
-      if ((rc = upload_conv(*A5, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu, h->cfg.precision)) ||
-          (rc = upload_wino(*A5, w->data, cout, cin, cin_pad, h->cfg.precision, 5)))
-        return rc;
-    }
-  }
   *out = L.get();
   h->convs.push_back(std::move(L));
   return 0;
@@ -671,7 +655,8 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
       L->name = "decode_head.bottleneck.conv[x]";
       if ((rc = upload_conv(*L, wx.data(), scale.data(), shift.data(), hc, inplanes, inplanes, 3, 3, 1, 1, 1, 1, cfg->precision))) return rc;
       if (cfg->conv_algo == PEANUT_ALGO_AUTO && wino_eligible(inplanes, hc, 3, 3, 1, 1, 1, cfg->precision) &&
-          (rc = upload_wino(*L, wx.data(), hc, inplanes, inplanes, cfg->precision, 4)))   // F(4x4): see wino_tile_for
+          (rc = upload_wino_forms(*L, wx.data(), scale.data(), shift.data(), hc, inplanes, inplanes, 1, 1, 1, cfg->precision,
+                                  wino_head_tile(cfg->precision))))
         return rc;
       h->bottleneck_x = L.get();
       h->convs.push_back(std::move(L));

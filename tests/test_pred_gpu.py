@@ -391,8 +391,8 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
     large-tile kernel does so here too (36 000 rows: conv_pw_uses_256 needs M * cout >= 8.39 M, gemm_rs_uses_256 16.8 M) --
     asserted by kernel family name per op, so that a change of a gate cannot silently take these kernels out of the
     oracle's reach again.  fp32: conv_pw_glds256_kernel (layer3 conv1, layer4 conv1, layer4.0 conv3 + downsample, the
-    bottleneck's Winograd GEMM); bf16x6: gemm_rs_kernel<256,256> (layer3.0 / layer4.0 conv3 + downsample, layer4 conv1 /
-    conv3 / Winograd GEMMs, the bottleneck)."""
+    bottleneck's Winograd GEMM); bf16x6 / fp16x3: gemm_rs_kernel<256,256> (layer3.0 / layer4.0 conv3 + downsample, layer4
+    conv1 / conv3 / Winograd GEMMs, the bottleneck)."""
     from bench import synth_maps
     from oracle import pspnet_ref
     from peanut_amd.prediction import PEANUT_Prediction_Model
@@ -403,7 +403,7 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
     xd = x.cuda()
     want = {
         "fp32": ("conv_pw_glds_256x128", ["layer3.1.conv1", "layer4.0.conv1", "layer4.0.conv3+downsample", "layer4.2.conv1",
-                                          "bottleneck.conv[x][wino_gemm]"]),
+                                          "bottleneck.conv[x][wino6_gemm]"]),
         "bf16x6": ("gemm_rs6_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
                                         "layer4.1.conv2[wino5_gemm]", "bottleneck.conv[x][wino_gemm]"]),
         "fp16x3": ("gemm_rs3h_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
@@ -418,14 +418,17 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
         print(f"{precision}: B=10 480x480 vs oracle max-abs {err:.3e} (|logit| max {ref.abs().max().item():.2f}); "
               f"{len(on_family)} ops on {family}")
         assert err <= TOL, f"{precision}: logits max err {err:.3e}"
-        # the backbone's Winograd layers up to dilation 2 run the F(6x6) form at this size, the dilation-4 layers F(5x5) (their
-        # 15 x 15 sub-grids are 3 x 3 tiles of 5) and the bottleneck F(4x4) (csrc/net_common.h: wino_tile_for / wino5_wanted /
-        # wino_pick_form) -- so this comparison with the oracle covers all three forms
+        # the backbone's Winograd layers up to dilation 2 run the F(6x6) form at this size and the dilation-4 layers F(5x5)
+        # (their 15 x 15 sub-grids are 3 x 3 tiles of 5): csrc/net_common.h, wino_tile_for / wino5_wanted / wino_pick_form.
+        # The PSP bottleneck: F(6x6) on the fp32 MFMA kernels, whose position GEMMs accumulate in two levels (partial sums
+        # of 64 channels: what makes the form admissible over K = 2048), F(4x4) in the emulated modes (wino_head_tile).
+        # The small golden cases run the F(4x4) form everywhere -- so the comparisons with the oracle cover all three.
         for layer in ("layer2.1.conv2", "layer3.0.conv2", "layer3.3.conv2", "layer4.0.conv2"):
             assert any(n.endswith(layer + "[wino6_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
         for layer in ("layer4.1.conv2", "layer4.2.conv2"):
             assert any(n.endswith(layer + "[wino5_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
-        assert any(n.endswith("bottleneck.conv[x][wino_gemm]") for n in ops), precision
+        head = "bottleneck.conv[x][wino6_gemm]" if precision == "fp32" else "bottleneck.conv[x][wino_gemm]"
+        assert any(n.endswith(head) for n in ops), (precision, [n for n in ops if "bottleneck.conv[x]" in n])
         for layer in layers:
             hit = [n for n in on_family if n.endswith(layer)]
             assert hit, f"{precision}: {layer} did not run on {family}: {[(n, k) for n, k in ops.items() if n.endswith(layer)]}"
