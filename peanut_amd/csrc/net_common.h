@@ -179,13 +179,25 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
 }
 
 // Adds the Winograd form to an uploaded stride-1 3x3 layer (keeps the direct form for the two-source path).
-inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int pad, int dil, int precision) {
-  // measured (profiles/r2s): from 128 input channels on (+1.2 % on the headline, +1.8 % on the detector; 64 adds 0.1 %);
-  // the transforms are fp32 in every precision mode
+inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int pad, int dil, int precision, int min_cin_default = 128) {
+  // measured (profiles/r2s): from 128 input channels on (+1.2 % on the headline, +1.8 % on the detector; 64 adds 0.1 % with
+  // the F(4x4) form).  The prediction planner passes 64: with F(6x6) (V / M 1.78 x the activations instead of 2.25 x) layer1's
+  // conv2 goes from 0.331 to 0.236 ms per launch at batch 32 (profiles/r4h: 829.4 -> 835.9 maps/s), and push_conv keeps
+  // such layers on the direct kernel where the launch is too small to pay for three (wino_min_pixels).  The transforms
+  // are fp32 in every precision mode.
+  // In the three-product modes the direct register-split kernel (conv_rs.hip) is the faster one for those narrow layers
+  // (fp16x3, layer1 conv2: 0.175 ms direct, 0.21 ms as Winograd; bf16x6: 0.248 -> 0.22 ms; profiles/r4i): they keep 128.
   static const int env_min = [] { const char* e = getenv("PEANUT_WINO_MIN_CIN"); return e ? atoi(e) : 0; }();
-  const int min_cin = env_min ? env_min : 128;
-  (void)precision;
+  const bool three_products = precision == PEANUT_PREC_FP16X3 || precision == PEANUT_PREC_BF16X3;
+  const int min_cin = env_min ? env_min : (three_products && min_cin_default < 128 ? 128 : min_cin_default);
   return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 && cout >= 64;
+}
+
+// Layers with fewer than 128 input channels take their Winograd form only from this many input pixels on: below it the
+// direct kernel's one launch beats transform + GEMM + transform (one 240 x 240 map: 3 600 pixels in layer1)
+inline long long wino_min_pixels(int cin_pad) {
+  static const long long env = [] { const char* e = getenv("PEANUT_WINO_NARROW_MINPIX"); return e ? atoll(e) : 100000LL; }();
+  return cin_pad < 128 ? env : 0;
 }
 
 // Tile size of a layer's Winograd form (requested = 0: this policy; 4 / 6: the caller's choice; PEANUT_WINO_M = 4 / 6

@@ -145,7 +145,7 @@ int add_conv(peanut_pred* h, const TensorMap& tm, const std::string& conv, const
   rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, dil, relu,
                    h->cfg.precision);
   if (rc) return rc;
-  if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, dil, h->cfg.precision) &&
+  if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, dil, h->cfg.precision, 64) &&
       (rc = upload_wino_forms(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, pad, dil, relu, h->cfg.precision, 0)))
     return rc;
   *out = L.get();
@@ -229,8 +229,9 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long lo
 // One conv layer into the plan.  `ar` is only needed for layers that carry a Winograd form (scratch for the transformed
 // tensors).
 void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, const Act* res, const Act& out, Arena* ar = nullptr) {
-  if (L->has_wino && !in2 && ar) L = wino_pick_form(L, in.B, in.H, in.W);
-  if (L->has_wino && !in2 && ar) {
+  const bool wino = L->has_wino && !in2 && ar && (long long)in.B * in.H * in.W >= wino_min_pixels(L->d.cin);
+  if (wino) L = wino_pick_form(L, in.B, in.H, in.W);
+  if (wino) {
     // V = B^T d B  ->  36 grouped GEMMs  ->  A^T M A + BN/residual/ReLU   (winograd.hip)
     int th, tw;
     long long n_tiles, m_pad;
