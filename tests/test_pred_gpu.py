@@ -296,6 +296,34 @@ def test_winograd_and_direct_conv_algorithms_agree(model_and_sd, golden_dir):
     assert worst_a <= TOL and worst_d <= 2e-5
 
 
+@pytest.mark.parametrize("tile", [5, 6])
+def test_forced_winograd_forms_match_reference_goldens(golden_dir, tile, monkeypatch):
+    """The planner picks a Winograd form per shape, and the small golden cases end up on F(4x4) (a position's few tiles pad
+    to one GEMM tile either way).  PEANUT_WINO_M = 5 / 6 (read at upload time) forces F(5x5) / F(6x6) on EVERY Winograd
+    layer -- PSP bottleneck included -- so that each form is also held against logits produced by the reference's own
+    files, not only against the oracle at ten 480 x 480 maps: same tolerance (5e-5 asserted; the two-level accumulation
+    of the position GEMMs is what keeps the larger tiles there, csrc/net_common.h: wino_flush_channels)."""
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    monkeypatch.setenv("PEANUT_WINO_M", str(tile))
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    worst = 0.0
+    for case in ("cfg1_240", "b2_96", "odd_100", "rect_72x104"):
+        x = torch.from_numpy(z[f"{case}/input"].astype(np.float32)).cuda()
+        ref = torch.from_numpy(z[f"{case}/logits"])
+        got = m.get_prediction_batch(x, apply_sigmoid=False).cpu()
+        worst = max(worst, (got - ref).abs().max().item())
+        names = [n for n, *_ in m.model.profile(x)]
+        gemms = [n for n in names if "_gemm]" in n]
+        assert gemms and all(n.endswith(f"[wino{tile}_gemm]") for n in gemms), (case, gemms)
+        assert any("bottleneck.conv[x]" in n for n in gemms), case
+    print(f"F({tile}x{tile},3x3) forced on every Winograd layer: max-abs vs reference golden logits {worst:.3e}")
+    assert worst <= TOL
+
+
 def test_graph_replay_is_bit_identical(model_and_sd):
     """peanut_pred_use_graph: the ~85 launches of a forward replayed as one hipGraph give bit-identical output
     (first call direct, second captured, later ones replayed; a second shape gets its own graph)."""
@@ -427,6 +455,10 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
             assert any(n.endswith(layer + "[wino6_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
         for layer in ("layer4.1.conv2", "layer4.2.conv2"):
             assert any(n.endswith(layer + "[wino5_gemm]") for n in ops), (precision, layer, [n for n in ops if layer in n])
+        # layer1's 64-channel conv2 takes the Winograd form from 100 000 pixels on (144 000 here) in fp32 and bf16x6; the
+        # three-product modes keep their direct register-split kernel there (wino_eligible / wino_min_pixels)
+        narrow = [n for n in ops if "layer1.1.conv2" in n]
+        assert any(n.endswith("[wino6_gemm]") for n in narrow) == (precision != "fp16x3"), (precision, narrow)
         head = "bottleneck.conv[x][wino6_gemm]" if precision == "fp32" else "bottleneck.conv[x][wino_gemm]"
         assert any(n.endswith(head) for n in ops), (precision, [n for n in ops if "bottleneck.conv[x]" in n])
         for layer in layers:
