@@ -194,6 +194,13 @@ using namespace peanut;
 
 namespace {
 
+// Winograd form request of the detector's front-end convs: 0 = per-shape policy; PEANUT_RCNN_WINO_M = 4 pins F(4x4) (A/B)
+int rcnn_wino_request() {
+  const char* e = getenv("PEANUT_RCNN_WINO_M");
+  const int m = e ? atoi(e) : 0;
+  return (m >= 4 && m <= 6) ? m : 0;
+}
+
 int add_rconv(peanut_rcnn* h, const TensorMap& tm, const std::string& name, int cin, int cin_pad, int cout, int k,
               int stride, int pad, bool norm, int relu, ConvLayer** out) {
   int rc = 0;
@@ -214,8 +221,11 @@ int add_rconv(peanut_rcnn* h, const TensorMap& tm, const std::string& name, int 
   if ((rc = upload_conv(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, k, k, stride, pad, 1, relu,
                         h->cfg.precision)))
     return rc;
+  // fp32 kernels: the prediction planner's forms (F(6x6) with an F(4x4) twin, chosen per shape in push_rconv; the position
+  // GEMMs accumulate in two levels, net_common.h); emulated modes: F(4x4)
   if (h->cfg.conv_algo == PEANUT_ALGO_AUTO && wino_eligible(cin_pad, cout, k, k, stride, pad, 1, h->cfg.precision) &&
-      (rc = upload_wino(*L, w->data, cout, cin, cin_pad, h->cfg.precision)))
+      (rc = upload_wino_forms(*L, w->data, scale.data(), shift.data(), cout, cin, cin_pad, pad, 1, relu, h->cfg.precision,
+                              rs_planes_of(h->cfg.precision) ? 4 : rcnn_wino_request())))
     return rc;
   *out = L.get();
   h->convs.push_back(std::move(L));
@@ -297,6 +307,7 @@ void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
 }
 
 void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
+  if (L->has_wino) L = wino_pick_form(L, in.B, in.H, in.W);
   ROp op;
   op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
   op.kernel = L->d.rs ? std::string(L->d.rs == 2 ? "conv_rs" : "gemm_rs") + (L->d.s_planes == 3 ? "6" : (L->d.s_planes == 4 ? "3h" : "3"))
