@@ -468,9 +468,11 @@ def main():
                        "parallelism": f"dp{world} (map shards, no data-path collective)"},
             "gflop_per_map_nominal": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
             "whole_forward_tflops_nominal": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
-            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 128 input channels as Winograd with fp32 "
-                          "transforms -- F(6x6,3x3) in the backbone up to dilation 2, F(4x4,3x3) in the PSP bottleneck and the "
-                          "dilation-4 layers; pyramid half of the PSP bottleneck folded through linearity "
+            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 64 input channels as Winograd with fp32 "
+                          "transforms, form chosen per shape -- at this size F(6x6,3x3) up to dilation 2 (PSP bottleneck included "
+                          "in the fp32 mode, whose position GEMMs accumulate in two levels: partial sums of 64 channels), "
+                          "F(5x5,3x3) for the dilation-4 layers (15x15 sub-grids), F(4x4,3x3) in the bottleneck of the emulated "
+                          "modes; pyramid half of the PSP bottleneck folded through linearity "
                           "(nominal GFLOP/map counts the reference's 61 direct convs, so nominal TFLOP/s can exceed the MFMA peak)",
             "roofline": roof, "cpu_baseline": cpu,
         }
