@@ -62,13 +62,16 @@ typedef struct peanut_pred_cfg {
   int fold_ppm;          /* 1: evaluate the pyramid half of the PSP bottleneck conv through linearity
                             (conv of a bilinear upsample of k*k vectors = bilinear blend of k*k folded
                             vectors; halves that conv's FLOPs, fp32 re-association only); 0: plain conv */
-  int conv_algo;         /* PEANUT_ALGO_*: algorithm of the stride-1 3x3 convs with >= 256 input channels */
+  int conv_algo;         /* PEANUT_ALGO_*: algorithm of the stride-1 3x3 convs with >= 64 input channels */
 } peanut_pred_cfg;
 
-/* PEANUT_ALGO_AUTO: Winograd with fp32 transforms -- F(6x6,3x3) for the prediction backbone's layers up to dilation 2,
- * F(4x4,3x3) for the PSP bottleneck, the dilation-4 layers, the detector and single convs -- (what cuDNN/MIOpen pick for these layers in the
- * reference's own GPU runs): 4x / 5.1x fewer multiplies; well-conditioned interpolation points (0, +-3/4, +-3/2, inf; 0, +-1/2, +-1, +-2, inf)
- * and the F(4x4) form next to the logits keep them within 1.3e-5 max-abs of the reference golden vectors (direct form 9e-6, bound 1e-3).
+/* PEANUT_ALGO_AUTO: Winograd with fp32 transforms, the form chosen per layer and shape -- F(6x6,3x3), F(5x5,3x3) (dilation-4
+ * layers of the prediction backbone) or F(4x4,3x3) in the prediction model and the detector's front end, F(4x4,3x3) for
+ * single convs, the detector heads and the PSP bottleneck of the emulated modes -- (what cuDNN/MIOpen pick for these layers
+ * in the reference's own GPU runs): 4x / 4.6x / 5.1x fewer multiplies; well-conditioned interpolation points (0, +-3/4,
+ * +-3/2, inf; 0, +-1/2, +-1, 3, inf; 0, +-1/2, +-1, +-2, inf) and position GEMMs that accumulate in two levels on the fp32
+ * kernels (partial sums of 64 channels) keep the logits within 1e-5 max-abs of the reference golden vectors (direct form
+ * 9e-6, bound 1e-3).
  * AUTO also runs conv3 and a stride-1 downsample / shortcut conv of a bottleneck block as ONE GEMM over [conv2 output | block
  * input] with the two BatchNorm scales folded into the weights (same function, another rounding order).
  * PEANUT_ALGO_DIRECT: every conv as the direct implicit GEMM (products summed exactly as an fmaf chain), every block in
@@ -223,7 +226,7 @@ typedef struct peanut_rcnn_cfg {
   float pixel_mean[3], pixel_std[3]; /* BGR (103.53, 116.28, 123.675), (1, 1, 1) */
   float bn_eps;            /* FrozenBatchNorm2d eps 1e-5 */
   int precision;           /* PEANUT_PREC_* */
-  int conv_algo;           /* PEANUT_ALGO_* (Winograd for the stride-1 3x3 convs with >= 256 input channels) */
+  int conv_algo;           /* PEANUT_ALGO_* (Winograd for the stride-1 3x3 convs with >= 128 input channels) */
   /* proposal generator and ROI heads (yaml :41-57, :163-253, :312); read by peanut_rcnn_inference only */
   float anchor_sizes[5];   /* ANCHOR_GENERATOR.SIZES, one per level p2..p6 (32, 64, 128, 256, 512) */
   float aspect_ratios[8];  /* ANCHOR_GENERATOR.ASPECT_RATIOS (0.5, 1, 2): num_anchors entries */
@@ -351,7 +354,7 @@ typedef struct peanut_conv peanut_conv_t;
  * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X6 / BF16X3: in the emulated modes a pointwise layer with
  * >= 64 output channels and the position GEMMs of a Winograd layer run on the bf16 matrix cores, every other layer in fp32;
  * peanut_conv_precision() returns the PEANUT_PREC_* mode the layer actually runs in (no silent change of arithmetic).  conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
- * >= 256 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */
+ * >= 128 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */
 int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
                        const float* shift_host, int cout, int cin, int cin_pad, int kh, int kw, int stride,
                        int pad, int dil, int relu, int precision, int conv_algo);

@@ -21,7 +21,7 @@ class FusedConv:
 
     weight: [cout, cin, kh, kw] (OIHW, host or device tensor); the NHWC input must carry
     ``cin_pad`` channels (multiple of 16; default round_up(cin, 16)), padded channels are ignored.
-    ``conv_algo='auto'`` runs stride-1 3x3 layers with >= 256 input channels as Winograd F(4x4,3x3)
+    ``conv_algo='auto'`` runs stride-1 3x3 layers with >= 128 input channels as Winograd F(4x4,3x3)
     (fp32 transforms, csrc/winograd.hip); ``'direct'`` always uses the direct implicit GEMM.
     """
 
