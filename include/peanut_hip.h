@@ -41,6 +41,10 @@ const char* peanut_source_hash(void);
  * patterns (bf16 or fp16; plane 2 zero for the two-piece modes); *pack_scale = the power of two the values were multiplied
  * by first (1 for the bf16 modes).  tests/test_abi.py compares them with numpy's / torch's own roundings. */
 int peanut_debug_weight_pieces(const float* values, int n, int precision, unsigned short* pieces, float* pack_scale);
+/* Host-side test hook (no GPU needed): the Winograd weight transform U = G g G^T of a [cout][cin][3][3] layer for output
+ * tiles of tile x tile (4, 5 or 6; csrc/winograd.hip), as the uploader computes it (double arithmetic, rounded once):
+ * out [(tile + 2)^2][cout][cin].  tests/test_abi.py holds it against the Toom-Cook construction in exact rationals. */
+int peanut_debug_wino_weights(const float* w_oihw, int cout, int cin, int tile, float* out);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 3 -- map-completion forward (PSPNet: ResNet-50-V1c-D8 + PSP head)

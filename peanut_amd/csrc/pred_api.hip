@@ -572,7 +572,7 @@ extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
-int peanut_abi_version(void) { return 9; }
+int peanut_abi_version(void) { return 10; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 #ifndef PEANUT_SOURCE_HASH
 #define PEANUT_SOURCE_HASH ""
@@ -891,6 +891,12 @@ int peanut_debug_weight_pieces(const float* values, int n, int precision, unsign
   for (int q = 0; q < 3; ++q)
     for (int c = 0; c < n; ++c)
       pieces[(size_t)q * n + c] = q < np ? o[((size_t)(c / 16) * np + q) * bn * 16 + (c % 16)] : (unsigned short)0;
+  return 0;
+}
+
+int peanut_debug_wino_weights(const float* w_oihw, int cout, int cin, int tile, float* out) {
+  if (!w_oihw || !out || cout < 1 || cin < 1 || tile < 4 || tile > 6) return fail(PEANUT_EINVAL, "peanut_debug_wino_weights: bad arguments");
+  wino_transform_weights(w_oihw, cout, cin, out, tile);
   return 0;
 }
 

@@ -170,3 +170,84 @@ def test_weight_pieces_of_the_emulated_modes_match_independent_roundings(precisi
             assert float(r.abs().max()) == 0.0 or bool((r.abs() <= torch.from_numpy(np.abs(v)) * 2.0 ** -24).all())
         else:
             assert not pieces[2].any()
+
+
+# ---- Winograd constants (csrc/winograd.hip): host side pinned here, device side by the GPU tests -------------------------------
+WINO_POINTS = {4: ["0", "3/4", "-3/4", "3/2", "-3/2"],                     # finite interpolation points, in position order; + infinity
+               5: ["0", "1/2", "-1/2", "1", "-1", "3"],
+               6: ["0", "1/2", "-1/2", "1", "-1", "2", "-2"]}
+
+
+def _toom_cook(m, points):
+    """F(m, 3) from its interpolation points in exact rationals: A^T [m][n], G [n][3], B^T [n][n] with n = m + 2, the rows of
+    B^T normalised to a last coefficient of 1 (the scale goes into G) as csrc/winograd.hip writes them."""
+    from fractions import Fraction as Fr
+    pts = [Fr(p) for p in points]
+    n = m + 2
+    assert len(pts) == n - 1
+
+    def poly_mul(a, b):
+        out = [Fr(0)] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                out[i + j] += x * y
+        return out
+    AT = [[Fr(0)] * n for _ in range(m)]
+    G = [[Fr(0)] * 3 for _ in range(n)]
+    BT = [[Fr(0)] * n for _ in range(n)]
+    full = [Fr(1)]
+    for p in pts:
+        full = poly_mul(full, [-p, Fr(1)])                     # prod (x - p_j): degree n - 1
+    for i, p in enumerate(pts):
+        Ni = Fr(1)
+        Mi = [Fr(1)]
+        for j, q in enumerate(pts):
+            if j != i:
+                Ni *= p - q
+                Mi = poly_mul(Mi, [-q, Fr(1)])                 # prod_{j != i} (x - p_j): degree n - 2
+        # Lagrange form: the row of B^T is M_i(x) up to a sign chosen so that its leading coefficient is +1; 1 / N_i goes to G
+        lead = Mi[-1]
+        for k in range(n - 1):
+            BT[i][k] = Mi[k] / lead
+        for k in range(m):
+            AT[k][i] = p ** k
+        for k in range(3):
+            G[i][k] = p ** k / Ni * lead
+    for k in range(n):
+        BT[n - 1][k] = full[k]
+    AT[m - 1][n - 1] = Fr(1)
+    G[n - 1][2] = Fr(1)
+    return AT, G, BT
+
+
+@pytest.mark.parametrize("tile", [4, 5, 6])
+def test_winograd_weight_transform_matches_the_toom_cook_construction(tile):
+    """U = G g G^T as the uploader computes it (peanut_debug_wino_weights: host code of csrc/winograd.hip, no GPU) against
+    the Toom-Cook construction of F(tile, 3) from the interpolation points the kernels document -- in exact rationals, so the
+    comparison is to the last bit of a double rounded once to fp32 -- and the construction itself against the defining
+    identity  A^T [(G g) . (B^T d)] = correlation(d, g)  (which ties G to the B^T / A^T the device kernels implement; those
+    are held against F.conv2d by the GPU tests)."""
+    import numpy as np
+    from fractions import Fraction as Fr
+    AT, G, BT = _toom_cook(tile, WINO_POINTS[tile])
+    n = tile + 2
+    # 1-D identity in exact arithmetic on integer data
+    rng = np.random.RandomState(tile)
+    d = [Fr(int(v)) for v in rng.randint(-9, 10, n)]
+    g = [Fr(int(v)) for v in rng.randint(-9, 10, 3)]
+    ref = [sum(d[k + j] * g[j] for j in range(3)) for k in range(tile)]
+    Gg = [sum(G[i][k] * g[k] for k in range(3)) for i in range(n)]
+    Bd = [sum(BT[i][k] * d[k] for k in range(n)) for i in range(n)]
+    y = [sum(AT[k][i] * Gg[i] * Bd[i] for i in range(n)) for k in range(tile)]
+    assert y == ref, "Toom-Cook construction does not satisfy the Winograd identity"
+    # the library's U against G g G^T
+    lib = _lib.load()
+    cout, cin = 3, 5
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    out = np.zeros((n * n, cout, cin), np.float32)
+    _lib.check(lib.peanut_debug_wino_weights(w.ctypes.data, cout, cin, tile, out.ctypes.data), "peanut_debug_wino_weights")
+    Gf = np.array([[float(v) for v in row] for row in G])
+    want = np.einsum("ia,ocab,lb->iloc", Gf, w.astype(np.float64), Gf).reshape(n * n, cout, cin)
+    assert np.abs(out - want.astype(np.float32)).max() <= 2.0 ** -22 * np.abs(want).max()      # a double product rounded once
+    assert np.abs(out.astype(np.float64) - want).max() <= 2.0 ** -23 * np.abs(want).max()
+    assert lib.peanut_debug_wino_weights(w.ctypes.data, cout, cin, 7, out.ctypes.data) != 0     # unknown tile size: refused
