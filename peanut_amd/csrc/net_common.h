@@ -236,7 +236,7 @@ inline int wino_head_tile(int precision) {
 // running sum).  The rounding error of a Winograd layer is the accumulation error of its position GEMMs times the
 // amplification of A^T (up to 32 per dimension for F(6x6)): with partial sums of 64 channels that error drops about
 // three-fold at K = 2048 (fp32 simulation: F(4x4) 4.1e-6 -> 0.95e-6 rms, F(6x6) 1.2e-5 -> 3.0e-6), and F(6x6) in the PSP
-// bottleneck lands at 6.1e-6 .. 8.6e-6 on the golden logits -- the level of F(4x4) with one running sum (6.7-7.9e-6);
+// bottleneck lands at 7.6e-6 .. 1.0e-5 on the golden logits -- next to F(4x4) with one running sum (6.7-7.9e-6);
 // F(6x6) with one running sum: 3.0-4.0e-5 (profiles/r4e, r4f).  Every Winograd GEMM of the fp32 MFMA kernels does it
 // (measured cost: within noise); PEANUT_WINO_FLUSH_CH overrides the 64 (a multiple of 32; 0 = off).
 inline int wino_flush_channels(bool rs) {
