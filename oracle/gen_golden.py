@@ -164,7 +164,37 @@ def gen_pspnet_round2(report):
     print(f"[pspnet fp64] cfg2_480: the reference's fp32 CPU path is {err32:.2e} from its fp64 self")
 
 
+def gen_pspnet_round3b(report):
+    """Round-3 (last sessions) addition, its own file: pspnet_b4_480_golden.npz -- FOUR 480x480 maps of the benchmark's
+    synthetic recipe (bench.synth_maps, seeds 777..780) through the reference's own model files in fp32, logits kept at rows
+    1::4, cols 2::4.  At this batch the planner of the HIP path runs the larger Winograd tiles (F(5x5) in the dilation-4
+    layers, F(6x6) in the PSP bottleneck), so those forms are held against reference-generated numbers, not only against
+    the oracle."""
+    from bench import synth_maps
+    cfg = PredCfg(in_channels=14)
+    m = ref_import.build_reference_model(in_channels=14)
+    sd = make_seeded_state_dict(cfg, 0, with_aux=True)
+    m.load_state_dict(sd, strict=True)
+    x = synth_maps(4, 14, 480, "cpu", seed0=777)
+    ref32 = np.stack(ref_import.reference_forward(m, x)).astype(np.float32)
+    mine = pspnet_ref.forward_batch(make_seeded_state_dict(cfg, 0), x, cfg).numpy()
+    err = float(np.abs(ref32 - mine).max())
+    assert err <= 1e-5, f"b4_480: oracle restatement deviates from the reference by {err}"
+    sub = (slice(None), slice(None), slice(1, None, 4), slice(2, None, 4))
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_b4_480_golden.npz"), **{
+        "b4_480/input_seed": np.int64(777), "b4_480/logits32_sub": ref32[sub],
+        "b4_480/input_sum": np.float64(x.double().sum().item())})
+    report["pspnet"]["b4_480"] = dict(shape=[4, 14, 480, 480], restatement_max_abs=err, logits_absmax=float(np.abs(ref32).max()))
+    print(f"[pspnet] b4_480: ref vs restatement max-abs {err:.2e}, |logit| max {np.abs(ref32).max():.2f}")
+
+
 def main():
+    if "--round3b" in sys.argv:      # only the fixture of the last sessions of round 3
+        report = {"pspnet": {}}
+        gen_pspnet_round3b(report)
+        with open(os.path.join(GOLDEN, "golden_report_r3b.json"), "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        return
     if "--round3" in sys.argv:       # only the round-3 fixtures (variant configs; mapping flags: oracle.gen_golden_mapping)
         report = {"pspnet": {}, "mapping": {}}
         gen_pspnet_variants(report)

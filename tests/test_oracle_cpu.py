@@ -88,6 +88,23 @@ def test_oracle_reproduces_golden(golden_dir):
         assert np.abs(got - z[f"{case}/logits"]).max() <= 1e-5, case
 
 
+def test_oracle_reproduces_the_four_map_480_golden(golden_dir):
+    """tests/golden/pspnet_b4_480_golden.npz (oracle/gen_golden.py --round3b): four 480 x 480 maps of the benchmark's recipe
+    through the reference's own model files, logits at rows 1::4 / cols 2::4 -- the oracle on ONE of them (the CPU suite
+    stays short), and the input recipe itself (the fixture stores the seed, not the maps)."""
+    from bench import synth_maps
+    z = np.load(os.path.join(golden_dir, "pspnet_b4_480_golden.npz"))
+    x = synth_maps(4, 14, 480, "cpu", seed0=int(z["b4_480/input_seed"]))
+    assert float(x.double().sum()) == float(z["b4_480/input_sum"]), "bench.synth_maps changed: regenerate the fixture"
+    if os.environ.get("PEANUT_FAST_TESTS"):
+        return
+    cfg = W.PredCfg()
+    sd = W.make_seeded_state_dict(cfg, 0)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    got = pspnet_ref.forward_batch(sd, x[2:3], cfg).numpy()[:, :, 1::4, 2::4]
+    assert np.abs(got - z["b4_480/logits32_sub"][2:3]).max() <= 1e-5
+
+
 def test_oracle_distance_to_fp64_reference(golden_dir):
     """The fp64 golden logits (the reference's model files run in float64, oracle/gen_golden.py) put a number on
     'fp32-class': the oracle -- bit-identical to the reference's fp32 CPU path -- is within 1e-5 of them."""

@@ -296,6 +296,35 @@ def test_winograd_and_direct_conv_algorithms_agree(model_and_sd, golden_dir):
     assert worst_a <= TOL and worst_d <= 2e-5
 
 
+def test_b4_480_forward_matches_reference_golden(golden_dir):
+    """Four 480 x 480 maps against logits from the reference's OWN model files (tests/golden/pspnet_b4_480_golden.npz, sub-grid
+    rows 1::4 / cols 2::4; oracle/gen_golden.py --round3b).  At this batch the default plan runs the larger Winograd tiles --
+    F(5x5) in the dilation-4 layers, F(6x6) in the PSP bottleneck of the fp32 mode (two-level accumulation) -- asserted by op
+    name, so those forms are pinned on reference-generated numbers and not only on the oracle."""
+    from bench import synth_maps
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_b4_480_golden.npz"))
+    x = synth_maps(4, 14, 480, "cpu", seed0=int(z["b4_480/input_seed"]))
+    assert float(x.double().sum()) == float(z["b4_480/input_sum"]), "bench.synth_maps changed: regenerate the fixture"
+    ref = z["b4_480/logits32_sub"]
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    xd = x.cuda()
+    for precision in ("fp32", "bf16x6", "fp16x3"):
+        m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
+        got = m.get_prediction_batch(xd, apply_sigmoid=False).cpu().numpy()[:, :, 1::4, 2::4]
+        err = float(np.abs(got - ref).max())
+        names = [n for n, *_ in m.model.profile(xd)]
+        print(f"{precision}: four 480x480 maps vs the reference golden max-abs {err:.3e}")
+        assert err <= TOL, precision
+        if precision == "fp32":     # (the emulated modes pad a position's rows to 256 here and stay on F(4x4) at this batch)
+            for layer in ("layer4.1.conv2", "layer4.2.conv2"):
+                assert any(n.endswith(layer + "[wino5_gemm]") for n in names), [n for n in names if layer in n]
+            assert any(n.endswith("bottleneck.conv[x][wino6_gemm]") for n in names), [n for n in names if "bottleneck.conv[x]" in n]
+        del m
+
+
 @pytest.mark.parametrize("tile", [5, 6])
 def test_forced_winograd_forms_match_reference_goldens(golden_dir, tile, monkeypatch):
     """The planner picks a Winograd form per shape, and the small golden cases end up on F(4x4) (a position's few tiles pad
