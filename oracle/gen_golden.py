@@ -187,6 +187,20 @@ def gen_pspnet_round3b(report):
     report["pspnet"]["b4_480"] = dict(shape=[4, 14, 480, 480], restatement_max_abs=err, logits_absmax=float(np.abs(ref32).max()))
     print(f"[pspnet] b4_480: ref vs restatement max-abs {err:.2e}, |logit| max {np.abs(ref32).max():.2f}")
 
+    # config 5 at its real size: ONE 960x960 map with 25 input channels (weights of seed 1, bench.synth_maps seed 53 -- map 3 of
+    # the batch test_config5_full_size_properties builds), sub-grid rows 1::4 / cols 2::4, into the same file
+    cfg = PredCfg(in_channels=25)
+    m = ref_import.build_reference_model(in_channels=25)
+    m.load_state_dict(make_seeded_state_dict(cfg, 1, with_aux=True), strict=True)
+    x5 = synth_maps(1, 25, 960, "cpu", seed0=53)
+    ref5 = np.stack(ref_import.reference_forward(m, x5)).astype(np.float32)
+    z = dict(np.load(os.path.join(GOLDEN, "pspnet_b4_480_golden.npz")))
+    z.update({"cfg5_960/input_seed": np.int64(53), "cfg5_960/logits32_sub": ref5[sub], "cfg5_960/c_in": np.int64(25),
+              "cfg5_960/weight_seed": np.int64(1), "cfg5_960/input_sum": np.float64(x5.double().sum().item())})
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_b4_480_golden.npz"), **z)
+    report["pspnet"]["cfg5_960"] = dict(shape=[1, 25, 960, 960], logits_absmax=float(np.abs(ref5).max()))
+    print(f"[pspnet] cfg5_960: one 960x960 x 25 map through the reference, |logit| max {np.abs(ref5).max():.2f}")
+
 
 def main():
     if "--round3b" in sys.argv:      # only the fixture of the last sessions of round 3

@@ -103,6 +103,13 @@ def test_oracle_reproduces_the_four_map_480_golden(golden_dir):
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     got = pspnet_ref.forward_batch(sd, x[2:3], cfg).numpy()[:, :, 1::4, 2::4]
     assert np.abs(got - z["b4_480/logits32_sub"][2:3]).max() <= 1e-5
+    # ... and the config-5-size map of the same file (960 x 960, 25 channels, weights of seed 1)
+    cfg5 = W.PredCfg(in_channels=int(z["cfg5_960/c_in"]))
+    sd5 = W.make_seeded_state_dict(cfg5, int(z["cfg5_960/weight_seed"]))
+    x5 = synth_maps(1, 25, 960, "cpu", seed0=int(z["cfg5_960/input_seed"]))
+    assert float(x5.double().sum()) == float(z["cfg5_960/input_sum"])
+    got5 = pspnet_ref.forward_batch(sd5, x5, cfg5).numpy()[:, :, 1::4, 2::4]
+    assert np.abs(got5 - z["cfg5_960/logits32_sub"]).max() <= 2e-5
 
 
 def test_oracle_distance_to_fp64_reference(golden_dir):

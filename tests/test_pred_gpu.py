@@ -602,6 +602,36 @@ def test_config5_full_size_properties():
     assert e_dir <= 1e-4 and e_x6 <= 1e-4
 
 
+def test_config5_size_map_matches_reference_golden(golden_dir):
+    """BASELINE.json config 5's shape against the reference itself: ONE 960 x 960 map with 25 input channels (map 3 of the
+    batch the property test above builds: bench.synth_maps seed 53, weights of seed 1) through the reference's own model files
+    (tests/golden/pspnet_b4_480_golden.npz, key cfg5_960, sub-grid rows 1::4 / cols 2::4; oracle/gen_golden.py --round3b), alone
+    and as a member of the full per-GPU batch of 8 -- fp32 and the two fp32-class emulations."""
+    from bench import synth_maps
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_b4_480_golden.npz"))
+    cfg = PredCfg(in_channels=int(z["cfg5_960/c_in"]))
+    sd = make_seeded_state_dict(cfg, int(z["cfg5_960/weight_seed"]))
+    dev = torch.device("cuda")
+    x = synth_maps(8, 25, 960, dev, seed0=50)
+    assert float(x[3].double().sum()) == float(z["cfg5_960/input_sum"]), "bench.synth_maps changed: regenerate the fixture"
+    ref = z["cfg5_960/logits32_sub"][0]
+    for precision in ("fp32", "bf16x6", "fp16x3"):
+        m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
+        one = m.get_prediction_batch(x[3:4].contiguous(), apply_sigmoid=False)[0, :, 1::4, 2::4].cpu().numpy()
+        e1 = float(np.abs(one - ref).max())
+        e8 = None
+        if precision == "fp32":
+            full = m.get_prediction_batch(x, apply_sigmoid=False)[3, :, 1::4, 2::4].cpu().numpy()
+            e8 = float(np.abs(full - ref).max())
+            assert e8 <= 2 * TOL
+        print(f"config-5 size (960x960x25) vs the reference golden, {precision}: alone {e1:.3e}" + (f", in the batch of 8 {e8:.3e}" if e8 is not None else "")
+              + f" (|logit| max {np.abs(ref).max():.2f})")
+        assert e1 <= 2 * TOL, precision        # |logit| reaches 10 here (6.3 in the 480 x 480 cases): same relative bound
+        del m
+
+
 def test_distance_to_the_fp64_reference_at_480(golden_dir):
     """The benchmark's own input recipe at the headline size: one 480x480 map (bench.synth_maps, seed 4242) against
     the reference's model files run in float64 (sub-grid rows 1::4, cols 2::4 of the logits,
