@@ -198,6 +198,17 @@ def gen_pspnet_round3b(report):
     z.update({"cfg5_960/input_seed": np.int64(53), "cfg5_960/logits32_sub": ref5[sub], "cfg5_960/c_in": np.int64(25),
               "cfg5_960/weight_seed": np.int64(1), "cfg5_960/input_sum": np.float64(x5.double().sum().item())})
     np.savez_compressed(os.path.join(GOLDEN, "pspnet_b4_480_golden.npz"), **z)
+    # the agent's deployed prediction window (agent_state.py:345-373: a 720 x 720 crop of the full map, one map per call)
+    cfg = PredCfg(in_channels=14)
+    m = ref_import.build_reference_model(in_channels=14)
+    m.load_state_dict(make_seeded_state_dict(cfg, 0, with_aux=True), strict=True)
+    x7 = synth_maps(1, 14, 720, "cpu", seed0=7200)
+    ref7 = np.stack(ref_import.reference_forward(m, x7)).astype(np.float32)
+    z.update({"win_720/input_seed": np.int64(7200), "win_720/logits32_sub": ref7[sub],
+              "win_720/input_sum": np.float64(x7.double().sum().item())})
+    np.savez_compressed(os.path.join(GOLDEN, "pspnet_b4_480_golden.npz"), **z)
+    report["pspnet"]["win_720"] = dict(shape=[1, 14, 720, 720], logits_absmax=float(np.abs(ref7).max()))
+    print(f"[pspnet] win_720: one 720x720 map through the reference, |logit| max {np.abs(ref7).max():.2f}")
     report["pspnet"]["cfg5_960"] = dict(shape=[1, 25, 960, 960], logits_absmax=float(np.abs(ref5).max()))
     print(f"[pspnet] cfg5_960: one 960x960 x 25 map through the reference, |logit| max {np.abs(ref5).max():.2f}")
 

@@ -103,6 +103,11 @@ def test_oracle_reproduces_the_four_map_480_golden(golden_dir):
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     got = pspnet_ref.forward_batch(sd, x[2:3], cfg).numpy()[:, :, 1::4, 2::4]
     assert np.abs(got - z["b4_480/logits32_sub"][2:3]).max() <= 1e-5
+    # ... the agent's deployed 720 x 720 window
+    x7 = synth_maps(1, 14, 720, "cpu", seed0=int(z["win_720/input_seed"]))
+    assert float(x7.double().sum()) == float(z["win_720/input_sum"])
+    got7 = pspnet_ref.forward_batch(sd, x7, cfg).numpy()[:, :, 1::4, 2::4]
+    assert np.abs(got7 - z["win_720/logits32_sub"]).max() <= 1e-5
     # ... and the config-5-size map of the same file (960 x 960, 25 channels, weights of seed 1)
     cfg5 = W.PredCfg(in_channels=int(z["cfg5_960/c_in"]))
     sd5 = W.make_seeded_state_dict(cfg5, int(z["cfg5_960/weight_seed"]))

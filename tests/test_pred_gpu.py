@@ -632,6 +632,26 @@ def test_config5_size_map_matches_reference_golden(golden_dir):
         del m
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x3", "auto"])
+def test_deployed_720_window_matches_reference_golden(golden_dir, precision):
+    """The shape the agent actually calls the model at -- ONE 720 x 720 crop of the full map per prediction
+    (nav/agent/agent_state.py:345-373) -- against logits from the reference's own model files
+    (tests/golden/pspnet_b4_480_golden.npz, key win_720, sub-grid rows 1::4 / cols 2::4; oracle/gen_golden.py --round3b),
+    in every fp32-class mode and in precision='auto' (fp16x3 with the announced escalation)."""
+    from bench import synth_maps
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_b4_480_golden.npz"))
+    x = synth_maps(1, 14, 720, "cpu", seed0=int(z["win_720/input_seed"]))
+    assert float(x.double().sum()) == float(z["win_720/input_sum"]), "bench.synth_maps changed: regenerate the fixture"
+    cfg = PredCfg()
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg, 0), cfg=cfg, precision=precision)
+    got = m.get_prediction_batch(x.cuda(), apply_sigmoid=False).cpu().numpy()[:, :, 1::4, 2::4]
+    err = float(np.abs(got - z["win_720/logits32_sub"]).max())
+    print(f"one 720x720 window vs the reference golden, {precision}: max-abs {err:.3e}")
+    assert err <= TOL
+
+
 def test_distance_to_the_fp64_reference_at_480(golden_dir):
     """The benchmark's own input recipe at the headline size: one 480x480 map (bench.synth_maps, seed 4242) against
     the reference's model files run in float64 (sub-grid rows 1::4, cols 2::4 of the logits,
