@@ -281,10 +281,21 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   // halves around a mid-iteration barrier as the two-stage kernel does is 2 % SLOWER here -- with two waves per SIMD
   // the other wave's MFMAs already cover them, and the extra scheduling fences cost more)
   int o_cur = 0, o_mid = STAGE, o_fill = 2 * STAGE;
+  // The two waves of a SIMD (waves w and w + 4) request their share of the next k-tile at DIFFERENT points of the
+  // iteration: waves 0-3 at the top, waves 4-7 after their first 32 MFMAs.  Issuing the six LDS-DMA instructions costs a
+  // wave several hundred cycles; with both waves of a SIMD doing it right after the barrier the matrix pipe starves at the
+  // head of every k-tile.  Calibrated on the bare loop (tools/micro/pw256_loop.hip, profiles/r5a): 132-136 -> 143 TF/s
+  // (no requests at all: 149); spreading the requests between the MFMAs instead: 120.
+  const bool late = p.phase_shift && wave >= 4;
+#define PW256_MFMA_GROUP(j)                                                                               \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                        \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                        \
+      _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                      \
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const float* const cur = smem + o_cur;
     const bool more = kt + 2 < nk;
-    if (more) PW256_DMA_TILE(smem + o_fill);
+    if (more && !late) PW256_DMA_TILE(smem + o_fill);
     f32x4 af[BK / 8][MI], bf[BK / 8][NI];
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
@@ -293,15 +304,13 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
 #pragma unroll
       for (int u = 0; u < NI; ++u) bf[j][u] = *reinterpret_cast<const f32x4*>(cur + b_row + u * 32 * BK + sw[j]);
     }
-#pragma unroll
-    for (int j = 0; j < BK / 8; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int t = 0; t < MI; ++t)
-#pragma unroll
-          for (int u = 0; u < NI; ++u)
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+    PW256_MFMA_GROUP(0);
+    PW256_MFMA_GROUP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && late) PW256_DMA_TILE(smem + o_fill);
+    __builtin_amdgcn_sched_barrier(0);
+    PW256_MFMA_GROUP(2);
+    PW256_MFMA_GROUP(3);
     PEANUT_FLUSH_STEP();
     // the next k-tile must have landed; the one just requested may stay in flight across the barrier
     if (more) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   }
 #undef PW256_DMA_TILE
 #undef PW256_BARRIER
+#undef PW256_MFMA_GROUP
   PEANUT_FLUSH_FINISH();
   conv_epilogue<BM, BN, WM, WN, 1, NT>(p, wk, acc, smem, m0, n0);
 }
@@ -352,6 +362,8 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
     static SlotCache slots256;
     ConvKParams q = p;
     if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
+    static const int phase_shift = [] { const char* e = getenv("PEANUT_PW256_PHASE"); return (e && e[0] == '0') ? 0 : 1; }();
+    q.phase_shift = phase_shift;
     note_kernel("conv_pw_glds_256x128");
     return launch_with_tail_split<decltype(&conv_pw_glds256_kernel), 256, 128, 512>(&conv_pw_glds256_kernel, q, ws, ws_floats, stream,
                                                                                      &slots256);
