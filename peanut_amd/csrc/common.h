@@ -77,6 +77,10 @@ bool conv_pw_enabled();
 // conv_pw.hip: whether a pointwise layer / grouped GEMM runs on the 256 x 128 three-stage kernel
 bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin);
 int conv_pw_256_min_k();
+// conv_pw.hip: ... on the 256 x 256 two-stage kernel (flush_ktiles: k-tiles per partial sum of the two-level accumulation, 0 = none)
+bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
+// conv_pw_ares.hip: ... on the persistent A-resident kernel (K = 128 / 256)
+bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_source, int flush_ktiles, int bn_tile);
 
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
 // tiles per sub-grid (th x tw), tile count and its padding to whole `gran`-row GEMM tiles (128; 256 when the position

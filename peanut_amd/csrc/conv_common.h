@@ -41,6 +41,7 @@ struct ConvKParams {
   int nchunk;                 // n-tiles per chunk of that order; 0 = plain order (n fastest over all n-tiles)
   int res_prefetch;           // epilogue: request the first rows of the residual before the accumulators go through LDS
   float alpha;                // y = relu(alpha * acc * scale + shift + res): 1 / the pack scale of fp16-piece weights, else 1
+  int ares_pbn;               // conv_pw_ares_kernel: the n-tile the weights were packed with (64 / 128)
   int phase_shift;            // conv_pw_glds256_kernel: waves 4-7 request their LDS-DMA pieces half an iteration after waves 0-3
   int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*
 };
@@ -65,6 +66,8 @@ const float* zero_page();   // per-device 4 KiB of zeros (allocated on first use
 // conv_pw.hip: fp32 pointwise convs / grouped GEMMs with LDS-DMA staging (PEANUT_PW_GLDS=0 disables)
 bool conv_pw_enabled();
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream);
+// conv_pw_ares.hip: persistent A-resident kernel for the K = 128 / 256 pointwise layers and grouped GEMMs
+int launch_conv_pw_ares(const ConvKParams& p, int bn_tile, hipStream_t stream);
 // gemm_rs.hip: pointwise layer / grouped GEMM emulated on the bf16 matrix cores: fp32 A (p.x, p.x2) split into bf16 pieces in
 // registers, p.w = the weights' pre-split pieces, nkt = cin / 16
 int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);

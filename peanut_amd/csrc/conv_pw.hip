@@ -325,6 +325,132 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   conv_epilogue<BM, BN, WM, WN, 1, NT>(p, wk, acc, smem, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 tiles, 8 waves as 4 x 2, wave tile 64 x 128 (128 accumulator registers), TWO stages of 64 KiB, one workgroup
+// per CU.  Per wave and k-tile: 8 LDS-DMA pieces and 24 ds_read_b128 for 128 MFMAs -- two thirds of the 256 x 128 kernel's
+// operand traffic per FLOP (LDS-DMA, L2 and LDS reads alike), and an iteration is twice as long, so one iteration of cover
+// (6.8 us at full rate) is enough for a loaded HBM round trip.  Calibrated on the bare loop (tools/micro/pw256_loop.hip,
+// profiles/r5a): 144.5 TF/s against 132-136 for the 256 x 128 loop (no requests at all: 150.8).  No room for the second
+// accumulator set of the two-level accumulation: the Winograd position GEMMs stay on the 256 x 128 kernel.  The weights
+// keep their 128-wide packing: a 256-wide n-tile is two consecutive packed tiles.  The A and B halves of a k-tile are
+// requested half an iteration apart by the two waves of a SIMD (see conv_pw_glds256_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_pw_glds256w_kernel(const ConvKParams p) {
+  constexpr int BM = 256, BN = 256, BK = 32, WM = 4, WN = 2, NT = 512, STAGES = 2;
+  constexpr int TM = BM / WM, TN = BN / WN;      // 64 x 128
+  constexpr int MI = TM / 32, NI = TN / 32;      // 2 x 4
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;   // 64 KiB
+  constexpr int A_INSTR = BM / 64, B_INSTR = BN / 64;   // 4 + 4
+  constexpr int CS = BN + 4, ER = BM / WM;
+  constexpr int SMEM_FLOATS = (STAGES * STAGE > ER * CS) ? STAGES * STAGE : ER * CS;
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const Work wk = decode_work(p);
+  const int mt = wk.mt, nt = wk.nt, nk = wk.kt1 - wk.kt0;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 3, lp = lane & 7;
+
+  const float* a_src[A_INSTR];
+  const float* a_src2[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int r = (wave * A_INSTR + j) * 8 + lr;
+    const int m = m0 + r;
+    const int mc = m < p.M ? m : p.M - 1;
+    const int b = mc / p.HoWo;
+    const int rem = mc - b * p.HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const size_t pix = (size_t)b * p.H * p.W + (size_t)oy * p.stride * p.W + (size_t)ox * p.stride;
+    const int c = lp ^ ((r >> 1) & 7);
+    const int k1 = p.c1 / BK;
+    a_src[j] = wk.kt0 < k1 ? p.x + pix * p.c1 + (size_t)wk.kt0 * BK + c * 4 : p.x2 + pix * p.c2 + (size_t)(wk.kt0 - k1) * BK + c * 4;
+    a_src2[j] = p.x2 + pix * p.c2 + c * 4;
+  }
+  int to_switch = p.c2 ? p.c1 / BK - wk.kt0 : 0x7fffffff;
+  const float* b_src[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    const int r = (wave * B_INSTR + j) * 8 + lr;      // row of the 256-wide n-tile: packed 128-tile 2 nt + (r >> 7), its row r & 127
+    const int c = lp ^ ((r >> 1) & 7);
+    b_src[j] = p.w + ((size_t)(2 * nt + (r >> 7)) * p.nkt + wk.kt0) * (128 * BK) + (r & 127) * BK + c * 4;
+  }
+#define PW256W_DMA_TILE(stage)                                                                                   \
+  {                                                                                                              \
+    if (to_switch-- == 0) {                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) a_src[j] = a_src2[j];                                  \
+    }                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < A_INSTR; ++j) {                                                        \
+      __builtin_amdgcn_global_load_lds((gptr_t)a_src[j], (lptr_t)((stage) + (wave * A_INSTR + j) * 256), 16, 0, 0); \
+      a_src[j] += BK;                                                                                            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j) {                                                        \
+      __builtin_amdgcn_global_load_lds((gptr_t)b_src[j], (lptr_t)((stage) + A_FLOATS + (wave * B_INSTR + j) * 256), 16, 0, 0); \
+      b_src[j] += 128 * BK;                                                                                      \
+    }                                                                                                            \
+  }
+#define PW256W_BARRIER()                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("" ::: "memory");
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  const int swz = (li >> 1) & 7;
+  int sw[BK / 8];
+#pragma unroll
+  for (int ks = 0; ks < BK / 8; ++ks) sw[ks] = ((ks * 2 + hi) ^ swz) * 4;
+  const int a_row = (wm * TM + li) * BK;
+  const int b_row = A_FLOATS + (wn * TN + li) * BK;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int t = 0; t < MI; ++t)
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  PW256W_DMA_TILE(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PW256W_BARRIER();
+  const bool late = p.phase_shift && wave >= 4;
+#define PW256W_READ_PAIR(g)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                    \
+    _Pragma("unroll") for (int t = 0; t < MI; ++t) af[j][t] = *reinterpret_cast<const f32x4*>(cur + a_row + t * 32 * BK + sw[(g) + j]); \
+    _Pragma("unroll") for (int u = 0; u < NI; ++u) bf[j][u] = *reinterpret_cast<const f32x4*>(cur + b_row + u * 32 * BK + sw[(g) + j]); \
+  }
+#define PW256W_MFMA_PAIR()                                                                                \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
+      _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                      \
+        _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                    \
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* const cur = smem + (kt & 1) * STAGE;
+    float* const fill = smem + ((kt + 1) & 1) * STAGE;
+    const bool more = kt + 1 < nk;
+    if (more && !late) PW256W_DMA_TILE(fill);
+    f32x4 af[2][MI], bf[2][NI];
+    PW256W_READ_PAIR(0);
+    PW256W_MFMA_PAIR();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && late) PW256W_DMA_TILE(fill);
+    __builtin_amdgcn_sched_barrier(0);
+    PW256W_READ_PAIR(2);
+    PW256W_MFMA_PAIR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PW256W_BARRIER();
+  }
+#undef PW256W_DMA_TILE
+#undef PW256W_BARRIER
+#undef PW256W_READ_PAIR
+#undef PW256W_MFMA_PAIR
+  conv_epilogue<BM, BN, WM, WN, WM, NT>(p, wk, acc, smem, m0, n0);
+}
+
 template <int BN, int WM, int WN>
 int launch_pw_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream) {
   static SlotCache slots;
@@ -356,8 +482,32 @@ bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
   return bn_tile == 128 && cin >= conv_pw_256_min_k() && mt_per_group % 2 == 0 && M * cout >= min_tiles * 256 * 128;
 }
 
+// whether the 256 x 256 kernel takes a pointwise layer: whole 256-wide n-tiles, no weight groups, one running sum (the
+// Winograd position GEMMs keep the 256 x 128 kernel and its two-level accumulation).  Measured per layer at the headline
+// shape (profiles/r5c): K = 768 -> N = 1024 (layer3.0 conv3 + downsample) 1.441 -> 1.386 ms, K = 1536 -> N = 2048 (layer4.0)
+// 5.350 -> 5.148 ms (140.8 TF/s); the N = 512 layers LOSE 5-6 % (900 tiles over 256 CUs: 3.5 rounds) and so do the
+// K = 512 -> N = 2048 ones (-3 %: 16 k-tiles per tile, and with one workgroup per CU nothing runs under the epilogue).
+// Hence: at least PEANUT_PW256W_MINK (768; 0 = off) input channels and PEANUT_PW256W_MINTILES (1536: six rounds) tiles.
+bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush) {
+  static const int min_k = [] { const char* e = getenv("PEANUT_PW256W_MINK"); return e ? atoi(e) : 768; }();
+  static const long long min_tiles = [] { const char* e = getenv("PEANUT_PW256W_MINTILES"); return e ? atoll(e) : 1536LL; }();
+  return min_k > 0 && bn_tile == 128 && cout % 256 == 0 && mt_per_group == 0 && flush == 0 && cin >= min_k &&
+         ((M + 255) / 256) * (cout / 256) >= min_tiles;
+}
+
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
+  static const int phase_shift_w = [] { const char* e = getenv("PEANUT_PW256_PHASE"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (conv_pw_uses_ares(p.c1, p.cout, p.M, p.stride, p.c2 != 0, p.flush, bn_tile)) return launch_conv_pw_ares(p, bn_tile, stream);
+  if (conv_pw_uses_256w(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, p.flush)) {
+    static SlotCache slots256w;
+    ConvKParams q = p;
+    q.ntiles = p.cout / 256;
+    q.phase_shift = phase_shift_w;
+    note_kernel("conv_pw_glds_256x256");
+    return launch_with_tail_split<decltype(&conv_pw_glds256w_kernel), 256, 256, 512>(&conv_pw_glds256w_kernel, q, ws, ws_floats, stream,
+                                                                                      &slots256w);
+  }
   if (conv_pw_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2)) {
     static SlotCache slots256;
     ConvKParams q = p;

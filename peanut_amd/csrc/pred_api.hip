@@ -221,8 +221,13 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long lo
   if (d.rs == 2) return std::string(d.s_planes == 3 ? "conv_rs6_128x" : (d.s_planes == 4 ? "conv_rs3h_128x" : "conv_rs3_128x")) + std::to_string(d.bn_tile);
   if (d.rs) return gemm_rs_kernel_name(d.cout, M, mt_per_group, d.bn_tile, d.cin, d.s_planes);
   if (d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
+  {
+    const int flush = d.flush_ch / d.bk;
+    if (conv_pw_uses_ares(d.cin, d.cout, M, d.stride, two_source, flush, d.bn_tile)) return "conv_pw_ares_128x128";
+    if (conv_pw_uses_256w(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush)) return "conv_pw_glds_256x256";
     return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
                                                                          : "conv_pw_glds_128x" + std::to_string(d.bn_tile);
+  }
   return "conv_igemm_128x" + std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
 }
 

@@ -251,3 +251,40 @@ def test_winograd_weight_transform_matches_the_toom_cook_construction(tile):
     assert np.abs(out - want.astype(np.float32)).max() <= 2.0 ** -22 * np.abs(want).max()      # a double product rounded once
     assert np.abs(out.astype(np.float64) - want).max() <= 2.0 ** -23 * np.abs(want).max()
     assert lib.peanut_debug_wino_weights(w.ctypes.data, cout, cin, 7, out.ctypes.data) != 0     # unknown tile size: refused
+
+
+def test_uncounted_asm_loads_are_not_touched_before_their_wait():
+    """csrc/conv_pw_ares.hip hides its residual / scale / shift loads from hipcc's wait-count bookkeeping (inline asm): the
+    destination registers are valid only after the kernel's own `s_waitcnt vmcnt(0)`.  tools/audit_uncounted_loads.py
+    compiles the file to gfx950 assembly and checks that nothing reads, copies or overwrites such a register between its
+    load and that wait (hipcc is free to: cdna_hip_programming.md 5.7).  The audit itself is checked on two synthetic
+    listings first: a clean one and one with the copy hipcc once inserted ahead of the wait."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_uncounted_loads", os.path.join(root, "tools", "audit_uncounted_loads.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    clean = """
+	;;#ASMSTART
+	global_load_dword v164, v[16:17], off
+	;;#ASMEND
+	s_cbranch_vccnz .LBB0_2
+	v_mfma_f32_32x32x2_f32 v[0:15], v20, v21, v[0:15]
+.LBB0_2:
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	v_mov_b32_e32 v81, v164
+	s_endpgm
+"""
+    n, findings = audit.audit(clean)
+    assert n == 1 and findings == []
+    copied = clean.replace("\tv_mfma_f32_32x32x2_f32 v[0:15], v20, v21, v[0:15]\n", "\tv_mov_b32_e32 v81, v164\n")
+    assert len(audit.audit(copied)[1]) == 1
+    ranged = clean.replace("v[0:15], v20, v21, v[0:15]", "v[0:15], v20, v21, v[160:175]")
+    assert len(audit.audit(ranged)[1]) == 1
+    escaping = clean.replace("s_cbranch_vccnz .LBB0_2", "s_cbranch_vccnz .LBB0_9")
+    assert len(audit.audit(escaping)[1]) == 1
+    n, findings = audit.audit(audit.assembly(audit.DEFAULT[0]))
+    assert n >= 100 and findings == [], findings[:5]

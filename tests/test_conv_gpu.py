@@ -144,6 +144,78 @@ def test_pw256_kernel_matches_torch(case):
     _pw_case(case, "fp32", "conv_pw_glds_256x128", 2e-5)
 
 
+WIDE_PW_CASES = [
+    # (B, H, W, cin, cout, stride, relu, residual): csrc/conv_pw.hip conv_pw_uses_256w -- cout % 256 == 0, cin >= 512,
+    # M * cout >= 256 tiles of 256 x 256 = 16.8 M
+    (8, 64, 64, 512, 512, 1, True, True),        # exactly at the gate, whole tiles, residual
+    (5, 57, 61, 1024, 1024, 1, True, True),      # M = 17 385: ragged last 256-row tile
+    (8, 64, 64, 512, 768, 1, False, False),      # 384 tiles over 256 CUs: the 128-tile tail runs split-K + the ordered reduce
+    (4, 150, 150, 512, 768, 2, True, False),     # strided 1x1 (the downsample form), M = 22 500
+]
+
+
+@pytest.mark.parametrize("case", WIDE_PW_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_pw256w_kernel_matches_torch(case):
+    """conv_pw_glds256w_kernel (256 x 256 tiles, wave tile 64 x 128, two 64 KiB LDS stages; round 4) against F.conv2d."""
+    _pw_case(case, "fp32", "conv_pw_glds_256x256", 2e-5)
+
+
+def test_pw256w_kernel_two_sources():
+    """The 256 x 256 kernel reading its A k-tiles from two tensors (layer4.0's conv3 + downsample form) against a conv over
+    the concatenation; the 448-tile launch has a split-K tail whose parts start on either side of the source switch."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, c1, c2, cout = 7, 64, 64, 512, 1024, 1024
+    g = torch.Generator().manual_seed(11)
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) * scale[None, :, None, None] + shift[None, :, None, None])
+    conv = FusedConv(w, scale, shift, relu=True)
+    y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda())
+    assert _last_kernel() == "conv_pw_glds_256x256", _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+ARES_CASES = [
+    # (B, H, W, cin, cout, stride, relu, residual): csrc/conv_pw_ares.hip conv_pw_uses_ares -- K = 128 / 256, M and cout whole
+    # 128-tiles, at least 512 (m-tile, n-tile) units
+    (8, 64, 64, 256, 1024, 1, True, True),       # layer3 conv3 class: 8 n-tiles per A tile, residual + ReLU; 2048 units over 256 CUs
+    (5, 80, 80, 256, 1024, 1, True, True),       # 250 m-tiles: unit ranges of 7 / 8 start and end inside an m-tile (A refill mid-range)
+    (8, 64, 64, 128, 512, 1, False, True),       # layer2 conv3 class: K = 128 (4 slices, 8 accumulators finished per iteration)
+    (8, 128, 128, 256, 128, 1, True, False),     # one n-tile per m-tile: every unit refills A (layer2.0 conv1 class), no residual
+    (3, 128, 128, 128, 256, 1, True, False),     # 768 units over 256 CUs: three per workgroup
+]
+
+
+@pytest.mark.parametrize("case", ARES_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_pw_ares_kernel_matches_torch(case):
+    """conv_pw_ares_kernel (persistent, A tile resident in LDS, epilogue of the previous unit from registers inside the next
+    unit's k-loop, residual loads hidden from hipcc's wait counts; round 4) against F.conv2d."""
+    _pw_case(case, "fp32", "conv_pw_ares_128x128", 2e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 96, 96, 256, 256, 1), (4, 96, 96, 128, 128, 1), (4, 60, 60, 256, 256, 2)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_pw_ares_kernel_grouped_winograd_gemm(case):
+    """The grouped position GEMMs of a narrow Winograd layer (layer3 / layer2 conv2: K = N = 256 / 128, partial sums of 64
+    channels) on the A-resident kernel against F.conv2d; dilation 2 as layer3.1-5."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    res = _rand((B, cout, H, W), g)
+    ref = F.relu(F.conv2d(x, w, None, padding=d, dilation=d) + shift[None, :, None, None] + res)
+    conv = FusedConv(w, None, shift, padding=d, dilation=d, relu=True)
+    y = conv(x.permute(0, 2, 3, 1).contiguous().cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda())
+    assert _last_kernel() == "conv_pw_ares_128x128", _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
 def test_pw256_kernel_grouped_winograd_gemm():
     """The 36 grouped position GEMMs of a Winograd conv on the 256 x 128 kernel (mt_per_group in 256-row tiles, rows
     padded to whole 256-row tiles per position: the bottleneck's form) against F.conv2d."""
