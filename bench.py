@@ -46,9 +46,9 @@ from peanut_amd.weights import PredCfg, conv_flops_per_map, make_seeded_state_di
 # split-product mode can deliver at most one third as fp32-equivalent FLOPs (3 MFMAs per product).
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}
 DTYPE = {"fp32": "f32",
-         "bf16x3": "f32 tensors; 1x1 / Winograd GEMM products from 2 bf16 pieces per value (3 MFMA products), f32 accumulate",
+         "bf16x3": "f32 tensors; conv products from 2 bf16 pieces per value (3 MFMA products), f32 accumulate",
          "fp16x3": "f32 tensors; conv products emulated from 2 fp16 pieces per value (3 MFMA products), f32 accumulate",
-         "bf16x6": "f32 tensors; 1x1 / Winograd GEMM products emulated from 3 bf16 pieces per value (6 MFMA products), f32 accumulate"}
+         "bf16x6": "f32 tensors; conv products emulated from 3 bf16 pieces per value (6 MFMA products), f32 accumulate"}
 MODE_NOTES = {
     "fp16x3": "opt-in: 2 fp16 pieces per value (22 significand bits; activations split in registers, weights pre-split "
               "after a per-layer power-of-two scale), 3 MFMA products per fp32 product, fp32 accumulate; needs the "
@@ -56,7 +56,7 @@ MODE_NOTES = {
               "golden vectors, 5-7e-6 from the float64 run",
     "bf16x3": "opt-in speed mode: 2 bf16 pieces per value, 3 MFMA products per fp32 product, fp32 accumulate; ~9e-5 max-abs "
               "on the logits vs the reference golden vectors (bound 1e-3); not fp32-class, not the headline value",
-    "bf16x6": "fp32 emulation on the bf16 matrix cores (csrc/gemm_rs.hip): activations stay fp32 in HBM / LDS and are split "
+    "bf16x6": "fp32 emulation on the bf16 matrix cores (csrc/gemm_rs.hip, conv_rs.hip): activations stay fp32 in HBM / LDS and are split "
               "into 3 bf16 pieces in registers (exact split), weights pre-split, 6 MFMA products per fp32 product, fp32 "
               "accumulate; 9.1e-6 max-abs on the logits vs the reference golden vectors, 5-9e-6 from a float64 run of the "
               "reference model (8.9e-6 at 480x480) -- the level of the fp32 MFMA path (7.9e-6 / 5-7e-6) and of the reference's own "

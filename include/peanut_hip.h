@@ -25,9 +25,10 @@ extern "C" {
 #define PEANUT_EINVAL (-2)   /* bad argument / unsupported configuration */
 #define PEANUT_EHIP (-3)     /* HIP runtime error */
 #define PEANUT_EWEIGHTS (-4) /* missing or mis-shaped tensor in the state dict */
+#define PEANUT_ERANGE (-5)   /* precision FP16X3: a value left fp16's exponent range (the result would be NaN / dropped) */
 
 const char* peanut_last_error(void);
-/* kernel family the calling thread's most recent conv / GEMM launch selected, e.g. "conv_pw_glds_256x128" (for tests
+/* kernel family the calling thread's most recent conv / GEMM launch selected, e.g. "conv_pw_glds_256x128", "conv_pw_glds_256x256", "conv_pw_ares_128x128" (for tests
  * and profiles: lets a parity test assert which kernel produced the result it checked) */
 const char* peanut_last_conv_kernel(void);
 /* library / ABI version and the arch it was compiled for ("gfx950") */
@@ -45,6 +46,19 @@ int peanut_debug_weight_pieces(const float* values, int n, int precision, unsign
  * tiles of tile x tile (4, 5 or 6; csrc/winograd.hip), as the uploader computes it (double arithmetic, rounded once):
  * out [(tile + 2)^2][cout][cin].  tests/test_abi.py holds it against the Toom-Cook construction in exact rationals. */
 int peanut_debug_wino_weights(const float* w_oihw, int cout, int cin, int tile, float* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Tuning options (csrc/options.h): kernel gates, Winograd form policy, launch-plan switches -- named by key, e.g.
+ * "pw256_mink"; peanut_option_list() returns one line per option: `key=default [create-time] help`.
+ * The process defaults come from the PEANUT_<KEY> environment variables (read once) and peanut_set_default_option.  A
+ * handle (peanut_pred_t / peanut_conv_t / peanut_rcnn_t) SNAPSHOTS the defaults when it is created and carries its own
+ * copy: peanut_*_set_option changes that one handle (and drops its cached launch plans), so two handles in one process
+ * can run different policies.  Options marked [create-time] shape the uploaded weights (Winograd forms, packing tiles):
+ * set them as defaults before the create call; peanut_*_set_option refuses them.
+ * ---------------------------------------------------------------------------------------- */
+int peanut_set_default_option(const char* key, long long value);
+int peanut_get_default_option(const char* key, long long* value);
+const char* peanut_option_list(void);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 3 -- map-completion forward (PSPNet: ResNet-50-V1c-D8 + PSP head)
@@ -84,14 +98,15 @@ typedef struct peanut_pred_cfg {
 #define PEANUT_ALGO_DIRECT 1
 
 /* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32, exact fp32 (bit-identical to an fmaf chain).
- * BF16X6: fp32 emulated on the bf16 matrix cores (csrc/gemm_rs.hip).  Activations stay fp32 in HBM and LDS -- the
- * forward's tensors, Winograd transforms and fusions are exactly the fp32 mode's; in the 1x1 convs and the Winograd
- * position GEMMs every fp32 value is split into three bf16 pieces (3 x 8 = 24 mantissa bits: the split is exact; the
- * activations in registers after the fragment read, the weights once at load time) and every product is rebuilt from
- * the six piece products that matter (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped ones are <= 2^-24
- * relative, the size of fp32's own product rounding) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class
- * results, measured as close to a float64 run of the reference model as the reference's own fp32 CPU path.  The other
- * layers (3x3 direct convs, the stem) stay on the fp32 MFMA kernels.
+ * BF16X6: fp32 emulated on the bf16 matrix cores.  Activations stay fp32 in HBM and LDS -- the forward's tensors,
+ * Winograd transforms and fusions are exactly the fp32 mode's; every fp32 value is split into three bf16 pieces (3 x 8 =
+ * 24 mantissa bits: the split is exact; the activations in registers after the fragment read, the weights once at load
+ * time) and every product is rebuilt from the six piece products that matter (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
+ * lo*hi; the dropped ones are <= 2^-24 relative, the size of fp32's own product rounding) on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation: fp32-class results, measured as close to a float64 run of the reference model as the
+ * reference's own fp32 CPU path.  The 1x1 convs and the Winograd position GEMMs run on csrc/gemm_rs.hip, every other conv
+ * (3x3 direct, strided, the stem) on csrc/conv_rs.hip -- the same arithmetic with im2col-free staging; the Winograd
+ * transforms themselves are fp32 in every mode.
  * BF16X3: the same with two pieces and three products (~2^-16 relative per product: ~7e-5 max-abs on the logits,
  * bound 1e-3); an opt-in speed mode, not fp32-class.
  * FP16X3: two FP16 pieces per value (2 x 11 = 22 significand bits) and the three products hi*hi, hi*lo, lo*hi on
@@ -167,6 +182,9 @@ int peanut_pred_probe_collect(peanut_pred_t* h, int max_ops, const char** names,
  * Up to 16 combinations are cached; growing the workspace drops them.  Results are identical.  Ignored while the probe or debug taps are on, and on the legacy default stream (NULL), which HIP
  * cannot capture: pass a created stream. */
 int peanut_pred_use_graph(peanut_pred_t* h, int enable);
+/* Tuning options of this handle (see above).  Not while the probe is enabled. */
+int peanut_pred_set_option(peanut_pred_t* h, const char* key, long long value);
+int peanut_pred_get_option(peanut_pred_t* h, const char* key, long long* value);
 
 /* ------------------------------------------------------------------------------------------
  * Stage 2 -- egocentric -> allocentric semantic-map projection
@@ -181,7 +199,7 @@ typedef struct peanut_map_cfg {
   int global_downscaling;          /* 2 */
   int vision_range;                /* 100 */
   double hfov;                     /* 79.0 */
-  int du_scale;                    /* 1 (only value supported) */
+  int du_scale;                    /* 1 (1..8: depth pixels taken every du_scale-th row / column, depth_utils.py:129-149) */
   double cat_pred_threshold, exp_pred_threshold, map_pred_threshold;   /* 5.0, 1.0, 0.1 */
   int num_sem_categories;          /* 10 */
   double camera_height;            /* 0.88 (m) */
@@ -255,6 +273,7 @@ typedef struct peanut_rcnn peanut_rcnn_t;
  * "....conv2.norm.running_var", "backbone.fpn_lateral3.bias", "proposal_generator.rpn_head.conv.weight". */
 int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const peanut_tensor* tensors, int n_tensors);
 void peanut_rcnn_destroy(peanut_rcnn_t* h);
+int peanut_rcnn_set_option(peanut_rcnn_t* h, const char* key, long long value);
 /* Geometry of a (B,H,W) input: resized (h,w), zero-padded (h,w), the 5 pyramid level sizes p2..p6 as
  * level_hw = {h2,w2,...,h6,w6}, workspace bytes, conv FLOPs per image.  Any output may be NULL. */
 int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], int padded_hw[2], int level_hw[10],
@@ -280,7 +299,9 @@ int peanut_rcnn_preprocess(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
  * back, image-major, in decreasing score order inside an image: boxes device [sum n, 4] (x0, y0, x1, y1 in pixels of
  * the ORIGINAL frame), scores device [sum n], classes device int32 [sum n], masks device uint8 [sum n, H, W] (1 where
  * the pasted mask >= mask_threshold; pass NULL to skip the mask head).  The caller sizes the buffers for
- * B * detections_per_image instances.  Synchronises the stream once (to read the detection counts). */
+ * B * detections_per_image instances.  Synchronises the stream once (to read the detection counts).  With precision
+ * FP16X3 the RPN objectness, class scores, box deltas and mask logits are scanned for non-finite values and the call
+ * returns PEANUT_ERANGE instead of an image without detections (one more 4-byte read behind the mask head). */
 int peanut_rcnn_inference(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
                           float* scores, int32_t* classes, uint8_t* masks, void* stream);
 /* SemanticPredMaskRCNN.get_prediction (nav/agent/utils/segmentation.py:41-62) for a batch of frames: the detector as
@@ -355,8 +376,9 @@ int peanut_seg_accumulate(const uint8_t* masks, const int32_t* classes, const fl
 typedef struct peanut_conv peanut_conv_t;
 /* w_oihw_host [cout][cin][kh][kw]; scale/shift host [cout] (NULL -> 1 / 0).  cin_pad = channel
  * count of the NHWC input buffer (multiple of 16, >= cin; extra channels must be zero-weighted,
- * which the packer guarantees).  precision = PEANUT_PREC_FP32 / BF16X6 / BF16X3: in the emulated modes a pointwise layer with
- * >= 64 output channels and the position GEMMs of a Winograd layer run on the bf16 matrix cores, every other layer in fp32;
+ * which the packer guarantees).  precision = PEANUT_PREC_*: in the emulated modes a pointwise layer with >= 64 output
+ * channels and the position GEMMs of a Winograd layer run on csrc/gemm_rs.hip, every other conv with a multiple of 16 input
+ * channels on csrc/conv_rs.hip;
  * peanut_conv_precision() returns the PEANUT_PREC_* mode the layer actually runs in (no silent change of arithmetic).  conv_algo = PEANUT_ALGO_* (AUTO: stride-1 3x3 layers with
  * >= 128 input channels run as Winograd F(4x4,3x3), scratch allocated on first use per shape). */
 int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const float* scale_host,
@@ -364,6 +386,7 @@ int peanut_conv_create(peanut_conv_t** out, const float* w_oihw_host, const floa
                        int pad, int dil, int relu, int precision, int conv_algo);
 void peanut_conv_destroy(peanut_conv_t* c);
 int peanut_conv_precision(peanut_conv_t* c);
+int peanut_conv_set_option(peanut_conv_t* c, const char* key, long long value);
 /* x_dev [B,H,W,cin_pad] (or split x_dev [..,c1] ++ x2_dev [..,cin_pad-c1] when x2_dev != NULL),
  * res_dev optional [B,Ho,Wo,cout], y_dev [B,Ho,Wo,cout]. */
 int peanut_conv_forward(peanut_conv_t* c, const float* x_dev, const float* x2_dev, int c1, const float* res_dev,

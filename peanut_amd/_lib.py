@@ -17,11 +17,15 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 10    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 11    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
     pass
+
+
+class PeanutRangeError(PeanutHipError, FloatingPointError):
+    """PEANUT_ERANGE: precision fp16x3 and a value left fp16's exponent range (include/peanut_hip.h)."""
 
 
 class PredCfgC(C.Structure):
@@ -131,6 +135,13 @@ SIGNATURES = {
     "peanut_conv_destroy": (None, [_P]),
     "peanut_conv_precision": (C.c_int, [_P]),
     "peanut_conv_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "peanut_set_default_option": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "peanut_get_default_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
+    "peanut_option_list": (C.c_char_p, []),
+    "peanut_pred_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
+    "peanut_pred_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_longlong)]),
+    "peanut_conv_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
+    "peanut_rcnn_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
 }
 
 
@@ -194,9 +205,50 @@ def load() -> C.CDLL:
         return lib
 
 
+_OPTION_LOCK = threading.RLock()
+
+
+class default_options:
+    """``with default_options(wino_m=6, pw256_mink=2048): handle = ...`` -- changes the process defaults of the library's
+    tuning options (csrc/options.h; ``peanut_option_list()`` names them) for the handles CREATED inside the block and
+    restores them afterwards.  A handle snapshots the defaults when it is created, so this is how the create-time options
+    (Winograd forms, packing tiles) reach one handle without touching the environment; run-time options can also be changed
+    on a live handle (``peanut_pred_set_option`` / ``peanut_conv_set_option`` / ``peanut_rcnn_set_option``)."""
+
+    def __init__(self, **options):
+        self.options = {k: int(v) for k, v in options.items()}
+        self.saved = {}
+
+    def __enter__(self):
+        lib = load()
+        _OPTION_LOCK.acquire()
+        try:
+            for k, v in self.options.items():
+                old = C.c_longlong()
+                check(lib.peanut_get_default_option(k.encode(), C.byref(old)), "peanut_get_default_option")
+                self.saved[k] = old.value
+                check(lib.peanut_set_default_option(k.encode(), v), "peanut_set_default_option")
+        except Exception:
+            self.__exit__(None, None, None)
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        try:
+            for k, v in self.saved.items():
+                lib.peanut_set_default_option(k.encode(), v)
+            self.saved = {}
+        finally:
+            _OPTION_LOCK.release()
+        return False
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().peanut_last_error()
+        if rc == -5:
+            raise PeanutRangeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
         raise PeanutHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 

@@ -35,8 +35,8 @@ struct ConvDesc {
   const float* w_packed;   // device: fp32 weights packed for the fp32 MFMA kernels
   const float* scale;      // device [cout_pad]
   const float* shift;      // device [cout_pad]
-  // emulated-fp32 modes (bf16x6 / bf16x3), pointwise layers only: the layer runs on gemm_rs.hip -- fp32 activations split
-  // into bf16 pieces in registers, the weights' pieces pre-split in w_s
+  // emulated-fp32 modes (bf16x6 / fp16x3 / bf16x3): fp32 activations split into 16-bit pieces in registers, the weights'
+  // pieces pre-split in w_s -- pointwise layers on gemm_rs.hip (rs = 1), every other conv on conv_rs.hip (rs = 2)
   int rs;                  // 1: pointwise layer on gemm_rs.hip; 2: any other conv on conv_rs.hip (k-tile = 16 channels of one tap)
   const void* w_s;         // device: pre-split weights [n-tile][k-tile of 16][plane][bn_tile][16 bf16] (pack_weights_sx), or null
   int s_planes;            // emulation kind (rs_common.h): 2 = bf16x3 (two bf16 pieces, three products), 3 = bf16x6 (three

@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "options.h"
 
 namespace peanut {
 
@@ -292,7 +293,7 @@ inline int plan_tail_split(int T, int S, int cus, int nkt, size_t tile_floats, s
   if (S <= 0 || ws_floats == 0) return 0;
   const int t = T % S;
   if (t == 0) return 0;
-  static const bool cu_model = [] { const char* e = getenv("PEANUT_SPLIT_MODEL"); return !(e && e[0] == '0'); }();
+  const bool cu_model = opt(OPT_SPLIT_MODEL) != 0;
   if (!cu_model || cus <= 0) {
     double best = 1.0;   // cost of the tail round without splitting, in tile-times
     int best_p = 1;
@@ -395,11 +396,9 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   p.n_sp = t * sp;
   p.n_full = T - t;
   p.partial = ws;
-  static const int nchunk = [] { const char* e = getenv("PEANUT_NCHUNK"); return e ? atoi(e) : 8; }();
   p.mtiles = mtiles;
-  p.nchunk = nchunk;
-  static const int res_prefetch = [] { const char* e = getenv("PEANUT_RES_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }();
-  p.res_prefetch = res_prefetch;
+  p.nchunk = (int)opt(OPT_NCHUNK);
+  p.res_prefetch = opt(OPT_RES_PREFETCH) != 0;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(NT), 0, stream, p);
   if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();

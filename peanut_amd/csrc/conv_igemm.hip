@@ -278,15 +278,15 @@ const float* zero_page() {
 }
 
 void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk) {
-  static const int forced_bk = [] { const char* e = getenv("PEANUT_FP32_BK"); return e ? atoi(e) : 0; }();
+  const int forced_bk = (int)opt(OPT_FP32_BK);
   *bk = (cin_pad % 32 == 0) ? 32 : 16;
   if (forced_bk == 16) *bk = 16;   // experiment knob: 3 workgroups/CU instead of 2 in the fp32 kernel
   *bn_tile = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
   // 128 x 64 tiles (48 KB LDS, three workgroups per CU instead of two) for the layers with <= 256 input channels: their
   // time goes to the epilogue's memory phases (output + residual per few k-tiles), which more resident workgroups
   // overlap better.  Measured (profiles/r2h): layer1 conv3 0.37 -> 0.30 ms, layer2 conv3 0.24 -> 0.20, layer3 conv3
-  // 0.645 -> 0.573; larger K loses (the matrix-core share grows).  PEANUT_BN64_MAXK overrides the threshold.
-  static const int bn64_maxk = [] { const char* e = getenv("PEANUT_BN64_MAXK"); return e ? atoi(e) : 256; }();
+  // 0.645 -> 0.573; larger K loses (the matrix-core share grows).  Option bn64_maxk overrides the threshold.
+  const int bn64_maxk = (int)opt(OPT_BN64_MAXK);
   if (*bn_tile == 128 && cin_pad <= bn64_maxk) *bn_tile = 64;
 }
 

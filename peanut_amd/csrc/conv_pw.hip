@@ -460,25 +460,15 @@ int launch_pw_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t s
 
 }  // namespace
 
-bool conv_pw_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("PEANUT_PW_GLDS");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
-  return on == 1;
-}
+bool conv_pw_enabled() { return opt(OPT_PW_GLDS) != 0; }
 
 // whether the 256 x 128 kernel takes a [M x cout] pointwise layer (mt_per_group: 128-row tiles per weight group, 0 = plain)
 // Measured per layer (profiles/r2t): +2-3 % on the K >= 1024 layers (layer3/4 conv1, layer4 downsample: 129 -> 133 TF/s),
 // -3 % on the K = 512 ones (short k-loops: with one workgroup per CU nobody computes under a tile's epilogue), level on
 // the K = 2048 Winograd GEMM of the bottleneck.  Grouped GEMMs need whole 256-row tiles per weight group.
-int conv_pw_256_min_k() {
-  static const int min_k = [] { const char* e = getenv("PEANUT_PW256_MINK"); return e ? atoi(e) : 1024; }();
-  return min_k;
-}
+int conv_pw_256_min_k() { return (int)opt(OPT_PW256_MINK); }
 bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin) {
-  static const long long min_tiles = [] { const char* e = getenv("PEANUT_PW256_MINTILES"); return e ? atoll(e) : 256LL; }();
+  const long long min_tiles = opt(OPT_PW256_MINTILES);
   return bn_tile == 128 && cin >= conv_pw_256_min_k() && mt_per_group % 2 == 0 && M * cout >= min_tiles * 256 * 128;
 }
 
@@ -487,17 +477,17 @@ bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
 // shape (profiles/r5c): K = 768 -> N = 1024 (layer3.0 conv3 + downsample) 1.441 -> 1.386 ms, K = 1536 -> N = 2048 (layer4.0)
 // 5.350 -> 5.148 ms (140.8 TF/s); the N = 512 layers LOSE 5-6 % (900 tiles over 256 CUs: 3.5 rounds) and so do the
 // K = 512 -> N = 2048 ones (-3 %: 16 k-tiles per tile, and with one workgroup per CU nothing runs under the epilogue).
-// Hence: at least PEANUT_PW256W_MINK (768; 0 = off) input channels and PEANUT_PW256W_MINTILES (1536: six rounds) tiles.
+// Hence: at least pw256w_mink (768; 0 = off) input channels and pw256w_mintiles (1536: six rounds) tiles (options.h).
 bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush) {
-  static const int min_k = [] { const char* e = getenv("PEANUT_PW256W_MINK"); return e ? atoi(e) : 768; }();
-  static const long long min_tiles = [] { const char* e = getenv("PEANUT_PW256W_MINTILES"); return e ? atoll(e) : 1536LL; }();
+  const int min_k = (int)opt(OPT_PW256W_MINK);
+  const long long min_tiles = opt(OPT_PW256W_MINTILES);
   return min_k > 0 && bn_tile == 128 && cout % 256 == 0 && mt_per_group == 0 && flush == 0 && cin >= min_k &&
          ((M + 255) / 256) * (cout / 256) >= min_tiles;
 }
 
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
-  static const int phase_shift_w = [] { const char* e = getenv("PEANUT_PW256_PHASE"); return (e && e[0] == '0') ? 0 : 1; }();
+  const int phase_shift_w = opt(OPT_PW256_PHASE) != 0;
   if (conv_pw_uses_ares(p.c1, p.cout, p.M, p.stride, p.c2 != 0, p.flush, bn_tile)) return launch_conv_pw_ares(p, bn_tile, stream);
   if (conv_pw_uses_256w(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, p.flush)) {
     static SlotCache slots256w;
@@ -512,8 +502,7 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
     static SlotCache slots256;
     ConvKParams q = p;
     if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
-    static const int phase_shift = [] { const char* e = getenv("PEANUT_PW256_PHASE"); return (e && e[0] == '0') ? 0 : 1; }();
-    q.phase_shift = phase_shift;
+    q.phase_shift = phase_shift_w;
     note_kernel("conv_pw_glds_256x128");
     return launch_with_tail_split<decltype(&conv_pw_glds256_kernel), 256, 128, 512>(&conv_pw_glds256_kernel, q, ws, ws_floats, stream,
                                                                                      &slots256);

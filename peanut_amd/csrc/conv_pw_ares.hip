@@ -285,11 +285,11 @@ int launch_ares_t(ConvKParams p, hipStream_t stream) {
 
 // Which pointwise layers / grouped GEMMs take the A-resident kernel: K = 128 or 256 from one source, stride 1, whole
 // 128-row and 128-column tiles (every Bottleneck conv3 and Winograd position GEMM of the prediction net at batch sizes
-// that fill the chip), one running sum or partial sums of 64 channels, and at least PEANUT_PW_ARES_MINUNITS units (two
-// per CU).  PEANUT_PW_ARES=0 switches the kernel off.
+// that fill the chip), one running sum or partial sums of 64 channels, and at least pw_ares_minunits units (two
+// per CU).  Option pw_ares = 0 switches the kernel off (options.h).
 bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_source, int flush_ktiles, int bn_tile) {
-  static const int on = [] { const char* e = getenv("PEANUT_PW_ARES"); return (e && e[0] == '0') ? 0 : 1; }();
-  static const long long min_units = [] { const char* e = getenv("PEANUT_PW_ARES_MINUNITS"); return e ? atoll(e) : 512LL; }();
+  const bool on = opt(OPT_PW_ARES) != 0;
+  const long long min_units = opt(OPT_PW_ARES_MINUNITS);
   if (!on || two_source || (cin != 128 && cin != 256) || stride != 1 || M % 128 != 0 || cout % 128 != 0) return false;
   if (bn_tile != 64 && bn_tile != 128) return false;
   if (flush_ktiles != 0 && flush_ktiles != 2) return false;
@@ -298,8 +298,7 @@ bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_sour
 
 int launch_conv_pw_ares(const ConvKParams& p0, int bn_tile, hipStream_t stream) {
   ConvKParams p = p0;
-  static const int phase_shift = [] { const char* e = getenv("PEANUT_PW256_PHASE"); return (e && e[0] == '0') ? 0 : 1; }();
-  p.phase_shift = phase_shift;
+  p.phase_shift = opt(OPT_PW256_PHASE) != 0;
   p.ares_pbn = bn_tile;
   p.mtiles = p.M / 128;
   p.ntiles = p.cout / 128;

@@ -280,8 +280,8 @@ void pack_weights_sx(const float* w, int cout, int cin_real, int cin_pad, int bn
 // 256 x 256 tiles (one workgroup per CU) where the shape fills the chip with them and K is long enough to amortise
 // a tile's epilogue, which nobody computes under with one workgroup per CU; else 128 x 128 (two per CU) / 128 x 64.
 bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int cin) {
-  static const int min_k = [] { const char* e = getenv("PEANUT_RS256_MINK"); return e ? atoi(e) : 512; }();
-  static const long long min_tiles = [] { const char* e = getenv("PEANUT_RS256_MINTILES"); return e ? atoll(e) : 256LL; }();
+  const int min_k = (int)opt(OPT_RS256_MINK);
+  const long long min_tiles = opt(OPT_RS256_MINTILES);
   return cin >= min_k && bn_tile == 128 && cout % 256 == 0 && mt_per_group % 2 == 0 && M * cout >= min_tiles * 256 * 256;
 }
 
@@ -291,8 +291,8 @@ bool gemm_rs_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
 // cut 4 ways along K, 16 k-tiles per workgroup) beats 212 workgroups of 64 k-tiles each: batch-1 detector 4.96 vs 5.51 ms
 // -- hence the K bound.
 bool gemm_rs_uses_64(int cout, long long M, int bn_tile, int cin) {
-  static const int max_tiles = [] { const char* e = getenv("PEANUT_RS64_MAXTILES"); return e ? atoi(e) : 128; }();
-  static const int max_k = [] { const char* e = getenv("PEANUT_RS64_MAXK"); return e ? atoi(e) : 512; }();
+  const int max_tiles = (int)opt(OPT_RS64_MAXTILES);
+  const int max_k = (int)opt(OPT_RS64_MAXK);
   const long long t128 = ((M + 127) / 128) * ((cout + bn_tile - 1) / bn_tile);
   return cout % 64 == 0 && cin <= max_k && t128 < max_tiles;
 }

@@ -411,7 +411,7 @@ int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned lo
       unsigned char* in = act + (size_t)(*cur) * nt;
       unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
       unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
-      static const bool local32 = [] { const char* e = getenv("PEANUT_FMM_LOCAL32"); return !(e && e[0] == '0'); }();
+      const bool local32 = opt(OPT_FMM_LOCAL32) != 0;
       if (local32)
         hipLaunchKernelGGL((fmm_round_kernel<SECOND, true>), dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p,
                            (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);

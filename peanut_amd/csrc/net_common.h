@@ -13,6 +13,7 @@
 
 #include "../../include/peanut_hip.h"
 #include "common.h"
+#include "options.h"
 
 namespace peanut {
 
@@ -114,14 +115,13 @@ inline int precision_of_planes(int planes) {
 }
 // PEANUT_RS_CONV=0 keeps the non-pointwise layers of the emulated modes on the fp32 MFMA kernel (A/B measurements)
 inline bool rs_conv_enabled() {
-  static const bool on = [] { const char* e = getenv("PEANUT_RS_CONV"); return !(e && e[0] == '0'); }();
-  return on;
+  return opt(OPT_RS_CONV) != 0;
 }
 // n-tile of a pointwise layer's pre-split weights in the emulated-fp32 modes (0: the layer stays on the fp32 kernel)
 inline int rs_bn_tile(int cin_pad, int cout, int kh, int kw, int pad) {
   if (kh != 1 || kw != 1 || pad != 0 || cin_pad % 16 != 0 || cout < 64) return 0;
   // 128 x 64 tiles (three workgroups per CU) for the short-K layers whose time is their epilogue's HBM traffic
-  static const int bn64_maxk = [] { const char* e = getenv("PEANUT_RS_BN64_MAXK"); return e ? atoi(e) : 128; }();
+  const int bn64_maxk = (int)opt(OPT_RS_BN64_MAXK);
   return (cout >= 128 && cin_pad > bn64_maxk) ? 128 : 64;
 }
 
@@ -187,7 +187,7 @@ inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int
   // are fp32 in every precision mode.
   // In the three-product modes the direct register-split kernel (conv_rs.hip) is the faster one for those narrow layers
   // (fp16x3, layer1 conv2: 0.175 ms direct, 0.21 ms as Winograd; bf16x6: 0.248 -> 0.22 ms; profiles/r4i): they keep 128.
-  static const int env_min = [] { const char* e = getenv("PEANUT_WINO_MIN_CIN"); return e ? atoi(e) : 0; }();
+  const int env_min = (int)opt(OPT_WINO_MIN_CIN);
   const bool three_products = precision == PEANUT_PREC_FP16X3 || precision == PEANUT_PREC_BF16X3;
   const int min_cin = env_min ? env_min : (three_products && min_cin_default < 128 ? 128 : min_cin_default);
   return kh == 3 && kw == 3 && stride == 1 && pad == dil && cin_pad >= min_cin && cin_pad % 32 == 0 && cout % 4 == 0 && cout >= 64;
@@ -196,7 +196,7 @@ inline bool wino_eligible(int cin_pad, int cout, int kh, int kw, int stride, int
 // Layers with fewer than 128 input channels take their Winograd form only from this many input pixels on: below it the
 // direct kernel's one launch beats transform + GEMM + transform (one 240 x 240 map: 3 600 pixels in layer1)
 inline long long wino_min_pixels(int cin_pad) {
-  static const long long env = [] { const char* e = getenv("PEANUT_WINO_NARROW_MINPIX"); return e ? atoll(e) : 100000LL; }();
+  const long long env = opt(OPT_WINO_NARROW_MINPIX);
   return cin_pad < 128 ? env : 0;
 }
 
@@ -211,12 +211,10 @@ inline long long wino_min_pixels(int cin_pad) {
 // sub-grids are 15 x 15 -- 3 x 3 tiles of 6 (18 rows) or 4 x 4 tiles of 4 (16): 576 position-tiles either way, F(4x4) stays
 // -- while a 720 x 720 map's 23 x 23 sub-grids take 4 x 4 tiles of 6 or 6 x 6 tiles of 4, and F(6x6) executes 0.71 of it.
 inline int wino_tile_for(int dil, int requested) {
-  const char* e = getenv("PEANUT_WINO_M");
-  const int forced = e ? atoi(e) : 0;
+  const int forced = (int)opt(OPT_WINO_M);
   if (forced >= 4 && forced <= 6) return forced;
   if (requested >= 4 && requested <= 6) return requested;
-  const char* md = getenv("PEANUT_WINO6_MAXDIL");            // A/B knob: largest dilation that gets an F(6x6) form at all
-  return dil <= (md ? atoi(md) : 4) ? 6 : 4;
+  return dil <= (int)opt(OPT_WINO6_MAXDIL) ? 6 : 4;            // A/B knob: largest dilation that gets an F(6x6) form at all
 }
 
 // Winograd form of the PSP bottleneck over x: 0 = the backbone's policy (F(6x6) with an F(4x4) twin, chosen per shape) on
@@ -226,8 +224,7 @@ inline int wino_tile_for(int dil, int requested) {
 // accuracy: 8.9e-6 -> 1.15e-5 / 7.0e-6 -> 9.3e-6 from the float64 run at 480 x 480 in bf16x6 / fp16x3).
 // PEANUT_WINO_HEAD_M = 4 / 5 / 6 pins one form.
 inline int wino_head_tile(int precision) {
-  const char* e = getenv("PEANUT_WINO_HEAD_M");
-  const int m = e ? atoi(e) : 0;
+  const int m = (int)opt(OPT_WINO_HEAD_M);
   if (m >= 4 && m <= 6) return m;
   return rs_planes_of(precision) ? 4 : 0;
 }
@@ -241,8 +238,7 @@ inline int wino_head_tile(int precision) {
 // (measured cost: within noise); PEANUT_WINO_FLUSH_CH overrides the 64 (a multiple of 32; 0 = off).
 inline int wino_flush_channels(bool rs) {
   if (rs) return 0;
-  const char* e = getenv("PEANUT_WINO_FLUSH_CH");
-  const int ch = e ? atoi(e) : 64;
+  const int ch = (int)opt(OPT_WINO_FLUSH_CH);
   return (ch > 0 && ch % 32 == 0) ? ch : 0;
 }
 
@@ -252,8 +248,7 @@ inline int wino_flush_channels(bool rs) {
 // F(6x6) executes less on every map size the agent uses, so those layers do not pay the upload for a third form
 // (PEANUT_WINO5_MINDIL: smallest dilation that gets one; 0 = none, 1 = every backbone layer).
 inline bool wino5_wanted(int dil) {
-  const char* e = getenv("PEANUT_WINO5_MINDIL");
-  const int mindil = e ? atoi(e) : 4;
+  const int mindil = (int)opt(OPT_WINO5_MINDIL);
   return mindil > 0 && dil >= mindil;
 }
 

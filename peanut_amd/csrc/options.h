@@ -1,0 +1,125 @@
+// Tuning options of the library -- kernel gates, Winograd form policy, launch-plan switches.
+//
+// Every option has a key ("pw256_mink"), a PEANUT_<KEY> environment variable that supplies its process default (read once,
+// on first use) and a built-in default.  Handles (peanut_pred_t, peanut_conv_t, peanut_rcnn_t) SNAPSHOT the process
+// defaults when they are created and carry their own copy from then on: peanut_*_set_option changes one handle,
+// peanut_set_default_option the defaults later handles start from -- so two handles in one process can run different
+// policies and tests need no environment games.  While an API call runs on a handle, that handle's copy is the calling
+// thread's "active" set (OptionScope); the gates in the kernel sources read opt(OPT_...).
+//
+// Options that shape the UPLOADED weights (wino_m, wino_head_m, wino6_maxdil, wino5_mindil, wino_flush_ch, wino_min_cin,
+// bn64_maxk, fp32_bk, rs_conv, rs_bn64_maxk, rcnn_wino_m, rcnn_stem_s2d) are read while a handle is created: set them as
+// defaults before the create call (the Python mirrors take `options=`); changing them on a live handle is refused.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+namespace peanut {
+
+enum OptionId {
+  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW_ARES,
+  OPT_PW_ARES_MINUNITS, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
+  OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
+  OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
+  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32,
+  OPT_COUNT
+};
+
+struct OptionInfo {
+  const char* key;
+  long long def;
+  bool upload_time;      // read while a handle is created (shapes the uploaded weights)
+  const char* help;
+};
+
+inline const OptionInfo* option_table() {
+  static const OptionInfo t[OPT_COUNT] = {
+      {"pw_glds", 1, false, "fp32 1x1 convs / grouped GEMMs on the LDS-DMA kernels of conv_pw.hip (0: conv_igemm)"},
+      {"pw256_mink", 1024, false, "fewest input channels for the 256 x 128 three-stage kernel"},
+      {"pw256_mintiles", 256, false, "fewest 256 x 128 tiles for that kernel"},
+      {"pw256_phase", 1, false, "the two waves of a SIMD request their LDS-DMA pieces half an iteration apart"},
+      {"pw256w_mink", 768, false, "fewest input channels for the 256 x 256 two-stage kernel (0: off)"},
+      {"pw256w_mintiles", 1536, false, "fewest 256 x 256 tiles for that kernel"},
+      {"pw_ares", 1, false, "K = 128 / 256 pointwise layers on the persistent A-resident kernel (conv_pw_ares.hip)"},
+      {"pw_ares_minunits", 512, false, "fewest (m-tile, n-tile) units for that kernel"},
+      {"bn64_maxk", 256, true, "128 x 64 tiles for layers with at most this many input channels"},
+      {"fp32_bk", 0, true, "16: force 16-channel k-tiles in conv_igemm (experiment)"},
+      {"nchunk", 8, false, "n-tiles per chunk of the tile order (0: n fastest over all n-tiles)"},
+      {"res_prefetch", 1, false, "request the first residual rows before the last k-tile's MFMAs"},
+      {"split_model", 1, false, "tail split-K plan counts CUs (1) or resident slots (0)"},
+      {"rs_conv", 1, true, "emulated modes: non-pointwise convs on conv_rs.hip (0: fp32 MFMA kernel)"},
+      {"rs_bn64_maxk", 128, true, "emulated modes: 128 x 64 tiles up to this many input channels"},
+      {"rs256_mink", 512, false, "emulated modes: fewest input channels for the 256 x 256 kernel"},
+      {"rs256_mintiles", 256, false, "emulated modes: fewest 256 x 256 tiles for it"},
+      {"rs64_maxk", 512, false, "emulated modes: 64 x 64 tiles up to this many input channels"},
+      {"rs64_maxtiles", 128, false, "emulated modes: ... and below this many 128-row tiles"},
+      {"wino_m", 0, true, "4 / 5 / 6: force one Winograd form on every eligible layer (0: policy)"},
+      {"wino_head_m", 0, true, "4 / 5 / 6: Winograd form of the PSP bottleneck (0: policy)"},
+      {"wino6_maxdil", 4, true, "largest dilation that gets an F(6x6) form"},
+      {"wino5_mindil", 4, true, "smallest dilation that also gets an F(5x5) form (0: none)"},
+      {"wino_flush_ch", 64, true, "channels per partial sum of the position GEMMs' two-level accumulation (0: off)"},
+      {"wino_min_cin", 0, true, "fewest input channels of a Winograd layer (0: the planner's policy)"},
+      {"wino_narrow_minpix", 100000, false, "layers under 128 channels take their Winograd form from this many input pixels on"},
+      {"ppm_overlap", -1, false, "pyramid branch of the PSP head on a side stream: 0 / 1, -1 = by size"},
+      {"ppm_grouped", -1, false, "per-scale PSP GEMMs as one grouped launch: 0 / 1, -1 = by size"},
+      {"rcnn_wino_m", 0, true, "detector front end: 4 / 5 / 6 pins one Winograd form (0: per shape)"},
+      {"rcnn_stem_s2d", 1, true, "detector stem 7x7 stride 2 as a space-to-depth 4x4 conv"},
+      {"fmm_local32", 1, false, "goal solver: single-precision local solve inside a tile"},
+  };
+  return t;
+}
+
+struct Options {
+  long long v[OPT_COUNT];
+};
+
+inline int option_index(const char* key) {
+  if (!key) return -1;
+  std::string k(key);
+  for (auto& c : k) c = (char)((c >= 'A' && c <= 'Z') ? c - 'A' + 'a' : c);
+  if (k.rfind("peanut_", 0) == 0) k = k.substr(7);
+  const OptionInfo* t = option_table();
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (k == t[i].key) return i;
+  return -1;
+}
+
+// process defaults: built-in values overridden by PEANUT_<KEY> (read once), then by peanut_set_default_option
+inline Options& default_options() {
+  static Options d = [] {
+    Options o;
+    const OptionInfo* t = option_table();
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      o.v[i] = t[i].def;
+      std::string env = "PEANUT_";
+      for (const char* c = t[i].key; *c; ++c) env += (char)((*c >= 'a' && *c <= 'z') ? *c - 'a' + 'A' : *c);
+      const char* e = getenv(env.c_str());
+      if (e && *e) o.v[i] = atoll(e);
+    }
+    return o;
+  }();
+  return d;
+}
+
+inline const Options*& active_options_ptr() {
+  static thread_local const Options* p = nullptr;
+  return p;
+}
+
+inline long long opt(OptionId id) {
+  const Options* a = active_options_ptr();
+  return (a ? a : &default_options())->v[id];
+}
+
+// RAII: the options of the handle an API call runs on become the calling thread's active set
+struct OptionScope {
+  const Options* saved;
+  explicit OptionScope(const Options* o) : saved(active_options_ptr()) { active_options_ptr() = o; }
+  ~OptionScope() { active_options_ptr() = saved; }
+  OptionScope(const OptionScope&) = delete;
+  OptionScope& operator=(const OptionScope&) = delete;
+};
+
+}  // namespace peanut

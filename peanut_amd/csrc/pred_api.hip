@@ -71,12 +71,14 @@ struct Plan {
 using namespace peanut;
 
 struct peanut_conv {
+  Options opts = default_options();   // this handle's tuning options (options.h): snapshot of the process defaults at creation
   ConvLayer L;
   DevBuf ws;   // tail split-K scratch, allocated on first forward
   DevBuf wino_v, wino_m;   // Winograd scratch, grown on demand
 };
 
 struct peanut_pred {
+  Options opts = default_options();   // this handle's tuning options (options.h): snapshot of the process defaults at creation
   peanut_pred_cfg cfg{};
   int cin_pad = 0;
   std::vector<std::unique_ptr<ConvLayer>> convs;
@@ -355,7 +357,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   // get their own split-K scratch.  Measured (profiles/r2m): +0.6 % at batch 32, +0.8 % on one 720 x 720 map, -3 % on
   // one 240 x 240 map (the GEMM is then shorter than the branch and the two event waits cost more than they hide), so
   // the branch only forks when the GEMM has >= 4096 rows.  PEANUT_PPM_OVERLAP=0 / 1 forces it off / on.
-  static const int overlap_env = [] { const char* e = getenv("PEANUT_PPM_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const int overlap_env = (int)opt(OPT_PPM_OVERLAP);
   const bool overlap = h->bottleneck_x != nullptr && (overlap_env >= 0 ? overlap_env == 1 : (long long)B * x.H * x.W >= 4096);
   const size_t side_first = pl->ops.size();
   if (overlap) {
@@ -380,7 +382,7 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     const int cand = (B * kmax * kmax + 127) / 128 * 128;
     long long separate = 0;
     for (int i = 0; i < h->cfg.n_pool_scales; ++i) separate += ((long long)B * h->cfg.pool_scales[i] * h->cfg.pool_scales[i] + 127) / 128 * 128;
-    static const int env = [] { const char* e = getenv("PEANUT_PPM_GROUPED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const int env = (int)opt(OPT_PPM_GROUPED);
     if (env != 0 && ((long long)h->cfg.n_pool_scales * cand <= 2 * separate || env == 1)) srows = cand;
   }
   const int prow = srows ? h->cfg.n_pool_scales * srows : nbins * B;       // rows of pooled / table / q
@@ -577,12 +579,74 @@ extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
-int peanut_abi_version(void) { return 10; }
+int peanut_abi_version(void) { return 11; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 #ifndef PEANUT_SOURCE_HASH
 #define PEANUT_SOURCE_HASH ""
 #endif
 const char* peanut_source_hash(void) { return PEANUT_SOURCE_HASH; }
+
+// ---- tuning options (options.h) ----
+namespace {
+int option_lookup(const char* key, const char* who) {
+  const int i = option_index(key);
+  if (i < 0) return fail(PEANUT_EINVAL, std::string(who) + ": unknown option '" + (key ? key : "(null)") + "'");
+  return i;
+}
+int handle_set_option(Options& o, const char* key, long long value, const char* who) {
+  const int i = option_lookup(key, who);
+  if (i < 0) return i;
+  if (option_table()[i].upload_time)
+    return fail(PEANUT_EINVAL, std::string(who) + ": option '" + option_table()[i].key +
+                                   "' shapes the uploaded weights; set it with peanut_set_default_option before creating the handle");
+  o.v[i] = value;
+  return 0;
+}
+}  // namespace
+
+int peanut_set_default_option(const char* key, long long value) {
+  const int i = option_lookup(key, "peanut_set_default_option");
+  if (i < 0) return i;
+  default_options().v[i] = value;
+  return 0;
+}
+int peanut_get_default_option(const char* key, long long* value) {
+  const int i = option_lookup(key, "peanut_get_default_option");
+  if (i < 0) return i;
+  if (value) *value = default_options().v[i];
+  return 0;
+}
+const char* peanut_option_list(void) {
+  static const std::string text = [] {
+    std::string t;
+    const OptionInfo* tab = option_table();
+    for (int i = 0; i < OPT_COUNT; ++i)
+      t += std::string(tab[i].key) + "=" + std::to_string(tab[i].def) + (tab[i].upload_time ? " [create-time] " : " ") + tab[i].help + "\n";
+    return t;
+  }();
+  return text.c_str();
+}
+int peanut_pred_set_option(peanut_pred_t* h, const char* key, long long value) {
+  if (!h) return fail(PEANUT_EINVAL, "peanut_pred_set_option: null handle");
+  if (h->probe) return fail(PEANUT_EINVAL, "peanut_pred_set_option: collect and disable the probe first");
+  if (int rc = handle_set_option(h->opts, key, value, "peanut_pred_set_option")) return rc;
+  h->graphs.clear();        // launch plans depend on the options: rebuilt on the next forward
+  h->plans.clear();
+  h->last_plan = nullptr;
+  h->probe_plan = nullptr;
+  return 0;
+}
+int peanut_pred_get_option(peanut_pred_t* h, const char* key, long long* value) {
+  if (!h) return fail(PEANUT_EINVAL, "peanut_pred_get_option: null handle");
+  const int i = option_lookup(key, "peanut_pred_get_option");
+  if (i < 0) return i;
+  if (value) *value = h->opts.v[i];
+  return 0;
+}
+int peanut_conv_set_option(peanut_conv_t* c, const char* key, long long value) {
+  if (!c) return fail(PEANUT_EINVAL, "peanut_conv_set_option: null handle");
+  return handle_set_option(c->opts, key, value, "peanut_conv_set_option");
+}
 
 int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const peanut_tensor* tensors, int n) {
   if (!out || !cfg || (!tensors && n > 0)) return fail(PEANUT_EINVAL, "peanut_pred_create: null argument");
@@ -594,6 +658,7 @@ int peanut_pred_create(peanut_pred_t** out, const peanut_pred_cfg* cfg, const pe
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT)
     return fail(PEANUT_EINVAL, "conv_algo must be PEANUT_ALGO_{AUTO,DIRECT}");
   auto h = std::make_unique<peanut_pred>();
+  OptionScope option_scope(&h->opts);
   h->cfg = *cfg;
   h->cin_pad = (cfg->in_channels + 15) / 16 * 16;
   TensorMap tm;
@@ -697,12 +762,14 @@ void peanut_pred_destroy(peanut_pred_t* h) { delete h; }
 
 size_t peanut_pred_workspace_bytes(peanut_pred_t* h, int B, int H, int W) {
   if (!h) return 0;
+  OptionScope option_scope(&h->opts);
   Plan* pl = get_plan(h, B, H, W);
   return pl ? pl->bytes : 0;
 }
 
 double peanut_pred_flops_per_map(peanut_pred_t* h, int H, int W) {
   if (!h) return 0;
+  OptionScope option_scope(&h->opts);
   Plan* pl = get_plan(h, 1, H, W);
   if (!pl) return 0;
   double f = 0;
@@ -741,6 +808,7 @@ int peanut_pred_debug_read(peanut_pred_t* h, const char* name, float* dst_dev, s
 int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, int B, int H, int W, int apply_sigmoid,
                         void* stream) {
   if (!h || !in_dev || !out_dev) return fail(PEANUT_EINVAL, "peanut_pred_forward: null argument");
+  OptionScope option_scope(&h->opts);
   Plan* pl = get_plan(h, B, H, W);
   if (!pl) return PEANUT_EINVAL;
   int rc;
@@ -839,6 +907,7 @@ int peanut_conv_create(peanut_conv_t** out, const float* w, const float* scale, 
     return fail(PEANUT_EINVAL, "peanut_conv_create: bad geometry");
   if (!precision_known(precision)) return fail(PEANUT_EINVAL, "peanut_conv_create: bad precision");
   auto c = std::make_unique<peanut_conv>();
+  OptionScope option_scope(&c->opts);
   c->L.name = "conv";
   if (conv_algo != PEANUT_ALGO_AUTO && conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "peanut_conv_create: bad conv_algo");
   int rc = upload_conv(c->L, w, scale, shift, cout, cin, cin_pad, kh, kw, stride, pad, dil, relu, precision);
@@ -863,6 +932,7 @@ int peanut_conv_precision(peanut_conv_t* c) {
 int peanut_conv_forward(peanut_conv_t* c, const float* x, const float* x2, int c1, const float* res, float* y, int B,
                         int H, int W, void* stream) {
   if (!c || !x || !y) return fail(PEANUT_EINVAL, "peanut_conv_forward: null argument");
+  OptionScope option_scope(&c->opts);
   const ConvDesc& d = c->L.d;
   ConvArgs a{};
   a.x = x; a.x2 = x2; a.res = res; a.y = y; a.B = B; a.H = H; a.W = W;

@@ -196,8 +196,7 @@ namespace {
 
 // Winograd form request of the detector's front-end convs: 0 = per-shape policy; PEANUT_RCNN_WINO_M = 4 pins F(4x4) (A/B)
 int rcnn_wino_request() {
-  const char* e = getenv("PEANUT_RCNN_WINO_M");
-  const int m = e ? atoi(e) : 0;
+  const int m = (int)opt(OPT_RCNN_WINO_M);
   return (m >= 4 && m <= 6) ? m : 0;
 }
 
@@ -458,13 +457,14 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
   if (!precision_known(cfg->precision)) return fail(PEANUT_EINVAL, "rcnn: precision must be PEANUT_PREC_{FP32,BF16X3,FP16X3,BF16X6}");
   if (cfg->conv_algo != PEANUT_ALGO_AUTO && cfg->conv_algo != PEANUT_ALGO_DIRECT) return fail(PEANUT_EINVAL, "rcnn: bad conv_algo");
   auto h = std::make_unique<peanut_rcnn>();
+  OptionScope option_scope(&h->opts);
   h->cfg = *cfg;
   TensorMap tm;
   for (int i = 0; i < n; ++i)
     if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
   int rc;
   if ((rc = add_rconv(h.get(), tm, "backbone.bottom_up.stem.conv1", 3, 16, cfg->stem_out, 7, 2, 3, true, 1, &h->stem))) return rc;
-  static const bool stem_s2d = [] { const char* e = getenv("PEANUT_RCNN_STEM_S2D"); return !(e && e[0] == '0'); }();
+  const bool stem_s2d = opt(OPT_RCNN_STEM_S2D) != 0;
   if (stem_s2d && (rc = add_stem_s2d(h.get(), tm, "backbone.bottom_up.stem.conv1", cfg->stem_out, &h->stem_s2d))) return rc;
   const int nblocks[3][4] = {{3, 4, 6, 3}, {3, 4, 23, 3}, {3, 8, 36, 3}};
   const int* nb = nblocks[cfg->depth == 50 ? 0 : (cfg->depth == 101 ? 1 : 2)];
@@ -509,9 +509,22 @@ int peanut_rcnn_create(peanut_rcnn_t** out, const peanut_rcnn_cfg* cfg, const pe
 
 void peanut_rcnn_destroy(peanut_rcnn_t* h) { delete h; }
 
+int peanut_rcnn_set_option(peanut_rcnn_t* h, const char* key, long long value) {
+  if (!h) return fail(PEANUT_EINVAL, "peanut_rcnn_set_option: null handle");
+  const int i = option_index(key);
+  if (i < 0) return fail(PEANUT_EINVAL, std::string("peanut_rcnn_set_option: unknown option '") + (key ? key : "(null)") + "'");
+  if (option_table()[i].upload_time)
+    return fail(PEANUT_EINVAL, std::string("peanut_rcnn_set_option: option '") + option_table()[i].key +
+                                   "' shapes the uploaded weights; set it with peanut_set_default_option before creating the handle");
+  h->opts.v[i] = value;
+  h->plans.clear();
+  return 0;
+}
+
 int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw_out[2], int padded_hw_out[2], int level_hw[10],
                      size_t* workspace_bytes, double* flops_per_image) {
   if (!h) return fail(PEANUT_EINVAL, "null handle");
+  OptionScope option_scope(&h->opts);
   RPlan* pl = get_rplan(h, B, H, W);
   if (!pl) return PEANUT_EINVAL;
   if (resized_hw_out) { resized_hw_out[0] = pl->nh; resized_hw_out[1] = pl->nw; }
@@ -529,6 +542,7 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw_out[2
 int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
                               float* const* objectness, float* const* deltas, void* stream) {
   if (!h || !img_bgr) return fail(PEANUT_EINVAL, "peanut_rcnn_forward_front: null argument");
+  OptionScope option_scope(&h->opts);
   RPlan* pl = get_rplan(h, B, H, W);
   if (!pl) return PEANUT_EINVAL;
   int rc;
@@ -596,6 +610,7 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
 
 int peanut_rcnn_preprocess(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* out_nchw, void* stream) {
   if (!h || !img_bgr || !out_nchw) return fail(PEANUT_EINVAL, "peanut_rcnn_preprocess: null argument");
+  OptionScope option_scope(&h->opts);
   RPlan* pl = get_rplan(h, B, H, W);
   if (!pl) return PEANUT_EINVAL;
   Norm3 nm;

@@ -36,6 +36,7 @@ struct RPlan {
 }  // namespace peanut
 
 struct peanut_rcnn {
+  peanut::Options opts = peanut::default_options();   // this handle's tuning options (options.h)
   peanut_rcnn_cfg cfg{};
   std::vector<std::unique_ptr<peanut::ConvLayer>> convs;
   peanut::ConvLayer* stem = nullptr;

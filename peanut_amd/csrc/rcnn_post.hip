@@ -699,9 +699,29 @@ struct peanut_rcnn::PostBufs {
   DevBuf dbox, dkey, dcat, dsbox, dscat, dsscore, dkeep, dnvalid, dkeys;
   DevBuf det_in, det_out, det_score, det_cls, det_count;
   DevBuf mrois, mlevel, mx0, mx1, mdeconv, mlogits, mprobs, splitk, wino_v, wino_m;
+  DevBuf range_flag;   // fp16x3: set when a checked stage output is not finite (see flag_nonfinite)
 };
 
 namespace {
+
+// fp16x3 detector: an activation outside fp16's range (Winograd-domain values included: B^T d B reaches ~100 x the
+// activations) makes the emulated layer's output inf - inf = NaN, and the selection kernels drop non-finite boxes and scores --
+// an overflow would come out as an image WITHOUT detections.  The stage outputs every later result depends on (RPN
+// objectness of all levels, class scores / box deltas, mask logits) are therefore scanned, and the call fails with
+// PEANUT_ERANGE instead (the prediction model's check_range does the same on its logits).
+__global__ __launch_bounds__(256) void flag_nonfinite_kernel(const float* __restrict__ p, size_t n, int* flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = p[i];
+    bad |= !(fabsf(v) <= 3.402823466e38f);      // false for inf and NaN
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+void flag_nonfinite(const float* p, size_t n, int* flag, hipStream_t s) {
+  if (n == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(flag_nonfinite_kernel, dim3(blocks), dim3(256), 0, s, p, n, flag);
+}
 
 int conv_on(const ConvLayer* L, const float* x, float* y, int B, int H, int W, float* splitk, float* wv, float* wm, hipStream_t s) {
   ConvArgs a{};
@@ -806,6 +826,7 @@ struct SemanticOut {
 static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int* n_det_host, float* boxes,
                                float* scores, int32_t* classes, uint8_t* masks, const SemanticOut& sem, void* stream) {
   if (!h || !img_bgr || !n_det_host || !boxes || !scores || !classes) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: null argument");
+  OptionScope option_scope(&h->opts);
   if (!h->has_heads) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: the handle was created without roi_heads.* tensors");
   if (B < 1 || B > 64) return fail(PEANUT_EINVAL, "peanut_rcnn_inference: 1 <= B <= 64");
   const peanut_rcnn_cfg& c = h->cfg;
@@ -872,6 +893,12 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   for (int l = 0; l < kLevels; ++l) { pyr[l] = (float*)pb.pyr[l].p; obj[l] = (float*)pb.obj[l].p; dl[l] = (float*)pb.dl[l].p; }
   if ((rc = peanut_rcnn_forward_front(h, img_bgr, B, H, W, pyr, obj, dl, stream))) return rc;
   for (int l = 0; l < kLevels; ++l) { lv.obj[l] = obj[l]; lv.delta[l] = dl[l]; }
+  const bool range_check = c.precision == PEANUT_PREC_FP16X3;
+  if (range_check) {
+    if ((rc = pb.range_flag.ensure(4))) return rc;
+    PEANUT_HIP_CHECK(hipMemsetAsync(pb.range_flag.p, 0, 4, s));
+    for (int l = 0; l < kLevels; ++l) flag_nonfinite(obj[l], (size_t)B * lv.n[l], (int*)pb.range_flag.p, s);
+  }
 
   // ---- RPN: per-level top-k, decode, per-image sort, NMS (per level), post-NMS top-k ----
   hipLaunchKernelGGL(rpn_topk_kernel, dim3(kLevels, B), dim3(1024), 0, s, lv, Ktot, (int*)pb.sel_idx.p, (float*)pb.sel_score.p);
@@ -899,6 +926,10 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   if ((rc = conv_on(h->fc2, (const float*)pb.f1.p, (float*)pb.f2.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
   if ((rc = conv_on(h->cls_score, (const float*)pb.f2.p, (float*)pb.cls.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
   if ((rc = conv_on(h->bbox_pred, (const float*)pb.f2.p, (float*)pb.bbox.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
+  if (range_check) {
+    flag_nonfinite((const float*)pb.cls.p, (size_t)N * (K + 1), (int*)pb.range_flag.p, s);
+    flag_nonfinite((const float*)pb.bbox.p, (size_t)N * 4 * K, (int*)pb.range_flag.p, s);
+  }
 
   // ---- fast_rcnn_inference: class candidates, per-image sort, class-wise NMS, top detections ----
   hipLaunchKernelGGL(box_post_kernel, dim3(blocks_for(N)), dim3(256), 0, s, (const float*)pb.cls.p, (const float*)pb.bbox.p, (const float*)pb.rois.p,
@@ -920,7 +951,16 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
 
   // ---- the one host read: detections per image ----
   PEANUT_HIP_CHECK(hipMemcpyAsync(n_det_host, pb.det_count.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  int range_bad = 0;
+  if (range_check) PEANUT_HIP_CHECK(hipMemcpyAsync(&range_bad, pb.range_flag.p, 4, hipMemcpyDeviceToHost, s));
   PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+  static const char* const kRangeMsg =
+      "peanut_rcnn_inference: precision fp16x3 -- a value left fp16's range (|x| >= 65520 in an emulated layer; for the Winograd "
+      "layers that is the transformed input B^T d B, up to ~100 x the activations); rerun the detector with bf16x6 or fp32";
+  if (range_bad) {
+    for (int b = 0; b < B; ++b) n_det_host[b] = 0;
+    return fail(PEANUT_ERANGE, kRangeMsg);
+  }
   Offsets64 of{};
   for (int b = 0; b < B; ++b) of.off[b + 1] = of.off[b] + n_det_host[b];
   const int n = of.off[B];
@@ -954,6 +994,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   if ((rc = conv_on(h->mask_pred, (const float*)pb.mdeconv.p, (float*)pb.mlogits.p, n, Pm, Pm * 4, sk, nullptr, nullptr, s))) return rc;
   hipLaunchKernelGGL(mask_prob_kernel, dim3(blocks_for((long long)n * 4 * Pm * Pm)), dim3(256), 0, s, (const float*)pb.mlogits.p, (const int*)classes, n,
                      Pm, K, (float*)pb.mprobs.p);
+  if (range_check) flag_nonfinite((const float*)pb.mlogits.p, (size_t)n * Pm * Pm * 4 * K, (int*)pb.range_flag.p, s);
   if (masks && (rc = peanut_paste_masks((const float*)pb.mprobs.p, boxes, n, 2 * Pm, H, W, c.mask_threshold, masks, stream))) return rc;
   if (sem.out) {
     SemGoal goal{};
@@ -962,6 +1003,11 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
     hipLaunchKernelGGL(paste_accumulate_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const float*)pb.mprobs.p, (const float*)boxes,
                        (const float*)scores, (const int*)classes, of, 2 * Pm, H, W, c.mask_threshold, sem.n_cats, sem.thr, sem.goal_thr, goal,
                        sem.out, total);
+  }
+  if (range_check) {      // the mask head's own overflow: one more 4-byte read (fp16x3 only)
+    PEANUT_HIP_CHECK(hipMemcpyAsync(&range_bad, pb.range_flag.p, 4, hipMemcpyDeviceToHost, s));
+    PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+    if (range_bad) return fail(PEANUT_ERANGE, kRangeMsg);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_rcnn_inference: ") + hipGetErrorString(e));

@@ -22,13 +22,15 @@ class FusedConv:
     weight: [cout, cin, kh, kw] (OIHW, host or device tensor); the NHWC input must carry
     ``cin_pad`` channels (multiple of 16; default round_up(cin, 16)), padded channels are ignored.
     ``conv_algo='auto'`` runs stride-1 3x3 layers with >= 128 input channels as Winograd F(4x4,3x3)
-    (fp32 transforms, csrc/winograd.hip); ``'direct'`` always uses the direct implicit GEMM.
+    (fp32 transforms, csrc/winograd.hip; the prediction planner goes down to 64 channels and picks F(5x5) / F(6x6) per
+    shape, a single conv keeps F(4x4)); ``'direct'`` always uses the direct implicit GEMM.  ``options``: tuning options of
+    this handle (csrc/options.h), e.g. ``{"pw256w_mintiles": 256}``.
     """
 
     def __init__(self, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0,
                  dilation: int = 1, relu: bool = False, cin_pad: Optional[int] = None,
-                 precision: str = "fp32", conv_algo: str = "auto", device=None):
+                 precision: str = "fp32", conv_algo: str = "auto", device=None, options=None):
         """``device``: HIP device the weights are uploaded to (default: the current one); inputs must live there."""
         self._lib = _lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -40,7 +42,7 @@ class FusedConv:
         sc = None if scale is None else np.ascontiguousarray(scale.detach().cpu().numpy(), dtype=np.float32)
         sh = None if shift is None else np.ascontiguousarray(shift.detach().cpu().numpy(), dtype=np.float32)
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):      # the library allocates on the current device
+        with _lib.default_options(**(options or {})), torch.cuda.device(self.device):      # the library allocates on the current device
             _lib.check(self._lib.peanut_conv_create(
                 C.byref(self._h), w.ctypes.data, None if sc is None else sc.ctypes.data,
                 None if sh is None else sh.ctypes.data, cout, cin, self.cin_pad, kh, kw, stride, padding,
@@ -54,6 +56,10 @@ class FusedConv:
             except Exception:  # pragma: no cover
                 pass
             self._h = C.c_void_p()
+
+    def set_option(self, key: str, value: int) -> None:
+        """Change one run-time tuning option of this conv handle (kernel gates; csrc/options.h)."""
+        _lib.check(self._lib.peanut_conv_set_option(self._h, key.encode(), int(value)), "peanut_conv_set_option")
 
     def out_hw(self, h: int, w: int):
         def o(n, k):

@@ -30,7 +30,8 @@ class HipSegmentor:
     device, ``prediction/mmseg/apis/inference.py:12-40``), here a handle of the HIP library."""
 
     def __init__(self, cfg: PredCfg, state_dict: Dict[str, torch.Tensor], device="cuda:0",
-                 classes=None, precision: str = "fp32", fold_ppm: bool = True, conv_algo: str = "auto"):
+                 classes=None, precision: str = "fp32", fold_ppm: bool = True, conv_algo: str = "auto",
+                 options: Optional[Dict[str, int]] = None):
         if not torch.cuda.is_available():
             raise _lib.PeanutHipError("PEANUT_Prediction_Model needs a HIP device (no CPU fallback)")
         self.cfg = cfg
@@ -67,7 +68,10 @@ class HipSegmentor:
         c.conv_algo = _lib.CONV_ALGOS[conv_algo]
         self.fold_ppm = bool(fold_ppm)
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        # tuning options of THIS handle (csrc/options.h): the library snapshots its process defaults at creation, so the
+        # create-time ones (Winograd forms, packing tiles) are set as defaults around the create call only
+        self.options = dict(options or {})
+        with _lib.default_options(**self.options), torch.cuda.device(self.device):
             _lib.check(self._lib.peanut_pred_create(C.byref(self._h), C.byref(c), arr, len(tensors)),
                        "peanut_pred_create")
 
@@ -83,6 +87,17 @@ class HipSegmentor:
     # nn.Module-ish surface the reference touches (prediction.py:150-152)
     def eval(self):
         return self
+
+    def set_option(self, key: str, value: int) -> None:
+        """Change one run-time tuning option of this handle (csrc/options.h; e.g. ``pw256_mink``, ``ppm_overlap``): its cached
+        launch plans are dropped and rebuilt under the new policy.  Create-time options are refused by the library."""
+        _lib.check(self._lib.peanut_pred_set_option(self._h, key.encode(), int(value)), "peanut_pred_set_option")
+        self.options[key] = int(value)
+
+    def get_option(self, key: str) -> int:
+        v = C.c_longlong()
+        _lib.check(self._lib.peanut_pred_get_option(self._h, key.encode(), C.byref(v)), "peanut_pred_get_option")
+        return int(v.value)
 
     def forward_logits(self, x: torch.Tensor, apply_sigmoid: bool = False,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -110,8 +125,9 @@ class HipSegmentor:
         instead of handing NaN probabilities to the planner.  ``forward_logits`` / ``get_prediction_batch`` stay
         asynchronous and unchecked."""
         if self.precision == "fp16x3" and not bool(torch.isfinite(y).all()):
-            raise FloatingPointError("precision='fp16x3': an activation left fp16's range (|x| >= 65520) and the output is "
-                                     "NaN; run this model with precision='bf16x6' (fp32's exponent range) or 'fp32'")
+            raise FloatingPointError("precision='fp16x3': a value left fp16's range (|x| >= 65520 in an emulated layer -- for "
+                                     "the Winograd layers that is the transformed input, up to ~100 x the activations) and the "
+                                     "output is NaN; run this model with precision='bf16x6' (fp32's exponent range) or 'fp32'")
         return y
 
     def workspace_bytes(self, b: int, h: int, w: int) -> int:
@@ -174,9 +190,11 @@ class HipSegmentor:
 
 
 def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
-                   precision: str = "fp32", fold_ppm: bool = True, conv_algo: str = "auto") -> HipSegmentor:
+                   precision: str = "fp32", fold_ppm: bool = True, conv_algo: str = "auto",
+                   options: Optional[Dict[str, int]] = None) -> HipSegmentor:
     """``prediction/mmseg/apis/inference.py:12-40``: config path (or PredCfg) + mmcv checkpoint.
-    ``state_dict`` lets tests/benchmarks pass seeded weights instead of a checkpoint file."""
+    ``state_dict`` lets tests/benchmarks pass seeded weights instead of a checkpoint file; ``options`` are the handle's
+    tuning options (csrc/options.h, e.g. ``{"wino_m": 6}``)."""
     if isinstance(config, str):
         cfg = pred_cfg_from_file(config)
     elif isinstance(config, PredCfg):
@@ -191,7 +209,7 @@ def init_segmentor(config, checkpoint=None, device="cuda:0", state_dict=None,
         raise ValueError("init_segmentor needs a checkpoint (or an explicit state_dict): the HIP "
                          "model has no random-init mode")
     return HipSegmentor(cfg, state_dict, device=device, classes=classes, precision=precision,
-                        fold_ppm=fold_ppm, conv_algo=conv_algo)
+                        fold_ppm=fold_ppm, conv_algo=conv_algo, options=options)
 
 
 def run_inference(model: HipSegmentor, full_map: np.ndarray) -> List[np.ndarray]:
@@ -212,7 +230,8 @@ class PEANUT_Prediction_Model():
     checkpoint file (seeded weights for tests/benchmarks)."""
 
     def __init__(self, args, state_dict=None, cfg: Optional[PredCfg] = None, precision: Optional[str] = None,
-                 fold_ppm: Optional[bool] = None, conv_algo: Optional[str] = None):
+                 fold_ppm: Optional[bool] = None, conv_algo: Optional[str] = None,
+                 options: Optional[Dict[str, int]] = None):
         self.args = args
         ckpt = getattr(args, "pred_model_wts", None) if state_dict is None else None
         if cfg is None:
@@ -233,9 +252,9 @@ class PEANUT_Prediction_Model():
         if precision == "auto":
             precision = "fp16x3"
             self._escalate = dict(config=cfg, checkpoint=ckpt, device=device, state_dict=state_dict, precision="bf16x6",
-                                  fold_ppm=fold_ppm, conv_algo=conv_algo)
+                                  fold_ppm=fold_ppm, conv_algo=conv_algo, options=options)
         self.model = init_segmentor(cfg, checkpoint=ckpt, device=device, state_dict=state_dict,
-                                    precision=precision, fold_ppm=fold_ppm, conv_algo=conv_algo)
+                                    precision=precision, fold_ppm=fold_ppm, conv_algo=conv_algo, options=options)
         self.model.eval()
         self.model.cfg = cfg
 

@@ -87,6 +87,7 @@ def test_bench_spawns_its_own_ranks_or_refuses():
     assert "allgather_maps_ms" in line
 
 
+@pytest.mark.slow
 def test_bench_line_carries_the_contract_fields():
     """The ONE JSON line of bench.py (small shape, short run): the driver's fields, the roofline object with the HBM-bound
     families reported against bandwidth, a cpu_baseline object (bounded sample), and every requested mode with its own

@@ -189,6 +189,7 @@ def test_fp16x3_range_violation_raises(golden_dir):
     assert np.isfinite(m6.get_prediction(big)).all()
 
 
+@pytest.mark.slow
 def test_precision_auto_escalates_to_bf16x6(golden_dir):
     """precision='auto' = fp16x3 until an activation leaves fp16's range, then (announced) bf16x6 for good: the call that
     trips it already returns the bf16x6 result."""
@@ -326,18 +327,17 @@ def test_b4_480_forward_matches_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("tile", [5, 6])
-def test_forced_winograd_forms_match_reference_goldens(golden_dir, tile, monkeypatch):
+def test_forced_winograd_forms_match_reference_goldens(golden_dir, tile):
     """The planner picks a Winograd form per shape, and the small golden cases end up on F(4x4) (a position's few tiles pad
-    to one GEMM tile either way).  PEANUT_WINO_M = 5 / 6 (read at upload time) forces F(5x5) / F(6x6) on EVERY Winograd
+    to one GEMM tile either way).  The create-time option wino_m = 5 / 6 (csrc/options.h) forces F(5x5) / F(6x6) on EVERY Winograd
     layer -- PSP bottleneck included -- so that each form is also held against logits produced by the reference's own
     files, not only against the oracle at ten 480 x 480 maps: same tolerance (5e-5 asserted; the two-level accumulation
     of the position GEMMs is what keeps the larger tiles there, csrc/net_common.h: wino_flush_channels)."""
     from peanut_amd.prediction import PEANUT_Prediction_Model
     from peanut_amd.weights import PredCfg, make_seeded_state_dict
-    monkeypatch.setenv("PEANUT_WINO_M", str(tile))
     cfg = PredCfg()
     sd = make_seeded_state_dict(cfg, 0)
-    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, options={"wino_m": tile})
     z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
     worst = 0.0
     for case in ("cfg1_240", "b2_96", "odd_100", "rect_72x104"):
@@ -410,6 +410,7 @@ def test_bf16x6_emulation_is_fp32_class(model_and_sd, golden_dir):
     assert worst6 <= 5e-5 and worst6 <= 3 * worst32
 
 
+@pytest.mark.slow
 def test_full_size_batch_properties(model_and_sd):
     """BASELINE.json config 2 at full size (B = 32, 480x480x14), where the oracle is too slow to run: properties that
     do not need it.  (a) a map's output depends only on that map: changing every other map of the batch leaves it
@@ -443,6 +444,7 @@ def test_full_size_batch_properties(model_and_sd):
     assert (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
 
 
+@pytest.mark.slow
 def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
     """Ten 480 x 480 maps against the ORACLE, at a size where every layer of the headline benchmark that runs on a
     large-tile kernel does so here too (36 000 rows: conv_pw_uses_256 needs M * cout >= 8.39 M, gemm_rs_uses_256 16.8 M) --
@@ -495,6 +497,74 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
             assert hit, f"{precision}: {layer} did not run on {family}: {[(n, k) for n, k in ops.items() if n.endswith(layer)]}"
         if mm is not m:
             del mm
+
+
+@pytest.mark.slow
+def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
+    """Sixteen 480 x 480 maps against the ORACLE at a size where the round-4 kernels carry the layers they carry in the
+    headline benchmark -- asserted by kernel family per op: the persistent A-resident kernel (csrc/conv_pw_ares.hip) runs
+    layer2 / layer3 conv3 and the position GEMMs of their Winograd conv2 (57 600 rows = 450 whole 128-row tiles), the
+    256 x 256 kernel (csrc/conv_pw.hip) layer4.0's conv3 + downsample (1 800 tiles).  Then the same maps through a handle
+    with both kernels switched off by option (csrc/options.h): the families sum in the same k order (bit-identical at
+    operator level, tests/test_conv_gpu.py), but the tile-per-workgroup kernels cut the k range of their LAST round's tiles
+    (tail split-K) and which tiles those are depends on the tile size -- so the two handles agree to rounding, not to the
+    bit -- and the options of one handle must not leak into the other."""
+    from bench import synth_maps
+    from oracle import pspnet_ref
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    x = synth_maps(16, cfg.in_channels, 480, torch.device("cpu"), seed0=1616)
+    with torch.no_grad():
+        ref = pspnet_ref.forward_batch(sd, x, cfg)
+    xd = x.cuda()
+    got = m.get_prediction_batch(xd, apply_sigmoid=False)
+    err = (got.cpu() - ref).abs().max().item()
+    ops = {name: kern for name, kern, *_ in m.model.profile(xd)}
+    print(f"fp32: B=16 480x480 vs oracle max-abs {err:.3e}; "
+          f"{sum(k == 'conv_pw_ares_128x128' for k in ops.values())} ops on conv_pw_ares_128x128, "
+          f"{sum(k == 'conv_pw_glds_256x256' for k in ops.values())} on conv_pw_glds_256x256")
+    assert err <= TOL
+    want = {"conv_pw_ares_128x128": ["layer2.1.conv3", "layer2.3.conv2[wino6_gemm]", "layer3.1.conv3", "layer3.5.conv3",
+                                     "layer3.2.conv2[wino6_gemm]", "layer2.0.conv1"],
+            "conv_pw_glds_256x256": ["layer4.0.conv3+downsample"],
+            "conv_pw_glds_256x128": ["layer3.1.conv1", "layer4.1.conv1", "bottleneck.conv[x][wino6_gemm]"]}
+    for family, layers in want.items():
+        for layer in layers:
+            hit = [n for n, k in ops.items() if n.endswith(layer)]
+            assert hit and all(ops[n] == family for n in hit), (layer, [(n, ops[n]) for n in hit])
+    plain = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    plain.model.set_option("pw_ares", 0)
+    plain.model.set_option("pw256w_mink", 0)
+    assert plain.model.get_option("pw_ares") == 0 and m.model.get_option("pw_ares") == 1
+    got2 = plain.get_prediction_batch(xd, apply_sigmoid=False)
+    ops2 = {name: kern for name, kern, *_ in plain.model.profile(xd)}
+    assert not any(k in ("conv_pw_ares_128x128", "conv_pw_glds_256x256") for k in ops2.values())
+    err2 = (got2.cpu() - ref).abs().max().item()
+    diff = float((got - got2).abs().max())
+    print(f"same maps with pw_ares = 0, pw256w_mink = 0: vs oracle {err2:.3e}, between the two handles {diff:.3e}")
+    assert err2 <= TOL and diff <= 3e-5
+    del plain
+
+
+def test_run_time_options_rebuild_the_plan_per_handle(model_and_sd):
+    """peanut_pred_set_option (csrc/options.h): a run-time option changes ONE handle and drops its cached launch plans --
+    the pyramid branch of the PSP head on / off the side stream (ppm_overlap), bit-identical either way; create-time options
+    are refused on a live handle."""
+    from peanut_amd import _lib
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    m, sd, cfg = model_and_sd
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand((4, cfg.in_channels, 240, 240), generator=g) > 0.7).float().cuda()
+    other = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    y0 = other.get_prediction_batch(x, apply_sigmoid=False)
+    for v in (0, 1):
+        other.model.set_option("ppm_overlap", v)
+        assert other.model.get_option("ppm_overlap") == v and m.model.get_option("ppm_overlap") == -1
+        assert torch.equal(other.get_prediction_batch(x, apply_sigmoid=False), y0)
+    with pytest.raises(_lib.PeanutHipError, match="uploaded weights"):
+        other.model.set_option("wino_head_m", 6)
+    assert torch.equal(m.get_prediction_batch(x, apply_sigmoid=False), y0)
+    del other
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x3"])

@@ -507,3 +507,23 @@ def test_input_transform_equals_pillow_resize_bit_for_bit(golden_dir):
     pil = torch.from_numpy(np.asarray(Image.fromarray(img[0].numpy()).resize((nw, nh), Image.BILINEAR)).copy())
     mean = torch.tensor(cfg.pixel_mean).view(3, 1, 1)
     assert torch.equal(net.preprocess(img.cuda()).cpu()[0, :, :nh, :nw], pil.permute(2, 0, 1).float() - mean)
+
+
+def test_fp16x3_detector_overflow_is_an_error_not_an_empty_image(small_net):
+    """The detector's front end runs its 3x3 convs as Winograd in fp16x3 too: a value past fp16's range (the transformed
+    input B^T d B is up to ~100 x the activations) makes an emulated layer's output NaN, and the selection kernels drop
+    non-finite boxes and scores -- the frame would come back WITHOUT detections.  peanut_rcnn_inference scans the RPN
+    objectness, class scores, box deltas and mask logits in that mode and fails with PEANUT_ERANGE (a FloatingPointError
+    on the Python side, like the prediction model's range check)."""
+    from rcnn_glue import GlueMaskRCNN as MaskRCNN
+    from peanut_amd import _lib
+    s = small_net
+    img = s["img"].cuda()
+    ok = MaskRCNN(s["cfg"], s["sd"], precision="fp16x3").inference(img)
+    assert len(ok) == 2 and sum(len(d["scores"]) for d in ok) > 0
+    sd = {k: v.clone() for k, v in s["sd"].items()}
+    sd["backbone.bottom_up.stem.conv1.weight"] *= 3.0e5          # activations far past 65 504 from res2 on
+    net = MaskRCNN(s["cfg"], sd, precision="fp16x3")
+    with pytest.raises(FloatingPointError, match="fp16x3") as e:
+        net.inference(img)
+    assert isinstance(e.value, _lib.PeanutRangeError)
