@@ -145,7 +145,9 @@ def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 40.0):
 
 # bench kernel family -> substring of the rocprofv3 kernel name
 FAMILY_KERNEL = {
-    "conv_pw_glds_256x128": "conv_pw_glds256_kernel",
+    "conv_pw_glds_256x128": "conv_pw_glds256_kernel(",
+    "conv_pw_glds_256x256": "conv_pw_glds256w_kernel",
+    "conv_pw_ares_128x128": "conv_pw_ares_kernel",
     "conv_pw_glds_128x128": "conv_pw_glds_kernel<128, 2, 2>",
     "conv_pw_glds_128x64": "conv_pw_glds_kernel<64, 2, 2>",
     "conv_pw_glds_128x32": "conv_pw_glds_kernel<32, 4, 1>",
@@ -265,13 +267,35 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+class HipBackend:
+    """What main() needs from the device side: the HIP device of this rank, the model factory (the product path through
+    the C ABI) and a synchronise.  tests/test_dist_cpu.py substitutes a host-side stand-in to run main()'s N > 1 control
+    flow (barriers, max-over-ranks timing, rank-0-only printing, the all-gather fallback and its exit status) under gloo."""
+    name = "hip"
+
+    def __init__(self):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def make_model(self, cfg, sd, precision):
+        from peanut_amd.prediction import PEANUT_Prediction_Model
+        return PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=self.device.index), state_dict=sd, cfg=cfg, precision=precision)
+
+    def state_dict(self, cfg):
+        return make_seeded_state_dict(cfg, seed=0)
+
+
 PRESETS = {   # SURVEY.md sec. 8d
     2: dict(size=480, channels=14, batch=32),
     5: dict(size=960, channels=25, batch=8),
 }
 
 
-def main():
+def main(argv=None, backend_factory=HipBackend):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -286,16 +310,20 @@ def main():
                                                "collect_maps.py format) used as input instead of synthetic maps")
     ap.add_argument("--precision", default=os.environ.get("PEANUT_PRECISION", "fp32"),
                     choices=sorted(PEAK_TFLOPS), help="conv arithmetic (include/peanut_hip.h PEANUT_PREC_*)")
-    ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO", "bf16x6,fp16x3,bf16x3"),
+    ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO"),
                     help="comma list of extra precision modes measured after the main run and reported under "
-                         "'modes' (empty string to skip)")
+                         "'modes' (empty string to skip); default: bf16x6,fp16x3,bf16x3 at N = 1, none at N > 1 (every rank "
+                         "would build three more models and run their steps: the scaling runs measure the headline only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-op HIP-event probe")
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
                     help="roofline.traffic: 'measure' profiles a short child run of this command with rocprofv3 PMC "
                          "counters; 'auto' = measure at N=1 when rocprofv3 is installed, else the committed file")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) here")
-    args = ap.parse_args()
+    ap.add_argument("--configs", default=os.environ.get("PEANUT_BENCH_CONFIGS", "1,3,4,5,mapping"),
+                    help="the other BASELINE.json configurations measured after the headline (N = 1 only) and reported under "
+                         "'configs', each with its own roofline and cpu_baseline (tools/configs_bench.py); empty string to skip")
+    args = ap.parse_args(argv)
     preset = PRESETS[args.config]
     for k, v in preset.items():
         if getattr(args, k) is None:
@@ -307,13 +335,13 @@ def main():
     rank, local_rank, world = pdist.init_process_group()
     if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    dev = torch.device("cuda", torch.cuda.current_device())
+    backend = backend_factory()
+    dev = backend.device
+    if args.also is None:
+        args.also = "bf16x6,fp16x3,bf16x3" if world == 1 else ""
 
-    from peanut_amd.prediction import PEANUT_Prediction_Model
     cfg = PredCfg(in_channels=args.channels)
-    sd = make_seeded_state_dict(cfg, seed=0)
+    sd = backend.state_dict(cfg)
     B, S = args.batch, args.size
     # this rank's shard of the global batch (weak scaling: B maps per GPU)
     if args.maps:
@@ -325,17 +353,16 @@ def main():
     def run_mode(precision, steps, warmup, op_table=""):
         """W untimed warm-up steps, then exactly `steps` timed steps bracketed by barrier + synchronize;
         returns (max-over-ranks seconds, roofline dict)."""
-        model = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=dev.index), state_dict=sd, cfg=cfg,
-                                        precision=precision)
+        model = backend.make_model(cfg, sd, precision)
         for _ in range(warmup):
             model.get_prediction_batch(x, apply_sigmoid=True, out=out)
-        torch.cuda.synchronize()
+        backend.synchronize()
         pdist.barrier()
-        torch.cuda.synchronize()
+        backend.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):                 # the timed region: the product path as a caller runs it, no probe
             model.get_prediction_batch(x, apply_sigmoid=True, out=out)
-        torch.cuda.synchronize()
+        backend.synchronize()
         pdist.barrier()
         elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
         roof = None
@@ -345,7 +372,7 @@ def main():
             model.model.probe_enable(True)
             for _ in range(min(steps, 10)):
                 model.get_prediction_batch(x, apply_sigmoid=True, out=out)
-            torch.cuda.synchronize()
+            backend.synchronize()
             nf, rows = model.model.probe_collect()
             model.model.probe_enable(False)
             fam = {}
@@ -421,22 +448,37 @@ def main():
             gather_path = f"torch.distributed all_gather_into_tensor (library path failed: {e})"
             gather_failed = True
             gather(out)
-        torch.cuda.synchronize()
+        backend.synchronize()
         pdist.barrier()
         tg = time.perf_counter()
         allmaps = gather(out)
-        torch.cuda.synchronize()
+        backend.synchronize()
         gather_ms = pdist.max_over_ranks((time.perf_counter() - tg) * 1e3, device=dev)
         assert allmaps.shape[0] == world * B
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and backend.name == "hip":
         cpu = cpu_baseline(cfg, sd, S)
+
+    # every other BASELINE.json configuration, at N = 1 only (they are per-GPU shares; episodes / maps shard without a collective)
+    configs = None
+    which = tuple(c for c in args.configs.split(",") if c)
+    if rank == 0 and world == 1 and which and backend.name == "hip" and args.config == 2 and not args.maps and args.batch == PRESETS[2]["batch"] and \
+            args.size == PRESETS[2]["size"]:
+        x = out = None                  # the headline's tensors are no longer needed: free them for the other configurations
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import configs_bench
+        try:
+            configs = configs_bench.measure_configs(which, dev, with_cpu=not args.no_cpu_baseline)
+        except Exception as e:     # noqa: BLE001 -- never lose the headline line over a secondary configuration
+            configs = {"error": f"{type(e).__name__}: {e}"}
+        out = torch.empty((B, cfg.num_classes, S, S), dtype=torch.float32, device=dev)
 
     if rank == 0 and roof is not None and args.traffic != "none":
         measured = None
         if world == 1 and args.traffic in ("auto", "measure"):
-            child = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-probe", "--also", "", "--traffic", "none",
+            child = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-probe", "--also", "", "--traffic", "none", "--configs", "",
                      "--config", str(args.config), "--batch", str(B), "--size", str(S), "--channels", str(cfg.in_channels),
                      "--precision", args.precision] + (["--maps", os.path.abspath(args.maps)] if args.maps else [])
             measured = measure_hbm_traffic(roof["kernel"], child)
@@ -482,10 +524,13 @@ def main():
                 m["speedup_vs_cpu_baseline"] = round(m["value"] / cpu["value"], 1)
         if modes:
             line["modes"] = modes
+        if configs is not None:
+            line["configs"] = configs
         if gather_ms is not None:
             line["allgather_maps_ms"] = round(gather_ms, 3)
             line["allgather_maps_bytes_per_rank"] = int(out.numel() * 4)
             line["allgather_maps_path"] = gather_path
+            line["rccl_ranks_seen"] = pdist.rccl_ranks_seen()       # ranks of the library's own communicator (peanut_comm_info); 0: none was built
         print(json.dumps(line), flush=True)
     pdist.barrier()
     if torch.distributed.is_initialized():

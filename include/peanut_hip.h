@@ -284,6 +284,13 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], i
 int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
                               float* const* objectness, float* const* deltas, void* stream);
 
+/* Event probe of the front end (bench.py: stage-1 roofline): runs it `reps` times on `stream` with a HIP event after every
+ * op, synchronises, and reports per op its name, the kernel family the launch picked (peanut_last_conv_kernel; "wino+..."
+ * = Winograd transforms + that GEMM), the mean milliseconds and the direct-form conv FLOPs (0 for non-conv ops).  names /
+ * kernels point to storage owned by the handle (valid until the next probe or plan change).  Returns the op count. */
+int peanut_rcnn_probe_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int reps, int max_ops,
+                            const char** names, const char** kernels, double* ms, double* flops, void* stream);
+
 /* The detector's input transform alone (DefaultPredictor.__call__: ResizeShortestEdge.get_transform(img).apply_image,
  * i.e. PIL.Image.resize(BILINEAR) for uint8 frames -- Pillow's two-pass fixed-point resample, restated bit for bit --
  * then GeneralizedRCNN.preprocess_image: (x - PIXEL_MEAN) / PIXEL_STD, zero padding to the size-divisible canvas).

@@ -101,6 +101,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_int * 10), C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "peanut_rcnn_forward_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P),
                                             C.POINTER(_P), _P]),
+    "peanut_rcnn_probe_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "peanut_rcnn_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_rcnn_inference": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "peanut_rcnn_semantic": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int32), _P,

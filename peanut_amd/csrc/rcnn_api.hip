@@ -539,10 +539,11 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw_out[2
   return 0;
 }
 
-int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
-                              float* const* objectness, float* const* deltas, void* stream) {
-  if (!h || !img_bgr) return fail(PEANUT_EINVAL, "peanut_rcnn_forward_front: null argument");
-  OptionScope option_scope(&h->opts);
+// the front end's launch sequence; with `events` (ops + 1 entries) a HIP event is recorded before the first and after every
+// op, and `families` (ops entries) receives the kernel family each conv launch really picked (peanut_last_conv_kernel)
+static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
+                           float* const* objectness, float* const* deltas, void* stream, hipEvent_t* events,
+                           std::string* families) {
   RPlan* pl = get_rplan(h, B, H, W);
   if (!pl) return PEANUT_EINVAL;
   int rc;
@@ -559,6 +560,8 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
   // outputs the caller asked for are written in place (and read from there by the ops that consume them)
   auto OUT = [&](const ROp& op) -> float* { float* e = ext(op.ext_slot); return e ? e : P(op.out); };
   auto IN = [&](const ROp& op) -> float* { float* e = ext(op.in_ext_slot); return e ? e : P(op.in); };
+  if (events) PEANUT_HIP_CHECK(hipEventRecord(events[0], s));
+  size_t op_index = 0;
   for (const auto& op : pl->ops) {
     switch (op.kind) {
       case R_PREPROCESS: {
@@ -602,10 +605,55 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
         break;
       }
     }
+    if (families) {
+      static const char* const kind_names[] = {"rcnn_preprocess", "conv", "maxpool", "fpn_add_upsampled", "subsample2"};
+      families[op_index] = op.kind == R_CONV ? std::string(op.has_wino ? "wino+" : "") + noted_kernel() : kind_names[op.kind];
+    }
+    ++op_index;
+    if (events) PEANUT_HIP_CHECK(hipEventRecord(events[op_index], s));
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_rcnn_forward_front: ") + hipGetErrorString(e));
   return 0;
+}
+
+int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
+                              float* const* objectness, float* const* deltas, void* stream) {
+  if (!h || !img_bgr) return fail(PEANUT_EINVAL, "peanut_rcnn_forward_front: null argument");
+  OptionScope option_scope(&h->opts);
+  return rcnn_front_impl(h, img_bgr, B, H, W, pyramid, objectness, deltas, stream, nullptr, nullptr);
+}
+
+int peanut_rcnn_probe_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int reps, int max_ops,
+                            const char** names, const char** kernels, double* ms, double* flops, void* stream) {
+  if (!h || !img_bgr || reps < 1) return fail(PEANUT_EINVAL, "peanut_rcnn_probe_front: bad argument");
+  OptionScope option_scope(&h->opts);
+  RPlan* pl = get_rplan(h, B, H, W);
+  if (!pl) return PEANUT_EINVAL;
+  const size_t n = pl->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) PEANUT_HIP_CHECK(hipEventCreate(&e));
+  h->probe_families.assign(n, std::string());
+  std::vector<double> sum(n, 0.0);
+  int rc = 0;
+  for (int r = 0; r < reps && !rc; ++r) {
+    if ((rc = rcnn_front_impl(h, img_bgr, B, H, W, nullptr, nullptr, nullptr, stream, ev.data(), h->probe_families.data()))) break;
+    if (hipEventSynchronize(ev[n]) != hipSuccess) { rc = fail(PEANUT_EHIP, "peanut_rcnn_probe_front: event synchronise failed"); break; }
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+      sum[i] += t;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  for (size_t i = 0; i < n && (int)i < max_ops; ++i) {
+    if (names) names[i] = pl->ops[i].name.c_str();
+    if (kernels) kernels[i] = h->probe_families[i].c_str();
+    if (ms) ms[i] = sum[i] / reps;
+    if (flops) flops[i] = pl->ops[i].flops;
+  }
+  return (int)n;
 }
 
 int peanut_rcnn_preprocess(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* out_nchw, void* stream) {

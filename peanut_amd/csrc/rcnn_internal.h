@@ -46,6 +46,7 @@ struct peanut_rcnn {
   peanut::ConvLayer *lateral[4] = {nullptr}, *output[4] = {nullptr};   // levels 2..5
   peanut::ConvLayer *rpn_conv = nullptr, *rpn_obj = nullptr, *rpn_delta = nullptr;
   std::map<std::string, std::unique_ptr<peanut::RPlan>> plans;
+  std::vector<std::string> probe_families;   // peanut_rcnn_probe_front: kernel family per op of the last probe
   peanut::DevBuf ws;
   // ROI heads (present when the state dict carries roi_heads.*): FC layers as 1x1 convs, mask head convs
   bool has_heads = false;

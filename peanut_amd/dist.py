@@ -127,6 +127,19 @@ def map_comm() -> MapComm:
     return _MAP_COMM
 
 
+def rccl_ranks_seen() -> int:
+    """Ranks of the library's own RCCL communicator as ``peanut_comm_info`` reports them (0 when none has been built in
+    this process: one rank, or a host-tensor all-gather) -- bench.py prints it so that a multi-GPU record shows how many
+    ranks ``peanut_allgather_maps`` really spanned."""
+    if _MAP_COMM is None or not getattr(_MAP_COMM, "_h", None):
+        return 0
+    import ctypes as C
+    n, r = C.c_int(0), C.c_int(0)
+    if _MAP_COMM._lib.peanut_comm_info(_MAP_COMM._h, C.byref(n), C.byref(r)) != 0:
+        return 0
+    return int(n.value)
+
+
 def close_map_comm():
     global _MAP_COMM
     if _MAP_COMM is not None:

@@ -98,6 +98,22 @@ class MaskRCNNFront:
         _lib.check(rc, "peanut_rcnn_forward_front")
         return pyr, obj, dl
 
+    def probe_front(self, img_bgr: torch.Tensor, reps: int = 3):
+        """[(op name, kernel family, mean ms, direct-form conv flops)] of the front end (``peanut_rcnn_probe_front``: HIP
+        events on the launch stream after every op) -- what bench.py's stage-1 roofline is computed from."""
+        assert img_bgr.is_cuda and img_bgr.dtype == torch.uint8 and img_bgr.dim() == 4 and img_bgr.shape[3] == 3
+        img_bgr = img_bgr.contiguous()
+        b, h, w, _ = img_bgr.shape
+        cap = 2048
+        names, kernels = (C.c_char_p * cap)(), (C.c_char_p * cap)()
+        ms, fl = (C.c_double * cap)(), (C.c_double * cap)()
+        with torch.cuda.device(img_bgr.device):
+            n = self._lib.peanut_rcnn_probe_front(self._h, img_bgr.data_ptr(), b, h, w, reps, cap, names, kernels, ms, fl,
+                                                  _lib.current_stream_ptr(img_bgr.device))
+        if n < 0:
+            _lib.check(n, "peanut_rcnn_probe_front")
+        return [(names[i].decode(), kernels[i].decode(), ms[i], fl[i]) for i in range(min(n, cap))]
+
 
 # =========================================================================================================
 # Full inference: proposal selection + ROI heads + mask pasting.

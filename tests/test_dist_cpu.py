@@ -154,3 +154,96 @@ def test_world8_gloo_map_and_episode_shards(tmp_path, n_eps):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+# ---- bench.py's own main() at N > 1, on the CPU: the product model replaced by a host-side stand-in at the point where main()
+# asks its backend for one (bench.HipBackend.make_model -> PEANUT_Prediction_Model -> the C ABI) ----
+class _StubSegmentor:
+    def probe_enable(self, on):
+        pass
+
+    def probe_collect(self):          # (forwards, [(op, kernel family, summed ms, flops, bytes)])
+        return 2, [("backbone.layer4.0.conv1", "conv_pw_glds_256x128", 2.0, 1.0e9, 1.0e6), ("upsample_logits", "upsample_logits", 0.2, 0.0, 1.0e6)]
+
+
+class _StubModel:
+    def __init__(self, rank):
+        self.rank, self.model = rank, _StubSegmentor()
+
+    def get_prediction_batch(self, x, apply_sigmoid=True, out=None):
+        out.fill_(float(self.rank))
+        return out
+
+
+def _bench_worker(rank, world, port, q, break_gather):
+    import contextlib
+    import io
+    import json
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import bench
+
+        class StubBackend:
+            name = "stub"
+            device = torch.device("cpu")
+
+            def synchronize(self):
+                pass
+
+            def make_model(self, cfg, sd, precision):
+                return _StubModel(rank)
+
+            def state_dict(self, cfg):
+                return {}
+
+        if break_gather:               # the library's all-gather entry fails: main() must fall back, finish the line and exit 4
+            real, calls = bench.pdist.allgather_maps, []
+
+            def flaky(t):
+                calls.append(1)
+                if len(calls) == 1:
+                    raise RuntimeError("simulated peanut_allgather_maps failure")
+                return real(t)
+            bench.pdist.allgather_maps = flaky
+        buf, code = io.StringIO(), 0
+        with contextlib.redirect_stdout(buf):
+            try:
+                bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "32"], backend_factory=StubBackend)
+            except SystemExit as e:
+                code = e.code if isinstance(e.code, int) else 1
+        lines = [l for l in buf.getvalue().splitlines() if l.startswith("{")]
+        q.put((rank, code, [json.loads(l) for l in lines]))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, -1, traceback.format_exc() + repr(ex)))
+
+
+@pytest.mark.parametrize("break_gather", [False, True], ids=["gather_ok", "gather_falls_back"])
+def test_bench_main_runs_its_multi_rank_control_flow_under_gloo(break_gather):
+    """bench.py's main() with WORLD_SIZE = 2 on gloo and a stand-in model: both ranks pass the barriers, the step time is the
+    max over ranks, ONLY rank 0 prints the JSON line, the line carries n_gpus = 2, weak scaling, the whole-job value, the
+    all-gather time, rccl_ranks_seen and a roofline whose traffic came from the committed file (no PMC child pass at
+    N > 1), the extra precision modes are skipped -- and when the library's all-gather entry fails, the run still prints
+    its complete line through the torch.distributed fallback but exits with status 4 on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q, break_gather)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, code, lines in res:
+        assert code == (4 if break_gather else 0), (rank, code, lines)
+    assert len(res[0][2]) == 1 and res[1][2] == [], res
+    line = res[0][2][0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["config"]["global_batch"] == 4 and line["steps"] == 3 and line["warmup"] == 1
+    assert abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"] + 1e-3
+    assert "modes" not in line and "configs" not in line and line["cpu_baseline"] is None
+    assert line["allgather_maps_ms"] >= 0 and line["allgather_maps_bytes_per_rank"] == 2 * 6 * 32 * 32 * 4
+    assert line["rccl_ranks_seen"] == 0                      # host tensors: the library's RCCL communicator was not built
+    assert ("failed" in line["allgather_maps_path"]) == break_gather
+    roof = line["roofline"]
+    assert roof["kernel"] == "conv_pw_glds_256x128" and roof["bound"] == "mfma" and "traffic" in roof

@@ -42,21 +42,14 @@ def synth_episode(seed, n_frames, dev):
     return frames
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--episodes", type=int, default=8)
-    ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--precision", default="fp32")
-    ap.add_argument("--detector", action="store_true", help="run Mask R-CNN on every frame instead of canned masks")
-    ap.add_argument("--no-goal", action="store_true", help="skip the long-term goal selection (round-1 behaviour of this tool)")
-    a = ap.parse_args()
-    rank, local_rank, world = pdist.init_process_group()
-    dev = torch.device("cuda", torch.cuda.current_device())
+def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, dev=None, rank=0, world=1):
+    """The timed loop; returns the result dict on every rank (rank 0's is the one to print)."""
+    dev = dev or torch.device("cuda", torch.cuda.current_device())
     from peanut_amd.agent_state import default_args   # nav/arguments.py defaults
-    args = default_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=a.precision, select_goal=not a.no_goal)
+    args = default_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=precision, select_goal=goal)
     st = Agent_State(args, state_dict=make_seeded_state_dict(PredCfg(), 0))
     goal_ms, goal_n, goal_rounds = [0.0], [0], [0]
-    if not a.no_goal:      # time the goal selection separately (it synchronises anyway: the goal cell goes to the host)
+    if goal:      # time the goal selection separately (it synchronises anyway: the goal cell goes to the host)
         inner = st.update_global_goal
 
         def timed():
@@ -67,14 +60,14 @@ def main():
             goal_n[0] += 1
             goal_rounds[0] += st.goal_rounds
         st.update_global_goal = timed
-    mine = episode_shard(a.episodes)
-    eps = {e: synth_episode(1000 + e, a.frames, dev) for e in mine}
+    mine = episode_shard(episodes)
+    eps = {e: synth_episode(1000 + e, frames, dev) for e in mine}
     det = None
-    if a.detector:
+    if detector:
         from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
         from peanut_amd.segmentation import HipDetector
         rcfg = RcnnCfg(score_thresh_test=0.5)
-        det = HipDetector(rcfg, make_seeded_rcnn_state_dict(rcfg, 0), device=dev, precision=a.precision)
+        det = HipDetector(rcfg, make_seeded_rcnn_state_dict(rcfg, 0), device=dev, precision=precision)
         for fr in (f for e in mine for f in eps[e]):
             for k in ("masks", "classes", "scores"):
                 fr.pop(k)
@@ -90,16 +83,30 @@ def main():
     torch.cuda.synchronize()
     pdist.barrier()
     dt = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    steps = episodes * frames
+    seg = "Mask R-CNN R-101-FPN inference + mask accumulation" if detector else "seg-accumulate (canned instance masks)"
+    gtxt = " + long-term goal selection (geodesic field on the 960x960 map)" if goal else ""
+    return {"workload": f"config 4: {episodes} synthetic episodes x {frames} frames, {seg} + "
+                        f"obs formatting + map projection per step, 720x720 map prediction{gtxt} every 10 steps",
+            "n_gpus": world, "steps_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "predictions_rank0": n_pred, "precision": precision,
+            "goal_selection_ms_per_call": round(goal_ms[0] / goal_n[0], 3) if goal_n[0] else None,
+            "goal_selection_rounds_per_call": round(goal_rounds[0] / goal_n[0], 1) if goal_n[0] else None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--episodes", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--detector", action="store_true", help="run Mask R-CNN on every frame instead of canned masks")
+    ap.add_argument("--no-goal", action="store_true", help="skip the long-term goal selection (round-1 behaviour of this tool)")
+    a = ap.parse_args()
+    rank, local_rank, world = pdist.init_process_group()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res = run_pipeline(a.episodes, a.frames, a.precision, a.detector, not a.no_goal, dev, rank, world)
     if rank == 0:
-        steps = a.episodes * a.frames
-        seg = "Mask R-CNN R-101-FPN inference + mask accumulation" if a.detector else "seg-accumulate (canned instance masks)"
-        goal = "" if a.no_goal else " + long-term goal selection (geodesic field on the 960x960 map)"
-        print(json.dumps({"workload": f"config 4: {a.episodes} synthetic episodes x {a.frames} frames, {seg} + "
-                                      f"obs formatting + map projection per step, 720x720 map prediction{goal} every 10 steps",
-                          "n_gpus": world, "steps_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-                          "predictions_rank0": n_pred, "precision": a.precision,
-                          "goal_selection_ms_per_call": round(goal_ms[0] / goal_n[0], 3) if goal_n[0] else None,
-                          "goal_selection_rounds_per_call": round(goal_rounds[0] / goal_n[0], 1) if goal_n[0] else None}))
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":
