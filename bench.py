@@ -183,6 +183,14 @@ def _pmc_pass(counter: str, child_args, timeout_s: float, want=None):
             return None
         agg = {}
         cur = sqlite3.connect(dbs[0]).cursor()
+        if want is not None:      # kernel durations of the same pass (ns): the effective clock is GRBM_GUI_ACTIVE / 8 / duration
+            try:
+                for kname, dur in cur.execute("select name, duration from kernels"):
+                    a = agg.setdefault((kname, "__duration_ns"), [0, 0.0])
+                    a[0] += 1
+                    a[1] += dur
+            except sqlite3.Error:
+                pass
         for kname, cname, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
             if want is not None:
                 if cname in want:
@@ -229,6 +237,10 @@ def measure_hbm_traffic(family: str, child_args, timeout_s: float = 150.0):
             busy = {"mfma_busy": round(mf / (ga / 8.0 * 1024.0), 4), "mfma_busy_dispatches": nd,
                     "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), third PMC child pass "
                                         "(MFMA utilisation in cycles: independent of the clock the governor picks)"}
+            dur_ns = sum(a[1] for (k, c), a in both.items() if pat in k and c == "__duration_ns")
+            if dur_ns > 0:      # what the power / clock governor left of the 2.4 GHz nameplate while this kernel ran
+                busy["effective_clock_ghz"] = round(ga / 8.0 / dur_ns, 3)
+                busy["effective_clock_source"] = "GRBM_GUI_ACTIVE / 8 / kernel duration of the same (profiled) pass"
     return {**busy, "traffic": round((2.0 * fetch_kib + write_kib) * 1024.0),
             "traffic_fetch_kib_raw": round(fetch_kib, 1), "traffic_write_kib": round(write_kib, 1),
             "traffic_dispatches": res["FETCH_SIZE"][0],
@@ -423,6 +435,15 @@ def main(argv=None, backend_factory=HipBackend):
     for extra in [m for m in args.also.split(",") if m and m != args.precision]:
         st = max(3, args.steps // 2)
         e_s, e_roof = run_mode(extra, st, 2)
+        if rank == 0 and world == 1 and e_roof is not None and args.traffic in ("auto", "measure") and not args.maps:
+            # the same three PMC child passes as for the headline: HBM traffic, matrix-pipe busy share and effective clock of
+            # this mode's dominant kernel
+            child = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-probe", "--also", "", "--traffic", "none", "--configs", "",
+                     "--config", str(args.config), "--batch", str(B), "--size", str(S), "--channels", str(cfg.in_channels),
+                     "--precision", extra]
+            got = measure_hbm_traffic(e_roof["kernel"], child)
+            if got:
+                e_roof.update(got)
         modes[extra] = {"value": round(world * B * st / e_s, 3), "unit": "maps/s", "ms_per_step": round(e_s / st * 1e3, 3),
                         "dtype": DTYPE[extra], "steps": st, "roofline": e_roof,
                         "note": MODE_NOTES.get(extra, "")}

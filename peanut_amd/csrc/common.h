@@ -79,6 +79,8 @@ bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
 int conv_pw_256_min_k();
 // conv_pw.hip: ... on the 256 x 256 two-stage kernel (flush_ktiles: k-tiles per partial sum of the two-level accumulation, 0 = none)
 bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
+// conv_pw256p.hip: ... on the persistent 256 x 128 kernel (epilogue of the previous tile inside the next tile's k-loop)
+bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
 // conv_pw_ares.hip: ... on the persistent A-resident kernel (K = 128 / 256)
 bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_source, int flush_ktiles, int bn_tile);
 

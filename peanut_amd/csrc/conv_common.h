@@ -69,6 +69,8 @@ bool conv_pw_enabled();
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream);
 // conv_pw_ares.hip: persistent A-resident kernel for the K = 128 / 256 pointwise layers and grouped GEMMs
 int launch_conv_pw_ares(const ConvKParams& p, int bn_tile, hipStream_t stream);
+// conv_pw256p.hip: persistent 256 x 128 kernel (p.ntiles = 128-wide n-tiles)
+int launch_conv_pw256p(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream);
 // gemm_rs.hip: pointwise layer / grouped GEMM emulated on the bf16 matrix cores: fp32 A (p.x, p.x2) split into bf16 pieces in
 // registers, p.w = the weights' pre-split pieces, nkt = cin / 16
 int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);

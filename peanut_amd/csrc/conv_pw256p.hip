@@ -1,0 +1,405 @@
+// conv_pw_glds256p_kernel: the 256 x 128 three-stage LDS-DMA GEMM of conv_pw.hip as a PERSISTENT kernel.
+//
+// conv_pw_glds256_kernel runs one tile per workgroup, one workgroup per CU: every tile pays a pipeline fill (two k-tiles
+// requested, nothing to compute until the first has landed) and an epilogue under which nothing computes -- 2.4 % of the
+// family's time at K >= 1024 (profiles/r4d), ~15 % at K = 512, which is why the K = 512 layers had to stay on the two-stage
+// 128 x 128 kernel at 121 TF/s.  Here one workgroup per CU walks a list of work items (whole tiles, then its share of the
+// tail's split-K parts -- the same plan as launch_with_tail_split):
+//   * the three-stage ring runs ACROSS item boundaries: the first two k-tiles of the next item are requested during the last
+//     two iterations of the current one -- no fill;
+//   * the epilogue of item i runs inside the first eight iterations of item i + 1, from registers: the finished accumulators
+//     are copied to a second set, each of those iterations loads the residual of eight of them at its top (asm loads hipcc
+//     does not count, waited by the iteration's own `s_waitcnt vmcnt(6)`: they are older than the LDS-DMA requests), and
+//     after the MFMAs applies scale / shift / residual / ReLU and stores them.  A lane's values are rows x one column; a wave
+//     instruction covers two rows x 32 consecutive channels = two whole 128-byte lines;
+//   * the two waves of a SIMD request their LDS-DMA pieces half an iteration apart (conv_pw_glds256_kernel).
+// Same MFMA fragment layout and k order as the other fp32 kernels: bit-identical results (one running sum: the Winograd
+// position GEMMs with their two-level accumulation keep conv_pw_glds256_kernel).
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_common.h"
+
+namespace peanut {
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// A global load hipcc does not count (see conv_pw_ares.hip / tools/audit_uncounted_loads.py): wave-uniform base in SGPRs +
+// a 32-bit lane offset.  The leading s_nop covers the case that hipcc materialised the base through v_readfirstlane right
+// before the statement (VALU-written SGPR read by a VMEM instruction: 5 wait states hipcc does not pad inside an asm).
+__device__ __forceinline__ float p_load_uncounted(const float* base, unsigned byte_off) {
+  float v;
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+  return v;
+}
+// the iteration's wait: all but the `N` youngest vector-memory operations of this wave have completed (N = 6: the LDS-DMA
+// pieces requested this iteration stay in flight; N = 0 at the end of the stream).  Names every uncounted destination as an
+// input so that their registers stay allocated until the data has landed.
+template <int N>
+__device__ __forceinline__ void p_wait(const float (&r)[8], float a, float b, float c, float d) {
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (N == 6)
+    asm volatile("s_waitcnt vmcnt(6)" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(a), "v"(b),
+                 "v"(c), "v"(d)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(a), "v"(b),
+                 "v"(c), "v"(d)
+                 : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+struct PItem { int mt, nt, kt0, kt1, part; };   // part >= 0: split-K part -> partial tile #part
+
+__global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams p) {
+  constexpr int BM = 256, BN = 128, BK = 32, WN = 2;
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;   // 48 KiB
+  constexpr int A_INSTR = 4, B_INSTR = 2;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 3, lp = lane & 7;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, hi = lane >> 5;
+  const bool late = p.phase_shift && wave >= 4;
+
+  // ---- this workgroup's items: nf whole tiles (a contiguous run of the tile order), then its share of the split parts ----
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int lw = (bid & 7) * (G >> 3) + (bid >> 3);                    // neighbouring runs on one XCD (G is a multiple of 8)
+  const int nf = p.n_full / G;                                         // the launcher makes n_full a multiple of G
+  const int sp0 = (int)((long long)p.n_sp * lw / G), sp1 = (int)((long long)p.n_sp * (lw + 1) / G);
+  const int n_items = nf + (sp1 - sp0);
+  if (n_items == 0) return;
+  auto item_at = [&](int i) {
+    PItem it;
+    int tile;
+    if (i < nf) {
+      tile = lw * nf + i;
+      it.kt0 = 0; it.kt1 = p.nkt; it.part = -1;
+    } else {
+      const int s = sp0 + (i - nf);
+      const int j = s / p.split_p, part = s - j * p.split_p;
+      tile = p.n_full + j;
+      it.part = s;
+      it.kt0 = (int)((long long)part * p.nkt / p.split_p);
+      it.kt1 = (int)((long long)(part + 1) * p.nkt / p.split_p);
+    }
+    tile_to_mn(p, tile, &it.mt, &it.nt);
+    return it;
+  };
+
+  // ---- the request cursor: runs two k-tiles ahead of the compute cursor, across item boundaries.  Per lane it holds only
+  // the pixel index of its four A rows; everything else is a lane constant or wave-uniform.  A piece's address is
+  //   source base (uniform) + pixel * channels * 4 + k-tile offset (uniform) + chunk constant.
+  // The launcher guarantees every tensor is smaller than 4 GiB (32-bit byte offsets).
+  unsigned a_pix[A_INSTR], a_chunk[A_INSTR], b_off[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int r = (wave * A_INSTR + j) * 8 + lr;
+    a_chunk[j] = (unsigned)((lp ^ ((r >> 1) & 7)) * 16);
+    a_pix[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    const int r = (wave * B_INSTR + j) * 8 + lr;
+    b_off[j] = (unsigned)(r * BK * 4 + (lp ^ ((r >> 1) & 7)) * 16);
+  }
+  int d_item = 0, d_left = 0, d_kt = 0;      // item of the cursor, its k-tiles not requested yet, the next k-tile (absolute)
+  const float* d_wtile = p.w;                // weights of (n-tile of the cursor's item, k-tile 0)
+  auto cursor_open = [&](int i) {
+    const PItem it = item_at(i);
+    const int m0 = it.mt * BM;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int m = m0 + (wave * A_INSTR + j) * 8 + lr;           // < M: the gate admits whole 256-row tiles only
+      const int b = m / p.HoWo;
+      const int rem = m - b * p.HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_pix[j] = (unsigned)(b * p.H * p.W + oy * p.stride * p.W + ox * p.stride);
+    }
+    d_wtile = p.w + (size_t)it.nt * p.nkt * (BN * BK);
+    d_kt = it.kt0;
+    d_left = it.kt1 - it.kt0;
+  };
+  const int k1 = p.c1 / BK;
+  // The cursor's next k-tile into `stage`.  Once the stream has ended (d_left == 0: the last two iterations of the
+  // workgroup) the last k-tile is requested AGAIN, into a stage nobody reads any more: every iteration then issues exactly
+  // six LDS-DMA pieces, and its wait is one unconditional `s_waitcnt vmcnt(6)` -- no second wait arm for hipcc to merge.
+  auto request = [&](float* stage) {
+    const bool live = d_left > 0;
+    if (!live) --d_kt;
+    const bool second = d_kt >= k1;                               // two sources: k-tiles [0, k1) from x, the rest from x2
+    const char* abase = reinterpret_cast<const char*>(second ? p.x2 : p.x) + (size_t)(second ? d_kt - k1 : d_kt) * (BK * 4);
+    const unsigned cbytes = (unsigned)(second ? p.c2 : p.c1) * 4u;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(abase + (a_pix[j] * cbytes + a_chunk[j])), (lptr_t)(stage + (wave * A_INSTR + j) * 256), 16, 0, 0);
+    const char* bbase = reinterpret_cast<const char*>(d_wtile + (size_t)d_kt * (BN * BK));
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(bbase + b_off[j]), (lptr_t)(stage + A_FLOATS + (wave * B_INSTR + j) * 256), 16, 0, 0);
+    ++d_kt;
+    if (live) --d_left;
+  };
+  // after an iteration's wait: if the cursor's item is exhausted, open the next one (pixel indices: four integer divisions
+  // per lane -- kept OUT of the stretch between the uncounted loads and their wait)
+  auto cursor_advance = [&]() {
+    if (d_left == 0 && d_item + 1 < n_items) {
+      ++d_item;
+      cursor_open(d_item);
+    }
+  };
+
+  // ---- MFMA fragment coordinates ----
+  const int swz = (li >> 1) & 7;
+  int sw[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) sw[ks] = ((ks * 2 + hi) ^ swz) * 4;
+  const int a_row = (wm * 64 + li) * BK;
+  const int b_row = A_FLOATS + (wn * 64 + li) * BK;
+
+  f32x16 acc[2][2], prev[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[t][u][r] = 0.f; prev[t][u][r] = 0.f; }
+
+  // ---- epilogue state of the PREVIOUS item.  Chunk c (0..7) = accumulator block (t, u) = (c >> 2, (c >> 1) & 1), registers
+  // r = (c & 1) * 8 .. + 7: rows t*32 + (r & 3) + 8 * (r >> 2) (+ wm*64 + 4*hi), column u*32 + li (+ wn*64).  Bases are
+  // wave-uniform, the lane contributes a constant byte offset; whole tiles only (the gate), so no bounds are checked.
+  const int cout = p.cout;
+  bool prev_valid = false, prev_raw = false;
+  const float* prev_res = p.zeros;        // uniform: residual of the previous item's tile (or the zero page, stride 0)
+  float* prev_out = p.y;                  // uniform: its output tile (or its raw partial tile)
+  const float* prev_ss = p.scale;         // uniform: scale of its first column
+  unsigned prev_rs = 0;                   // bytes between rows of the residual (0: zero page)
+  unsigned prev_os = (unsigned)cout * 4;  // bytes between rows of the output
+  const unsigned lane_row = (unsigned)(wm * 64 + 4 * hi), lane_col = (unsigned)(wn * 64 + li);
+  const unsigned ss_lane = lane_col * 4;
+  const unsigned shift_delta = (unsigned)((p.shift - p.scale) * 4);
+  float sc0 = 1.f, sc1 = 1.f, sh0 = 0.f, sh1 = 0.f;
+  const bool has_res = p.res != nullptr;
+  const float alpha = p.alpha;
+  const bool relu = p.relu != 0;
+
+#define P256_EPI_LOADS(c)                                                                                         \
+  float resv[8];                                                                                                  \
+  {                                                                                                               \
+    if ((c) == 0) {                                                                                               \
+      sc0 = p_load_uncounted(prev_ss, ss_lane);                                                                   \
+      sc1 = p_load_uncounted(prev_ss, ss_lane + 128);                                                             \
+      sh0 = p_load_uncounted(prev_ss, ss_lane + shift_delta);                                                     \
+      sh1 = p_load_uncounted(prev_ss, ss_lane + shift_delta + 128);                                               \
+    }                                                                                                             \
+    const unsigned lane_off = (lane_row * prev_rs) + (prev_rs ? lane_col * 4 : 0);                                \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+      const int r = ((c) & 1) * 8 + i, row = ((c) >> 2) * 32 + (r & 3) + 8 * (r >> 2);                            \
+      resv[i] = p_load_uncounted(prev_res, lane_off + (unsigned)row * prev_rs + (prev_rs ? (((c) >> 1) & 1) * 128u : 0u)); \
+    }                                                                                                             \
+  }
+#define P256_EPI_FINISH(c)                                                                                        \
+  if (prev_valid) {                                                                                               \
+    const float scv = (((c) >> 1) & 1) ? sc1 : sc0, shv = (((c) >> 1) & 1) ? sh1 : sh0;                           \
+    char* const obase = reinterpret_cast<char*>(prev_out) + (lane_row * prev_os + lane_col * 4 + (((c) >> 1) & 1) * 128u); \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+      const int r = ((c) & 1) * 8 + i, row = ((c) >> 2) * 32 + (r & 3) + 8 * (r >> 2);                            \
+      float v = prev[(c) >> 2][((c) >> 1) & 1][r];                                                                \
+      if (!prev_raw) {                                                                                            \
+        v = v * (scv * alpha) + shv;                                                                              \
+        v += resv[i];                                                                                             \
+        if (relu) v = relu_keep_nan(v);                                                                           \
+      }                                                                                                           \
+      *reinterpret_cast<float*>(obase + (unsigned)row * prev_os) = v;                                             \
+    }                                                                                                             \
+  }
+
+  // ---- prologue: two k-tiles in flight ----
+  cursor_open(0);
+  request(smem);
+  cursor_advance();
+  request(smem + STAGE);
+  cursor_advance();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int o_cur = 0, o_mid = STAGE, o_fill = 2 * STAGE;
+
+#define P256_MFMA_PAIR()                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                       \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                     \
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+#define P256_READ_PAIR(g)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                    \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) af[j][t] = *reinterpret_cast<const f32x4*>(cur + a_row + t * 32 * BK + sw[(g) + j]); \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) bf[j][u] = *reinterpret_cast<const f32x4*>(cur + b_row + u * 32 * BK + sw[(g) + j]); \
+  }
+  // one k-tile; the caller defines P256_EPI_LOADS_IF / P256_EPI_FINISH_IF / P256_RESV for the epilogue chunk it carries
+#define P256_ITERATION()                                                                                  \
+  {                                                                                                       \
+    const float* const cur = smem + o_cur;                                                                \
+    float* const fill = smem + o_fill;                                                                    \
+    float resv_none[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                        \
+    (void)resv_none;                                                                                      \
+    P256_EPI_LOADS_IF                                                                                     \
+    if (!late) request(fill);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    f32x4 af[2][2], bf[2][2];                                                                             \
+    P256_READ_PAIR(0);                                                                                    \
+    P256_MFMA_PAIR();                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    if (late) request(fill);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    P256_READ_PAIR(2);                                                                                    \
+    P256_MFMA_PAIR();                                                                                     \
+    p_wait<6>(P256_RESV, sc0, sc1, sh0, sh1);                                                             \
+    P256_EPI_FINISH_IF                                                                                    \
+    cursor_advance();                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    asm volatile("" ::: "memory");                                                                        \
+    { const int tmp = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = tmp; }                               \
+  }
+
+  for (int ci = 0; ci < n_items; ++ci) {
+    const PItem it = item_at(ci);
+    const int nk = it.kt1 - it.kt0;
+    // the first eight iterations carry the previous item's epilogue (chunk = iteration)
+    static_for<8>([&](auto kc) {
+      constexpr int c = decltype(kc)::value;
+      if (c < nk) {
+#define P256_EPI_LOADS_IF P256_EPI_LOADS(c)
+#define P256_EPI_FINISH_IF P256_EPI_FINISH(c)
+#define P256_RESV resv
+        P256_ITERATION()
+#undef P256_EPI_LOADS_IF
+#undef P256_EPI_FINISH_IF
+#undef P256_RESV
+      }
+    });
+    for (int kt = 8; kt < nk; ++kt) {
+#define P256_EPI_LOADS_IF
+#define P256_EPI_FINISH_IF
+#define P256_RESV resv_none
+      P256_ITERATION()
+#undef P256_EPI_LOADS_IF
+#undef P256_EPI_FINISH_IF
+#undef P256_RESV
+    }
+    // an item shorter than eight k-tiles (a split part): the rest of the previous epilogue, with nothing under it
+    if (nk < 8 && prev_valid) {
+      static_for<8>([&](auto kc) {
+        constexpr int c = decltype(kc)::value;
+        if (c >= nk) {
+          P256_EPI_LOADS(c)
+          p_wait<0>(resv, sc0, sc1, sh0, sh1);
+          P256_EPI_FINISH(c)
+        }
+      });
+    }
+    // the item's accumulators become the "previous" set
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        prev[t][u] = acc[t][u];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+      }
+    {
+      const size_t tile_el = (size_t)it.mt * BM * cout + (size_t)it.nt * BN;
+      prev_valid = true;
+      prev_raw = it.part >= 0;
+      if (prev_raw) {
+        prev_out = p.partial + (size_t)it.part * (BM * BN);
+        prev_os = BN * 4;
+        prev_res = p.zeros;
+        prev_rs = 0;
+      } else {
+        prev_out = p.y + tile_el;
+        prev_os = (unsigned)cout * 4;
+        prev_res = has_res ? p.res + tile_el : p.zeros;
+        prev_rs = has_res ? (unsigned)cout * 4 : 0;
+      }
+      prev_ss = p.scale + it.nt * BN;
+    }
+  }
+  // ---- drain: the last item's epilogue ----
+  static_for<8>([&](auto kc) {
+    constexpr int c = decltype(kc)::value;
+    P256_EPI_LOADS(c)
+    p_wait<0>(resv, sc0, sc1, sh0, sh1);
+    P256_EPI_FINISH(c)
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeated requests of the stream's end
+#undef P256_ITERATION
+#undef P256_READ_PAIR
+#undef P256_MFMA_PAIR
+#undef P256_EPI_LOADS
+#undef P256_EPI_FINISH
+}
+
+}  // namespace
+
+// Which pointwise layers take the persistent 256 x 128 kernel: one running sum (no two-level accumulation), no weight
+// groups, whole 128-wide packed n-tiles, at least pw256p_mink input channels (8 k-tiles: the previous item's epilogue is spread
+// over the first eight iterations of the next) and at least pw256p_mintiles tiles.
+bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles) {
+  const int min_k = (int)opt(OPT_PW256P_MINK);
+  if (min_k <= 0 || bn_tile != 128 || mt_per_group != 0 || flush_ktiles != 0 || cin < min_k || cin < 256) return false;
+  if (M % 256 != 0 || cout % 128 != 0) return false;                       // whole tiles: the register epilogue checks no bounds
+  if (M * (long long)cin * 4 >= (1LL << 32) || M * (long long)cout * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets
+  return (M / 256) * (cout / 128) >= opt(OPT_PW256P_MINTILES);
+}
+
+int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipStream_t stream) {
+  ConvKParams p = p0;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+    return fail(-3, "conv_pw256p: no current device");
+  const int mtiles = (p.M + 255) / 256;
+  const int T = mtiles * p.ntiles;
+  int G = T < cus ? T : cus;
+  G -= G % 8;
+  if (G < 8) return fail(-2, "conv_pw256p: launch too small");
+  // Every workgroup gets the same number of whole tiles (n_full / G); the T mod G tiles left over are cut into split_p
+  // k-ranges each (raw partial tiles + the ordered reduce, as in launch_with_tail_split) and dealt out evenly.  split_p
+  // minimises the busiest workgroup's extra work: ceil(t * p / G) parts of nkt / p k-tiles plus ~1.5 k-tile times per part (raw
+  // store, cursor switch); parts keep at least four k-tiles, preferably eight (the previous epilogue rides on eight iterations).
+  const int t = T % G;
+  int sp = 1;
+  if (t > 0) {
+    double best = 1e30;
+    for (int cand = 1; cand <= 16 && p.nkt / cand >= 4; ++cand) {
+      if (ws == nullptr || (size_t)t * cand * 256 * 128 > ws_floats) break;
+      const double parts = (double)(((long long)t * cand + G - 1) / G);
+      const double cost = parts * ((double)p.nkt / cand + 1.5 + (p.nkt / cand < 8 ? 2.0 : 0.0));
+      if (cost < best - 1e-9) { best = cost; sp = cand; }
+    }
+  }
+  p.split_p = sp;
+  p.n_sp = t * sp;
+  p.n_full = T - t;
+  if (p.n_sp > 0 && (!ws || (size_t)p.n_sp * 256 * 128 > ws_floats)) return fail(-2, "conv_pw256p: split-K scratch too small");
+  p.partial = ws;
+  p.mtiles = mtiles;
+  p.nchunk = (int)opt(OPT_NCHUNK);
+  p.phase_shift = opt(OPT_PW256_PHASE) != 0;
+  note_kernel("conv_pw_glds_256x128p");
+  hipLaunchKernelGGL(conv_pw_glds256p_kernel, dim3((unsigned)G), dim3(512), 0, stream, p);
+  if (p.n_sp > 0)
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<256, 128>), dim3((unsigned)(T % G), 256 / 16), dim3(256), 0, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-3, std::string("conv_pw256p launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace peanut

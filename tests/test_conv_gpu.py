@@ -218,6 +218,60 @@ def test_pw_ares_kernel_grouped_winograd_gemm(case):
     assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
 
+P256P_CASES = [
+    # (B, H, W, cin, cout, stride, relu, residual): csrc/conv_pw256p.hip conv_pw_uses_256p -- whole 256 x 128 tiles, >= 256 input
+    # channels, one running sum; the tile gate is lowered for these handles (option pw256p_mintiles)
+    (8, 64, 64, 512, 2048, 1, True, True),       # layer4 conv3 class: 2048 tiles, eight per workgroup, residual + ReLU
+    (9, 64, 64, 1024, 256, 1, True, False),      # layer3 conv1 class: 288 tiles over 256 CUs -> one whole tile each + 32 tail tiles in split parts
+    (8, 64, 64, 256, 1024, 1, False, True),      # K = 256: exactly the eight iterations the previous epilogue rides on
+    (5, 64, 64, 512, 384, 1, True, True),        # 240 tiles < 256 CUs: every workgroup one tile, grid of 240
+    (8, 128, 128, 512, 128, 2, True, False),     # strided 1x1 (the downsample form): M = 32 768
+]
+P256P_OPTS = {"pw256p_mink": 256, "pw256p_mintiles": 8, "pw_ares": 0, "pw256w_mink": 0, "bn64_maxk": 128}   # K = 256 layers packed 128 wide
+
+
+@pytest.mark.parametrize("case", P256P_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_pw256p_kernel_matches_torch(case):
+    """conv_pw_glds256p_kernel (persistent 256 x 128: the ring runs across tiles, the previous tile's epilogue rides on the
+    next tile's first eight iterations from registers; round 4) against F.conv2d, and bit for bit against the
+    tile-per-workgroup kernels on the same layer."""
+    from peanut_amd.ops import FusedConv
+    _pw_case(case, "fp32", "conv_pw_glds_256x128p", 2e-5, options=P256P_OPTS)
+    B, H, W, cin, cout, stride, relu, residual = case
+    g = torch.Generator().manual_seed(sum(case[:6]) + 1)
+    x = _rand((B, H, W, cin), g).cuda()
+    w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = _rand((B, ho, wo, cout), g).cuda() if residual else None
+    y0 = FusedConv(w, None, shift, stride=stride, relu=relu, options=P256P_OPTS)(x, residual=res)
+    assert _last_kernel() == "conv_pw_glds_256x128p"
+    y1 = FusedConv(w, None, shift, stride=stride, relu=relu, options={**P256P_OPTS, "pw256p_mink": 0})(x, residual=res)
+    assert _last_kernel() != "conv_pw_glds_256x128p"
+    if (B * ho * wo // 256) * (cout // 128) % 256 == 0:      # no tail: neither kernel cuts a k range, the sums agree bit for bit
+        assert torch.equal(y0, y1)
+    else:
+        assert float((y0 - y1).abs().max()) <= 2e-5
+
+
+def test_pw256p_kernel_two_sources():
+    """The persistent kernel reading its A k-tiles from two tensors (the conv3 + downsample form: the source switches at
+    k-tile c1 / 32, inside a tile and inside split parts) against a conv over the concatenation."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, c1, c2, cout = 9, 64, 64, 256, 512, 1024
+    g = torch.Generator().manual_seed(13)
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) * scale[None, :, None, None] + shift[None, :, None, None])
+    conv = FusedConv(w, scale, shift, relu=True, options=P256P_OPTS)
+    y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda())
+    assert _last_kernel() == "conv_pw_glds_256x128p", _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
 def test_pw256_kernel_grouped_winograd_gemm():
     """The 36 grouped position GEMMs of a Winograd conv on the 256 x 128 kernel (mt_per_group in 256-row tiles, rows
     padded to whole 256-row tiles per position: the bottleneck's form) against F.conv2d."""

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Audit of the inline-asm global loads that hipcc does not count (csrc/conv_pw_ares.hip: load_uncounted).
 
-An asm `global_load_dword vN, ...` returns at once; vN holds its data only after the kernel's own `s_waitcnt vmcnt(0)`.
+An asm `global_load_dword vN, ...` returns at once; vN holds its data only after the kernel's own asm `s_waitcnt vmcnt(N)`
+(whether N is right is the kernel's protocol -- the loads are issued BEFORE the operations the count leaves in flight).
 hipcc treats vN as written at the end of the asm statement, so it MAY copy, spill or reuse it before the data has landed
 (cdna_hip_programming.md 5.7, item 1) -- silently wrong values.  This script compiles the source to gfx950 assembly and
 checks, for every kernel, that in program text no instruction between such a load and the next `s_waitcnt vmcnt(0)`
@@ -21,10 +22,11 @@ from typing import List, Tuple
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "peanut_amd", "csrc")
-DEFAULT = [os.path.join(CSRC, "conv_pw_ares.hip")]
+DEFAULT = [os.path.join(CSRC, "conv_pw_ares.hip"), os.path.join(CSRC, "conv_pw256p.hip")]
 
 LOAD = re.compile(r"^\s*global_load_dword\s+v(\d+)\s*,")
-WAIT0 = re.compile(r"^\s*s_waitcnt\s+vmcnt\(0\)")
+NOP = re.compile(r"^\s*s_nop\b")
+WAIT0 = re.compile(r"^\s*s_waitcnt\s+vmcnt\(\d+\)")      # the kernel's own counted wait (inside an asm statement)
 RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
 SINGLE = re.compile(r"\bv(\d+)\b")
 LABEL = re.compile(r"^\.LBB\d+_\d+:")
