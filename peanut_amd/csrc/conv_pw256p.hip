@@ -54,6 +54,8 @@ __device__ __forceinline__ void p_wait(const float (&r)[8], float a, float b, fl
 
 struct PItem { int mt, nt, kt0, kt1, part; };   // part >= 0: split-K part -> partial tile #part
 
+// RAGGED: the last m-tile may hang over the end of the rows (M % 256 != 0): its A rows are clamped, its stores predicated.
+template <bool RAGGED>
 __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams p) {
   constexpr int BM = 256, BN = 128, BK = 32, WN = 2;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;   // 48 KiB
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
     const int m0 = it.mt * BM;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const int m = m0 + (wave * A_INSTR + j) * 8 + lr;           // < M: the gate admits whole 256-row tiles only
+      int m = m0 + (wave * A_INSTR + j) * 8 + lr;
+      if (RAGGED) m = m < p.M ? m : p.M - 1;                     // rows past the end fetch a valid row and are dropped
       const int b = m / p.HoWo;
       const int rem = m - b * p.HoWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   const float* prev_ss = p.scale;         // uniform: scale of its first column
   unsigned prev_rs = 0;                   // bytes between rows of the residual (0: zero page)
   unsigned prev_os = (unsigned)cout * 4;  // bytes between rows of the output
+  int prev_rows = BM;                     // RAGGED: rows of the previous item's tile that exist (raw partial tiles: all)
   const unsigned lane_row = (unsigned)(wm * 64 + 4 * hi), lane_col = (unsigned)(wn * 64 + li);
   const unsigned ss_lane = lane_col * 4;
   const unsigned shift_delta = (unsigned)((p.shift - p.scale) * 4);
@@ -200,7 +204,12 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
     const unsigned lane_off = (lane_row * prev_rs) + (prev_rs ? lane_col * 4 : 0);                                \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
       const int r = ((c) & 1) * 8 + i, row = ((c) >> 2) * 32 + (r & 3) + 8 * (r >> 2);                            \
-      resv[i] = p_load_uncounted(prev_res, lane_off + (unsigned)row * prev_rs + (prev_rs ? (((c) >> 1) & 1) * 128u : 0u)); \
+      unsigned roff = lane_off + (unsigned)row * prev_rs;                                                         \
+      if (RAGGED) {                                                                                               \
+        const int rr = (int)lane_row + row;                                                                       \
+        roff = (unsigned)(rr < prev_rows ? rr : prev_rows - 1) * prev_rs + (prev_rs ? lane_col * 4 : 0);          \
+      }                                                                                                           \
+      resv[i] = p_load_uncounted(prev_res, roff + (prev_rs ? (((c) >> 1) & 1) * 128u : 0u));                      \
     }                                                                                                             \
   }
 #define P256_EPI_FINISH(c)                                                                                        \
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
         v += resv[i];                                                                                             \
         if (relu) v = relu_keep_nan(v);                                                                           \
       }                                                                                                           \
-      *reinterpret_cast<float*>(obase + (unsigned)row * prev_os) = v;                                             \
+      if (!RAGGED || (int)lane_row + row < prev_rows) *reinterpret_cast<float*>(obase + (unsigned)row * prev_os) = v; \
     }                                                                                                             \
   }
 
@@ -318,12 +327,14 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
       const size_t tile_el = (size_t)it.mt * BM * cout + (size_t)it.nt * BN;
       prev_valid = true;
       prev_raw = it.part >= 0;
+      prev_rows = BM;
       if (prev_raw) {
         prev_out = p.partial + (size_t)it.part * (BM * BN);
         prev_os = BN * 4;
         prev_res = p.zeros;
         prev_rs = 0;
       } else {
+        if (RAGGED && p.M - it.mt * BM < BM) prev_rows = p.M - it.mt * BM;
         prev_out = p.y + tile_el;
         prev_os = (unsigned)cout * 4;
         prev_res = has_res ? p.res + tile_el : p.zeros;
@@ -355,9 +366,9 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
 bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles) {
   const int min_k = (int)opt(OPT_PW256P_MINK);
   if (min_k <= 0 || bn_tile != 128 || mt_per_group != 0 || flush_ktiles != 0 || cin < min_k || cin < 256) return false;
-  if (M % 256 != 0 || cout % 128 != 0) return false;                       // whole tiles: the register epilogue checks no bounds
+  if (cout % 128 != 0) return false;                                       // whole 128-wide n-tiles: the register epilogue checks no column bounds
   if (M * (long long)cin * 4 >= (1LL << 32) || M * (long long)cout * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets
-  return (M / 256) * (cout / 128) >= opt(OPT_PW256P_MINTILES);
+  return ((M + 255) / 256) * (cout / 128) >= opt(OPT_PW256P_MINTILES);
 }
 
 int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipStream_t stream) {
@@ -367,9 +378,7 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
     return fail(-3, "conv_pw256p: no current device");
   const int mtiles = (p.M + 255) / 256;
   const int T = mtiles * p.ntiles;
-  int G = T < cus ? T : cus;
-  G -= G % 8;
-  if (G < 8) return fail(-2, "conv_pw256p: launch too small");
+  const int G = cus - cus % 8;          // one workgroup per CU whatever the tile count: a launch with fewer tiles than CUs is all split parts
   // Every workgroup gets the same number of whole tiles (n_full / G); the T mod G tiles left over are cut into split_p
   // k-ranges each (raw partial tiles + the ordered reduce, as in launch_with_tail_split) and dealt out evenly.  split_p
   // minimises the busiest workgroup's extra work: ceil(t * p / G) parts of nkt / p k-tiles plus ~1.5 k-tile times per part (raw
@@ -394,9 +403,10 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
   p.nchunk = (int)opt(OPT_NCHUNK);
   p.phase_shift = opt(OPT_PW256_PHASE) != 0;
   note_kernel("conv_pw_glds_256x128p");
-  hipLaunchKernelGGL(conv_pw_glds256p_kernel, dim3((unsigned)G), dim3(512), 0, stream, p);
+  if (p.M % 256 == 0) hipLaunchKernelGGL(conv_pw_glds256p_kernel<false>, dim3((unsigned)G), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL(conv_pw_glds256p_kernel<true>, dim3((unsigned)G), dim3(512), 0, stream, p);
   if (p.n_sp > 0)
-    hipLaunchKernelGGL((conv_splitk_reduce_kernel<256, 128>), dim3((unsigned)(T % G), 256 / 16), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<256, 128>), dim3((unsigned)t, 256 / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("conv_pw256p launch: ") + hipGetErrorString(e));
   return 0;

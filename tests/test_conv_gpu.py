@@ -226,6 +226,9 @@ P256P_CASES = [
     (8, 64, 64, 256, 1024, 1, False, True),      # K = 256: exactly the eight iterations the previous epilogue rides on
     (5, 64, 64, 512, 384, 1, True, True),        # 240 tiles < 256 CUs: every workgroup one tile, grid of 240
     (8, 128, 128, 512, 128, 2, True, False),     # strided 1x1 (the downsample form): M = 32 768
+    (5, 57, 61, 1024, 512, 1, True, True),       # M = 17 385: the last 256-row tile hangs over the end (RAGGED variant), residual
+    (1, 90, 90, 1024, 256, 1, True, False),      # one 720 x 720 map's layer3 conv1: 64 tiles < 256 CUs -> every tile in split parts, ragged M = 8 100
+    (1, 90, 90, 512, 2048, 1, True, True),       # its layer4 conv3: 512 tiles, two per workgroup, ragged last m-tile, residual
 ]
 P256P_OPTS = {"pw256p_mink": 256, "pw256p_mintiles": 8, "pw_ares": 0, "pw256w_mink": 0, "bn64_maxk": 128}   # K = 256 layers packed 128 wide
 
@@ -248,7 +251,7 @@ def test_pw256p_kernel_matches_torch(case):
     assert _last_kernel() == "conv_pw_glds_256x128p"
     y1 = FusedConv(w, None, shift, stride=stride, relu=relu, options={**P256P_OPTS, "pw256p_mink": 0})(x, residual=res)
     assert _last_kernel() != "conv_pw_glds_256x128p"
-    if (B * ho * wo // 256) * (cout // 128) % 256 == 0:      # no tail: neither kernel cuts a k range, the sums agree bit for bit
+    if (B * ho * wo) % 256 == 0 and (B * ho * wo // 256) * (cout // 128) % 256 == 0:      # no tail: neither kernel cuts a k range, the sums agree bit for bit
         assert torch.equal(y0, y1)
     else:
         assert float((y0 - y1).abs().max()) <= 2e-5
