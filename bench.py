@@ -147,6 +147,7 @@ def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 40.0):
 FAMILY_KERNEL = {
     "conv_pw_glds_256x128": "conv_pw_glds256_kernel(",
     "conv_pw_glds_256x256": "conv_pw_glds256w_kernel",
+    "conv_pw_glds_256x128p": "conv_pw_glds256p_kernel",
     "conv_pw_ares_128x128": "conv_pw_ares_kernel",
     "conv_pw_glds_128x128": "conv_pw_glds_kernel<128, 2, 2>",
     "conv_pw_glds_128x64": "conv_pw_glds_kernel<64, 2, 2>",

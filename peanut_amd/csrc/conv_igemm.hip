@@ -324,7 +324,10 @@ static int launch_t(const ConvKParams& p, float* ws, size_t ws_floats, hipStream
 
 int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   if (a.c1 + a.c2 != d.cin) return fail(-2, "launch_conv: c1 + c2 != cin");
-  const int kgran = d.rs ? 16 : d.bk;     // k-tile of the kernel that will run
+  // gemm_rs.hip reads two sources at one pixel stride only for stride 1; a strided two-source pointwise layer of an emulated
+  // mode runs on the fp32 MFMA kernels instead (its fp32-packed weights are always uploaded; exact fp32: nothing is lost)
+  const bool rs_fallback = d.rs == 1 && a.c2 != 0 && d.stride != 1;
+  const int kgran = (d.rs && !rs_fallback) ? 16 : d.bk;     // k-tile of the kernel that will run
   if (a.c1 % kgran != 0 || (a.c2 % kgran) != 0) return fail(-2, "launch_conv: channel split not a multiple of the k-tile");
   ConvKParams p{};
   p.x = a.x; p.x2 = a.x2 ? a.x2 : a.x; p.w = d.w_packed; p.scale = d.scale; p.shift = d.shift;
@@ -342,9 +345,9 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.ntiles = d.cout_pad / d.bn_tile;
   p.n_full = 0; p.n_sp = 0; p.split_p = 1; p.partial = nullptr;
   p.alpha = 1.f;
-  p.flush = d.rs ? 0 : d.flush_ch / d.bk;   // k-tiles per partial sum (conv_pw.hip; every other kernel keeps one running sum)
+  p.flush = (d.rs && !rs_fallback) ? 0 : d.flush_ch / d.bk;   // k-tiles per partial sum (conv_pw.hip; every other kernel keeps one running sum)
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
-  if (d.rs) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
+  if (d.rs && !rs_fallback) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
     if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");
     p.w = static_cast<const float*>(d.w_s);
     p.nkt = (d.cin / 16) * p.ntaps;

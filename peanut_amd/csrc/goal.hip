@@ -51,7 +51,7 @@ namespace {
 constexpr int TILE = 32, HALO = 2, LT = TILE + 2 * HALO;   // 36
 constexpr int MAX_SWEEPS = 96;                             // per round and tile (a front crosses a tile in <= 64)
 constexpr int ROUNDS_PER_CHECK = 8, MAX_ROUNDS_PER_CHECK = 96;
-constexpr int MAX_ORDER_PASSES = 6;     // measured distance to the heap-ordered march: 3 passes 0.39 / 0.70 cell (maze / cluttered map), 4 passes 0.14 / 0.47, fixed point (5-6) 0.14 / 0.03
+constexpr int MAX_ORDER_PASSES = 6;     // default of option fmm_max_passes; measured distance to the heap-ordered march: 3 passes 0.39 / 0.70 cell (maze / cluttered map), 4 passes 0.14 / 0.47, fixed point (5-6) 0.14 / 0.03
 
 enum : unsigned char { ST_MASKED = 0, ST_FREE = 1, ST_SEED = 2 };
 
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(64) void goal_argmax_final_kernel(const ArgMax* __r
 using namespace peanut;
 
 struct peanut_goal {
+  peanut::Options opts = peanut::default_options();   // tuning options of this handle (options.h): snapshot at creation
   int H = 0, W = 0, rad = 0, tiles_x = 0, tiles_y = 0;
   DevBuf trav, state, dist, order, active, counters, maxbits, wt_new, wt_last, sum, partial, out_idx, out_val, value;
   bool have_last = false;
@@ -450,7 +451,8 @@ int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* 
   // stage B: second order on the graph ordered by the previous field, until a pass changes nothing
   g->last_passes = 0;
   g->last_converged = false;
-  for (int pass = 0; pass < MAX_ORDER_PASSES; ++pass) {
+  const int max_passes = (int)std::min<long long>(std::max<long long>(opt(OPT_FMM_MAX_PASSES), 2), 64);
+  for (int pass = 0; pass < max_passes; ++pass) {
     PEANUT_HIP_CHECK(hipMemcpyAsync(g->order.p, g->dist.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (pass == 0) {      // from the seeds again
       hipLaunchKernelGGL(fmm_restart_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned char*)g->state.p, n, (double*)g->dist.p);
@@ -506,6 +508,7 @@ int peanut_goal_converged(peanut_goal_t* g) { return g ? (g->last_converged ? 1 
 
 int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint8_t* goal_mask, int goal_r, int goal_c, int fill_mode,
                         double* dist_out, void* stream) {
+  peanut::OptionScope option_scope(g ? &g->opts : nullptr);
   if (!g || !traversible || !dist_out) return fail(PEANUT_EINVAL, "peanut_fmm_distance: null argument");
   if (!goal_mask && (goal_r < 0 || goal_r >= g->H || goal_c < 0 || goal_c >= g->W))
     return fail(PEANUT_EINVAL, "peanut_fmm_distance: goal cell outside the map");
@@ -536,6 +539,7 @@ int peanut_goal_traversible(peanut_goal_t* g, const float* full_obstacle, const 
 int peanut_goal_select(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map, const uint8_t* visited_vis,
                        const int lmb[4], int loc_r, int loc_c, const float* target_pred, double dist_weight_temperature,
                        int map_resolution, int goal_rc_out[2], double stats_out[4], double* dist_out, double* value_out, void* stream) {
+  peanut::OptionScope option_scope(g ? &g->opts : nullptr);
   if (!g || !full_obstacle || !lmb || !goal_rc_out) return fail(PEANUT_EINVAL, "peanut_goal_select: null argument");
   const int gx1 = lmb[0], gx2 = lmb[1], gy1 = lmb[2], gy2 = lmb[3];
   const int lw = gx2 - gx1, lh = gy2 - gy1;

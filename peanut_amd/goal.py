@@ -85,7 +85,18 @@ class GeodesicSolver:
             rc = self._lib.peanut_fmm_distance(self._h, trav.data_ptr(), None if gm is None else gm.data_ptr(), gr, gc,
                                                int(fill_max_plus_one), out.data_ptr(), _lib.current_stream_ptr(self.device))
         _lib.check(rc, "peanut_fmm_distance")
+        self._note_convergence()
         return out
+
+    def _note_convergence(self):
+        """The ordering passes of the second-order stage stop at a cap (library option ``fmm_max_passes``, default 6); a
+        solve that hit it with its last pass still changing tiles returns the last iterate, not the fixed point (measured
+        effect: a few hundredths of a cell).  Said once per solver instead of passing silently."""
+        if not self.converged and not getattr(self, "_warned_unconverged", False):
+            import warnings
+            self._warned_unconverged = True
+            warnings.warn(f"GeodesicSolver: the ordering passes stopped at their cap ({self.passes}) before reaching their fixed "
+                          "point; the field is the last iterate (raise the library option fmm_max_passes to iterate further)")
 
     def select(self, full_obstacle, collision_map, visited_vis, lmb, loc_rc, target_pred, dist_weight_temperature: float,
                map_resolution: int, want_dist: bool = False, want_value: bool = False):
@@ -107,8 +118,9 @@ class GeodesicSolver:
                                               C.byref(goal), C.byref(stats), None if dist is None else dist.data_ptr(),
                                               None if value is None else value.data_ptr(), _lib.current_stream_ptr(self.device))
         _lib.check(rc, "peanut_goal_select")
+        self._note_convergence()
         out = dict(goal=(int(goal[0]), int(goal[1])), value_max=float(stats[0]), wt_sum=float(stats[1]), kept_last=bool(stats[2]),
-                   rounds=int(stats[3]))
+                   rounds=int(stats[3]), passes=self.passes, converged=self.converged)
         if want_dist:
             out["dist"] = dist
         if want_value:

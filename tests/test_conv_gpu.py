@@ -719,7 +719,9 @@ def test_pointwise_kernel_families_are_bit_identical():
     """Every fp32 pointwise kernel family sums its products in the same k order on the same MFMA fragment layout, so the
     SAME layer must come out bit for bit whichever family runs it: the LDS-DMA kernels of conv_pw.hip against the
     register-staged conv_igemm kernel (option pw_glds = 0), the persistent A-resident kernel of conv_pw_ares.hip against
-    the tile-per-workgroup 128 x 64 kernel (pw_ares = 0), the 256 x 256 kernel against 256 x 128 (pw256w_mink = 0) --
+    the tile-per-workgroup 128 x 64 kernel (pw_ares = 0), the 256 x 256 kernel against 256 x 128 (pw256w_mink = 0), the persistent
+    256 x 128 kernel of conv_pw256p.hip against the tile-per-workgroup ones (pw256p_mink = 0; shapes without a tail, so that no
+    kernel cuts a k range) --
     switched per handle through the option API (csrc/options.h), the kernel family asserted by name."""
     from peanut_amd.ops import FusedConv
     cases = [  # (B, H, W, cin, cout, stride, residual), options of the alternative handle, family of the default / the alternative
@@ -729,7 +731,9 @@ def test_pointwise_kernel_families_are_bit_identical():
         ((1, 12, 12, 64, 256, 1, True), {"pw_glds": 0}, "conv_pw_glds_128x64", "conv_igemm_128x64x32"),
         ((8, 64, 64, 256, 1024, 1, True), {"pw_ares": 0}, "conv_pw_ares_128x128", "conv_pw_glds_128x64"),
         ((8, 64, 64, 128, 512, 1, True), {"pw_ares": 0}, "conv_pw_ares_128x128", "conv_pw_glds_128x64"),
-        ((8, 64, 64, 1024, 1024, 1, True), {"pw256w_mink": 0}, "conv_pw_glds_256x256", "conv_pw_glds_256x128"),
+        ((8, 64, 64, 1024, 1024, 1, True), {"pw256w_mink": 0, "pw256p_mink": 0}, "conv_pw_glds_256x256", "conv_pw_glds_256x128"),
+        ((8, 64, 64, 1024, 512, 1, True), {"pw256p_mink": 0}, "conv_pw_glds_256x128p", "conv_pw_glds_256x128"),
+        ((8, 64, 64, 512, 1024, 1, True), {"pw256p_mink": 0}, "conv_pw_glds_256x128p", "conv_pw_glds_128x128"),
     ]
     for i, (case, alt, fam0, fam1) in enumerate(cases):
         B, H, W, cin, cout, s, residual = case
@@ -739,7 +743,7 @@ def test_pointwise_kernel_families_are_bit_identical():
         shift = _rand((cout,), g, 0.1)
         ho, wo = (H - 1) // s + 1, (W - 1) // s + 1
         res = _rand((B, ho, wo, cout), g).cuda() if residual else None
-        base = {"pw256w_mintiles": 256} if "256x256" in fam0 else {}
+        base = {"pw256w_mintiles": 256} if "256x256" in fam0 else {"pw256w_mink": 0}
         y0 = FusedConv(w, None, shift, stride=s, relu=True, options=base)(x, residual=res)
         assert _last_kernel() == fam0, (case, _last_kernel())
         y1 = FusedConv(w, None, shift, stride=s, relu=True, options={**base, **alt})(x, residual=res)
@@ -782,3 +786,22 @@ def test_options_are_per_handle():
     assert _last_kernel() == "conv_pw_glds_128x64"
     text = lib.peanut_option_list().decode()
     assert "pw256_mink=1024" in text and "wino_m=0 [create-time]" in text
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "fp16x3"])
+def test_strided_two_source_pointwise_in_the_emulated_modes(precision):
+    """gemm_rs.hip reads two sources at one pixel stride only for stride 1; a STRIDED two-source 1x1 conv (a stride-2
+    downsample over [x | x2]) of an emulated mode therefore runs on the fp32 MFMA kernels from the layer's fp32-packed
+    weights -- accepted, exact fp32, instead of the error the register-split kernel used to return."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, c1, c2, cout = 2, 31, 29, 64, 96, 256
+    g = torch.Generator().manual_seed(29)
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w, stride=2) + shift[None, :, None, None])
+    conv = FusedConv(w, None, shift, stride=2, relu=True, precision=precision)
+    y = conv(xa.permute(0, 2, 3, 1).contiguous().cuda(), x2=xb.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+    assert _last_kernel().startswith("conv_igemm_"), _last_kernel()
+    err = (y - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"

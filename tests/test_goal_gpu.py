@@ -244,3 +244,39 @@ def test_update_state_selects_goals_and_keeps_last_weights_when_stuck():
     r5 = sol.select(obst, None, None, lmb, (10, 10), None, 0, 5)          # temperature 0: frontier mode, no target_pred
     gr, gc = r5["goal"]
     assert 59.0 <= np.hypot(gr - 10, gc - 10) or r5["value_max"] == 0.0
+
+
+@pytest.mark.parametrize("shape,seed", [((960, 960), 1), ((480, 480), 2)], ids=lambda v: str(v))
+def test_ordering_pass_cap_is_reported_and_its_effect_is_bounded(shape, seed):
+    """The agent's map sizes (480 local, 960 full): a solve under the default cap of six ordering passes either reaches its
+    fixed point or says so (``converged`` False + ONE warning from the Python mirror); with the cap raised through the
+    library option fmm_max_passes the passes DO reach their fixed point, and the field the capped solve returned is within
+    0.1 cell of it -- the bound on what stopping early can cost FMMPlanner / goal selection."""
+    import warnings
+    from peanut_amd import _lib
+    from peanut_amd.goal import GeodesicSolver
+    h, w = shape
+    trav = _maze(h, w, seed)
+    src = (h // 2 + 3, w // 2 - 5)
+    trav[src[0] - 2:src[0] + 3, src[1] - 2:src[1] + 3] = 1
+    tt = torch.from_numpy(trav)
+    sol = GeodesicSolver(h, w, 0)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        capped = sol.distance(tt, goal=src).cpu().numpy()
+        capped_again = sol.distance(tt, goal=src).cpu().numpy()
+    hit_cap = not sol.converged
+    said = [r for r in rec if "ordering passes stopped at their cap" in str(r.message)]
+    assert len(said) == (1 if hit_cap else 0), [str(r.message) for r in rec]
+    assert np.array_equal(capped, capped_again)
+    lib = _lib.load()
+    with _lib.default_options(fmm_max_passes=24):
+        free = GeodesicSolver(h, w, 0)
+        full = free.distance(tt, goal=src).cpu().numpy()
+        assert free.converged, f"{free.passes} passes without reaching the ordering fixed point"
+    fin = np.isfinite(full)
+    assert np.array_equal(fin, np.isfinite(capped))
+    diff = np.abs(full[fin] - capped[fin]).max()
+    print(f"{h}x{w}: default cap {'hit' if hit_cap else 'not hit'} ({sol.passes} passes), fixed point after {free.passes} passes; "
+          f"capped vs fixed point max {diff:.3e} cells")
+    assert diff <= 0.1

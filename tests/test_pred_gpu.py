@@ -461,8 +461,7 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
         ref = pspnet_ref.forward_batch(sd, x, cfg)
     xd = x.cuda()
     want = {
-        "fp32": ("conv_pw_glds_256x128", ["layer3.1.conv1", "layer4.0.conv1", "layer4.0.conv3+downsample", "layer4.2.conv1",
-                                          "bottleneck.conv[x][wino6_gemm]"]),
+        "fp32": ("conv_pw_glds_256x128", ["layer3.1.conv1", "bottleneck.conv[x][wino6_gemm]"]),
         "bf16x6": ("gemm_rs6_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
                                         "layer4.1.conv2[wino5_gemm]", "bottleneck.conv[x][wino_gemm]"]),
         "fp16x3": ("gemm_rs3h_256x256", ["layer3.0.conv3+downsample", "layer4.0.conv3+downsample", "layer4.1.conv1", "layer4.1.conv3",
@@ -495,6 +494,10 @@ def test_b10_480_forward_vs_oracle_on_the_large_tile_kernels(model_and_sd):
         for layer in layers:
             hit = [n for n in on_family if n.endswith(layer)]
             assert hit, f"{precision}: {layer} did not run on {family}: {[(n, k) for n, k in ops.items() if n.endswith(layer)]}"
+        if precision == "fp32":      # 36 000 rows = 140.6 tiles of 256: the RAGGED variant of the persistent kernel (round 4) carries the K >= 512 layers with >= 512 tiles
+            for layer in ("layer4.0.conv1", "layer4.2.conv1", "layer4.1.conv3", "layer4.0.conv3+downsample"):
+                hit = [n for n, k in ops.items() if n.endswith(layer)]
+                assert hit and all(ops[n] == "conv_pw_glds_256x128p" for n in hit), (layer, [(n, ops[n]) for n in hit])
         if mm is not m:
             del mm
 
@@ -504,8 +507,9 @@ def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
     """Sixteen 480 x 480 maps against the ORACLE at a size where the round-4 kernels carry the layers they carry in the
     headline benchmark -- asserted by kernel family per op: the persistent A-resident kernel (csrc/conv_pw_ares.hip) runs
     layer2 / layer3 conv3 and the position GEMMs of their Winograd conv2 (57 600 rows = 450 whole 128-row tiles), the
-    256 x 256 kernel (csrc/conv_pw.hip) layer4.0's conv3 + downsample (1 800 tiles).  Then the same maps through a handle
-    with both kernels switched off by option (csrc/options.h): the families sum in the same k order (bit-identical at
+    256 x 256 kernel (csrc/conv_pw.hip) layer4.0's conv3 + downsample (1 800 tiles), the persistent 256 x 128 kernel
+    (csrc/conv_pw256p.hip) the K >= 512 layers with at least 512 tiles.  Then the same maps through a handle
+    with the three kernels switched off by option (csrc/options.h): the families sum in the same k order (bit-identical at
     operator level, tests/test_conv_gpu.py), but the tile-per-workgroup kernels cut the k range of their LAST round's tiles
     (tail split-K) and which tiles those are depends on the tile size -- so the two handles agree to rounding, not to the
     bit -- and the options of one handle must not leak into the other."""
@@ -527,7 +531,8 @@ def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
     want = {"conv_pw_ares_128x128": ["layer2.1.conv3", "layer2.3.conv2[wino6_gemm]", "layer3.1.conv3", "layer3.5.conv3",
                                      "layer3.2.conv2[wino6_gemm]", "layer2.0.conv1"],
             "conv_pw_glds_256x256": ["layer4.0.conv3+downsample"],
-            "conv_pw_glds_256x128": ["layer3.1.conv1", "layer4.1.conv1", "bottleneck.conv[x][wino6_gemm]"]}
+            "conv_pw_glds_256x128p": ["layer4.0.conv1", "layer4.1.conv1", "layer4.1.conv3", "layer4.2.conv3", "layer3.0.conv3+downsample"],
+            "conv_pw_glds_256x128": ["layer3.1.conv1", "bottleneck.conv[x][wino6_gemm]"]}
     for family, layers in want.items():
         for layer in layers:
             hit = [n for n, k in ops.items() if n.endswith(layer)]
@@ -535,13 +540,14 @@ def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
     plain = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
     plain.model.set_option("pw_ares", 0)
     plain.model.set_option("pw256w_mink", 0)
+    plain.model.set_option("pw256p_mink", 0)
     assert plain.model.get_option("pw_ares") == 0 and m.model.get_option("pw_ares") == 1
     got2 = plain.get_prediction_batch(xd, apply_sigmoid=False)
     ops2 = {name: kern for name, kern, *_ in plain.model.profile(xd)}
-    assert not any(k in ("conv_pw_ares_128x128", "conv_pw_glds_256x256") for k in ops2.values())
+    assert not any(k in ("conv_pw_ares_128x128", "conv_pw_glds_256x256", "conv_pw_glds_256x128p") for k in ops2.values())
     err2 = (got2.cpu() - ref).abs().max().item()
     diff = float((got - got2).abs().max())
-    print(f"same maps with pw_ares = 0, pw256w_mink = 0: vs oracle {err2:.3e}, between the two handles {diff:.3e}")
+    print(f"same maps with pw_ares = 0, pw256w_mink = 0, pw256p_mink = 0: vs oracle {err2:.3e}, between the two handles {diff:.3e}")
     assert err2 <= TOL and diff <= 3e-5
     del plain
 
