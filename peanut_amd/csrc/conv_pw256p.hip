@@ -55,7 +55,10 @@ __device__ __forceinline__ void p_wait(const float (&r)[8], float a, float b, fl
 struct PItem { int mt, nt, kt0, kt1, part; };   // part >= 0: split-K part -> partial tile #part
 
 // RAGGED: the last m-tile may hang over the end of the rows (M % 256 != 0): its A rows are clamped, its stores predicated.
-template <bool RAGGED>
+// FLUSH: two-level fp32 accumulation (partial sums of 64 channels: conv_common.h PEANUT_FLUSH_*) for the grouped Winograd
+// position GEMMs.  A third accumulator set does not fit: the finished totals stay in the second-level set and are stored during
+// the next item's first TWO iterations (32 values each; such layers have no residual), before its first flush needs the set.
+template <bool RAGGED, bool FLUSH>
 __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams p) {
   constexpr int BM = 256, BN = 128, BK = 32, WN = 2;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;   // 48 KiB
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
       a_pix[j] = (unsigned)(b * p.H * p.W + oy * p.stride * p.W + ox * p.stride);
     }
-    d_wtile = p.w + (size_t)it.nt * p.nkt * (BN * BK);
+    d_wtile = p.w + (p.mt_per_group ? (size_t)(it.mt / p.mt_per_group) * p.w_group_stride : 0) + (size_t)it.nt * p.nkt * (BN * BK);
     d_kt = it.kt0;
     d_left = it.kt1 - it.kt0;
   };
@@ -165,13 +168,23 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   const int a_row = (wm * 64 + li) * BK;
   const int b_row = A_FLOATS + (wn * 64 + li) * BK;
 
-  f32x16 acc[2][2], prev[2][2];
+  // accumulators; the previous item's finished values: `prev` (a copy), or -- FLUSH -- the second-level set `acc2` itself
+  f32x16 acc[2][2], prev[2][2], acc2[2][2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[t][u][r] = 0.f; prev[t][u][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { acc[t][u][r] = 0.f; prev[t][u][r] = 0.f; acc2[t][u][r] = 0.f; }
+#define P256_PREV(t, u, r) (FLUSH ? acc2[t][u][r] : prev[t][u][r])
+#define P256_FLUSH_STEP()                                                                                 \
+  if (FLUSH) {                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                     \
+        acc2[t][u] += acc[t][u];                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;                                \
+      }                                                                                                   \
+  }
 
   // ---- epilogue state of the PREVIOUS item.  Chunk c (0..7) = accumulator block (t, u) = (c >> 2, (c >> 1) & 1), registers
   // r = (c & 1) * 8 .. + 7: rows t*32 + (r & 3) + 8 * (r >> 2) (+ wm*64 + 4*hi), column u*32 + li (+ wn*64).  Bases are
@@ -192,6 +205,13 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   const float alpha = p.alpha;
   const bool relu = p.relu != 0;
 
+#define P256_EPI_SS_LOADS()                                                                                       \
+  {                                                                                                               \
+    sc0 = p_load_uncounted(prev_ss, ss_lane);                                                                     \
+    sc1 = p_load_uncounted(prev_ss, ss_lane + 128);                                                               \
+    sh0 = p_load_uncounted(prev_ss, ss_lane + shift_delta);                                                       \
+    sh1 = p_load_uncounted(prev_ss, ss_lane + shift_delta + 128);                                                 \
+  }
 #define P256_EPI_LOADS(c)                                                                                         \
   float resv[8];                                                                                                  \
   {                                                                                                               \
@@ -212,16 +232,17 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
       resv[i] = p_load_uncounted(prev_res, roff + (prev_rs ? (((c) >> 1) & 1) * 128u : 0u));                      \
     }                                                                                                             \
   }
-#define P256_EPI_FINISH(c)                                                                                        \
+#define P256_EPI_FINISH(c) P256_EPI_FINISH_RV(c, resv)
+#define P256_EPI_FINISH_RV(c, RV)                                                                                 \
   if (prev_valid) {                                                                                               \
     const float scv = (((c) >> 1) & 1) ? sc1 : sc0, shv = (((c) >> 1) & 1) ? sh1 : sh0;                           \
     char* const obase = reinterpret_cast<char*>(prev_out) + (lane_row * prev_os + lane_col * 4 + (((c) >> 1) & 1) * 128u); \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
       const int r = ((c) & 1) * 8 + i, row = ((c) >> 2) * 32 + (r & 3) + 8 * (r >> 2);                            \
-      float v = prev[(c) >> 2][((c) >> 1) & 1][r];                                                                \
+      float v = P256_PREV((c) >> 2, ((c) >> 1) & 1, r);                                                           \
       if (!prev_raw) {                                                                                            \
         v = v * (scv * alpha) + shv;                                                                              \
-        v += resv[i];                                                                                             \
+        v += RV[i];                                                                                               \
         if (relu) v = relu_keep_nan(v);                                                                           \
       }                                                                                                           \
       if (!RAGGED || (int)lane_row + row < prev_rows) *reinterpret_cast<float*>(obase + (unsigned)row * prev_os) = v; \
@@ -271,6 +292,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
     P256_MFMA_PAIR();                                                                                     \
     p_wait<6>(P256_RESV, sc0, sc1, sh0, sh1);                                                             \
     P256_EPI_FINISH_IF                                                                                    \
+    P256_FLUSH_IF                                                                                         \
     cursor_advance();                                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
     __builtin_amdgcn_s_barrier();                                                                         \
@@ -285,26 +307,51 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
     static_for<8>([&](auto kc) {
       constexpr int c = decltype(kc)::value;
       if (c < nk) {
+        if constexpr (!FLUSH) {
 #define P256_EPI_LOADS_IF P256_EPI_LOADS(c)
 #define P256_EPI_FINISH_IF P256_EPI_FINISH(c)
+#define P256_FLUSH_IF
 #define P256_RESV resv
-        P256_ITERATION()
+          P256_ITERATION()
 #undef P256_EPI_LOADS_IF
 #undef P256_EPI_FINISH_IF
+#undef P256_FLUSH_IF
 #undef P256_RESV
+        } else {
+          // iteration 0 stores chunks 0-3 of the previous totals, iteration 1 chunks 4-7 and clears the set; odd iterations flush
+#define P256_EPI_LOADS_IF if (c == 0) P256_EPI_SS_LOADS()
+#define P256_EPI_FINISH_IF                                                                   \
+  if (c == 0) { P256_EPI_FINISH_RV(0, resv_none) P256_EPI_FINISH_RV(1, resv_none) P256_EPI_FINISH_RV(2, resv_none) P256_EPI_FINISH_RV(3, resv_none) } \
+  if (c == 1) {                                                                              \
+    P256_EPI_FINISH_RV(4, resv_none) P256_EPI_FINISH_RV(5, resv_none) P256_EPI_FINISH_RV(6, resv_none) P256_EPI_FINISH_RV(7, resv_none) \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                            \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc2[t][u][r] = 0.f;                  \
+  }
+#define P256_FLUSH_IF if (c & 1) { P256_FLUSH_STEP() }
+#define P256_RESV resv_none
+          P256_ITERATION()
+#undef P256_EPI_LOADS_IF
+#undef P256_EPI_FINISH_IF
+#undef P256_FLUSH_IF
+#undef P256_RESV
+        }
       }
     });
     for (int kt = 8; kt < nk; ++kt) {
 #define P256_EPI_LOADS_IF
 #define P256_EPI_FINISH_IF
+#define P256_FLUSH_IF if (kt & 1) { P256_FLUSH_STEP() }
 #define P256_RESV resv_none
       P256_ITERATION()
 #undef P256_EPI_LOADS_IF
 #undef P256_EPI_FINISH_IF
+#undef P256_FLUSH_IF
 #undef P256_RESV
     }
+    if (FLUSH && (nk & 1)) { P256_FLUSH_STEP() }       // a split part with an odd number of k-tiles: its last one
     // an item shorter than eight k-tiles (a split part): the rest of the previous epilogue, with nothing under it
-    if (nk < 8 && prev_valid) {
+    if (!FLUSH && nk < 8 && prev_valid) {
       static_for<8>([&](auto kc) {
         constexpr int c = decltype(kc)::value;
         if (c >= nk) {
@@ -314,15 +361,17 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
         }
       });
     }
-    // the item's accumulators become the "previous" set
+    // the item's accumulators become the "previous" set (FLUSH: they already sit in acc2, and acc is zero)
+    if (!FLUSH) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        prev[t][u] = acc[t][u];
+        for (int u = 0; u < 2; ++u) {
+          prev[t][u] = acc[t][u];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-      }
+          for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+        }
+    }
     {
       const size_t tile_el = (size_t)it.mt * BM * cout + (size_t)it.nt * BN;
       prev_valid = true;
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
         prev_res = has_res ? p.res + tile_el : p.zeros;
         prev_rs = has_res ? (unsigned)cout * 4 : 0;
       }
-      prev_ss = p.scale + it.nt * BN;
+      prev_ss = p.scale + ((p.mt_per_group && p.ss_group_stride) ? (it.mt / p.mt_per_group) * p.ss_group_stride : 0) + it.nt * BN;
     }
   }
   // ---- drain: the last item's epilogue ----
@@ -351,6 +400,10 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
     P256_EPI_FINISH(c)
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeated requests of the stream's end
+#undef P256_PREV
+#undef P256_FLUSH_STEP
+#undef P256_EPI_SS_LOADS
+#undef P256_EPI_FINISH_RV
 #undef P256_ITERATION
 #undef P256_READ_PAIR
 #undef P256_MFMA_PAIR
@@ -365,7 +418,11 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
 // over the first eight iterations of the next) and at least pw256p_mintiles tiles.
 bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles) {
   const int min_k = (int)opt(OPT_PW256P_MINK);
-  if (min_k <= 0 || bn_tile != 128 || mt_per_group != 0 || flush_ktiles != 0 || cin < min_k || cin < 256) return false;
+  if (min_k <= 0 || bn_tile != 128 || cin < min_k || cin < 256) return false;
+  // Winograd position GEMMs (partial sums of 64 channels): measured per layer (profiles/r5o) K = 512 +2.5 %, K = 2048 -4 % (the
+  // totals leave in two bursts of 32 stores) -> up to pw256p_flush input channels only
+  if (flush_ktiles != 0 && (flush_ktiles != 2 || cin > opt(OPT_PW256P_FLUSH))) return false;
+  if (mt_per_group % 2 != 0) return false;                                 // grouped GEMM: whole 256-row tiles per weight group
   if (cout % 128 != 0) return false;                                       // whole 128-wide n-tiles: the register epilogue checks no column bounds
   if (M * (long long)cin * 4 >= (1LL << 32) || M * (long long)cout * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets
   return ((M + 255) / 256) * (cout / 128) >= opt(OPT_PW256P_MINTILES);
@@ -403,8 +460,16 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
   p.nchunk = (int)opt(OPT_NCHUNK);
   p.phase_shift = opt(OPT_PW256_PHASE) != 0;
   note_kernel("conv_pw_glds_256x128p");
-  if (p.M % 256 == 0) hipLaunchKernelGGL(conv_pw_glds256p_kernel<false>, dim3((unsigned)G), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL(conv_pw_glds256p_kernel<true>, dim3((unsigned)G), dim3(512), 0, stream, p);
+  if (p.mt_per_group) p.mt_per_group /= 2;       // 256-row tiles per weight group
+  const bool ragged = p.M % 256 != 0;
+  if (p.flush) {
+    if (p.res) return fail(-2, "conv_pw256p: the two-level accumulation variant takes no residual");
+    if (ragged) hipLaunchKernelGGL((conv_pw_glds256p_kernel<true, true>), dim3((unsigned)G), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_pw_glds256p_kernel<false, true>), dim3((unsigned)G), dim3(512), 0, stream, p);
+  } else {
+    if (ragged) hipLaunchKernelGGL((conv_pw_glds256p_kernel<true, false>), dim3((unsigned)G), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_pw_glds256p_kernel<false, false>), dim3((unsigned)G), dim3(512), 0, stream, p);
+  }
   if (p.n_sp > 0)
     hipLaunchKernelGGL((conv_splitk_reduce_kernel<256, 128>), dim3((unsigned)t, 256 / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();

@@ -340,7 +340,9 @@ inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
   const ConvDesc& g = L.wino;
   const long long np = L.wino_np();
   if (g.rs) return gemm_rs_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;
-  return (conv_pw_enabled() && conv_pw_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin)) ? 256 : 128;
+  return (conv_pw_enabled() && (conv_pw_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ||
+                                conv_pw_uses_256p(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin, g.flush_ch / 32)))
+             ? 256 : 128;
 }
 
 // position-rows the Winograd GEMMs of this layer execute on an input [B,H,W,*]: positions x padded tiles

@@ -275,6 +275,31 @@ def test_pw256p_kernel_two_sources():
     assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
 
+@pytest.mark.parametrize("case", [(2, 88, 88, 512, 512, 1), (2, 88, 88, 1024, 512, 2)], ids=lambda c: "x".join(map(str, c)))
+def test_pw256p_kernel_grouped_winograd_gemm_with_two_level_accumulation(case):
+    """The grouped position GEMMs of a Winograd conv (36 weight groups, partial sums of 64 channels) on the persistent
+    256 x 128 kernel's FLUSH variant -- the finished totals stay in the second-level accumulators and are stored during the
+    next item's first two iterations -- against F.conv2d, and bit for bit against the tile-per-workgroup kernels (option
+    pw256p_flush = 0; 576 tiles: no tail on either side... the 128 x 128 kernel's 1152 tiles over 512 slots leave one, hence
+    the tolerance there)."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    res = _rand((B, cout, H, W), g)
+    ref = F.relu(F.conv2d(x, w, None, padding=d, dilation=d) + shift[None, :, None, None] + res)
+    xd, rd = x.permute(0, 2, 3, 1).contiguous().cuda(), res.permute(0, 2, 3, 1).contiguous().cuda()
+    y = FusedConv(w, None, shift, padding=d, dilation=d, relu=True, options={"pw256p_flush": 4096})(xd, residual=rd)
+    assert _last_kernel() == "conv_pw_glds_256x128p", _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+    y2 = FusedConv(w, None, shift, padding=d, dilation=d, relu=True, options={"pw256p_flush": 0})(xd, residual=rd)
+    assert _last_kernel() != "conv_pw_glds_256x128p", _last_kernel()
+    assert float((y - y2).abs().max()) <= 2e-5
+
+
 def test_pw256_kernel_grouped_winograd_gemm():
     """The 36 grouped position GEMMs of a Winograd conv on the 256 x 128 kernel (mt_per_group in 256-row tiles, rows
     padded to whole 256-row tiles per position: the bottleneck's form) against F.conv2d."""
