@@ -84,6 +84,9 @@ bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int
 // conv_pw_ares.hip: ... on the persistent A-resident kernel (K = 128 / 256)
 bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_source, int flush_ktiles, int bn_tile);
 
+// conv_patch.hip: 3x3 convs with 16 / 32 input channels (the deep stem) on the persistent LDS-patch kernel
+bool conv_patch_eligible(const ConvDesc& d, const ConvArgs& a);
+
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
 // tiles per sub-grid (th x tw), tile count and its padding to whole `gran`-row GEMM tiles (128; 256 when the position
 // GEMMs run on a 256-row kernel)

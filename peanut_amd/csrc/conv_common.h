@@ -44,6 +44,7 @@ struct ConvKParams {
   float alpha;                // y = relu(alpha * acc * scale + shift + res): 1 / the pack scale of fp16-piece weights, else 1
   int ares_pbn;               // conv_pw_ares_kernel: the n-tile the weights were packed with (64 / 128)
   int phase_shift;            // conv_pw_glds256_kernel: waves 4-7 request their LDS-DMA pieces half an iteration after waves 0-3
+  int p_order;                // conv_pw_glds256p_kernel: item order (option pw256p_order)
   int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*
 };
 
@@ -71,6 +72,8 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
 int launch_conv_pw_ares(const ConvKParams& p, int bn_tile, hipStream_t stream);
 // conv_pw256p.hip: persistent 256 x 128 kernel (p.ntiles = 128-wide n-tiles)
 int launch_conv_pw256p(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream);
+// conv_patch.hip: persistent LDS-patch kernel for the 3x3 convs with 16 / 32 input channels (gate: conv_patch_eligible)
+int launch_conv_patch(const ConvKParams& p, const ConvDesc& d, int B, hipStream_t stream);
 // gemm_rs.hip: pointwise layer / grouped GEMM emulated on the bf16 matrix cores: fp32 A (p.x, p.x2) split into bf16 pieces in
 // registers, p.w = the weights' pre-split pieces, nkt = cin / 16
 int launch_gemm_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, size_t ws_floats, hipStream_t stream);

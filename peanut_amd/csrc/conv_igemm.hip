@@ -357,6 +357,7 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   }
   if (d.bk == 32 && p.ntaps == 1 && p.pad == 0 && p.c1 % 32 == 0 && p.c2 % 32 == 0 && (p.c2 == 0 || p.stride == 1) && conv_pw_enabled())
     return launch_conv_pw(p, d.bn_tile, a.ws, a.ws_floats, stream);
+  if (conv_patch_eligible(d, a)) return launch_conv_patch(p, d, a.B, stream);
   {
     static const char* const names[2][3] = {{"conv_igemm_128x128x32", "conv_igemm_128x64x32", "conv_igemm_128x32x32"},
                                             {"conv_igemm_128x128x16", "conv_igemm_128x64x16", "conv_igemm_128x32x16"}};

@@ -83,7 +83,10 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
     PItem it;
     int tile;
     if (i < nf) {
-      tile = lw * nf + i;
+      // p_order: the G/8 workgroups of an XCD take consecutive tiles of the XCD's run at every step -- co-resident workgroups
+      // then share A panels (n fastest) and walk the weights together, as a tile-per-workgroup launch does; else one
+      // contiguous run per workgroup (each A panel fetched once per n-tile: 2.7 x the algorithmic traffic at N = 512)
+      tile = p.p_order ? (lw / (G >> 3)) * (nf * (G >> 3)) + i * (G >> 3) + lw % (G >> 3) : lw * nf + i;
       it.kt0 = 0; it.kt1 = p.nkt; it.part = -1;
     } else {
       const int s = sp0 + (i - nf);
@@ -459,6 +462,7 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
   p.mtiles = mtiles;
   p.nchunk = (int)opt(OPT_NCHUNK);
   p.phase_shift = opt(OPT_PW256_PHASE) != 0;
+  p.p_order = opt(OPT_PW256P_ORDER) != 0;
   note_kernel("conv_pw_glds_256x128p");
   if (p.mt_per_group) p.mt_per_group /= 2;       // 256-row tiles per weight group
   const bool ragged = p.M % 256 != 0;

@@ -19,8 +19,8 @@
 namespace peanut {
 
 enum OptionId {
-  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW_ARES,
-  OPT_PW_ARES_MINUNITS, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
+  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW_ARES,
+  OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
   OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES,
@@ -45,8 +45,10 @@ inline const OptionInfo* option_table() {
       {"pw256p_mink", 512, false, "fewest input channels for the persistent 256 x 128 kernel (conv_pw256p.hip; 0: off)"},
       {"pw256p_mintiles", 512, false, "fewest 256 x 128 tiles for that kernel"},
       {"pw256p_flush", 512, false, "most input channels of a Winograd position GEMM (two-level accumulation) that runs on the persistent kernel (0: none)"},
+      {"pw256p_order", 1, false, "persistent 256 x 128 kernel: 1 = the workgroups of an XCD walk its run of tiles side by side (neighbours share operand panels in L2), 0 = one contiguous run per workgroup"},
       {"pw_ares", 1, false, "K = 128 / 256 pointwise layers on the persistent A-resident kernel (conv_pw_ares.hip)"},
       {"pw_ares_minunits", 512, false, "fewest (m-tile, n-tile) units for that kernel"},
+      {"patch_mintiles", 1024, false, "3x3 convs of 16 / 32 input channels on the persistent LDS-patch kernel (conv_patch.hip) from this many 8 x 16 output tiles (0: off)"},
       {"bn64_maxk", 256, true, "128 x 64 tiles for layers with at most this many input channels"},
       {"fp32_bk", 0, true, "16: force 16-channel k-tiles in conv_igemm (experiment)"},
       {"nchunk", 8, false, "n-tiles per chunk of the tile order (0: n fastest over all n-tiles)"},

@@ -300,6 +300,64 @@ def test_pw256p_kernel_grouped_winograd_gemm_with_two_level_accumulation(case):
     assert float((y - y2).abs().max()) <= 2e-5
 
 
+# conv_patch.hip: the stem's 3x3 convs on the persistent LDS-patch kernel.  patch_mintiles = 1 sends every eligible shape to it;
+# the cases cover all four instantiations, ragged widths / heights (16-column x 8-row output tiles hanging over both
+# edges), odd input sizes under stride 2, more tiles than CUs (the double-buffered patch ring and the deferred epilogue
+# run several rounds) and a single tile.
+PATCH_CASES = [
+    # (B, H, W, cin, cout, stride, relu, expected family)
+    (2, 96, 96, 14, 32, 2, True, "conv_patch_16x32s2"),       # stem.0: 14 -> 16 channels, stride 2
+    (3, 101, 75, 14, 32, 2, True, "conv_patch_16x32s2"),      # odd sizes: Ho = 51, Wo = 38
+    (2, 64, 64, 16, 32, 1, False, "conv_patch_16x32s1"),
+    (4, 120, 120, 32, 32, 1, True, "conv_patch_32x32s1"),     # stem.3: 480 tiles
+    (2, 50, 37, 32, 32, 1, True, "conv_patch_32x32s1"),       # ragged both ways
+    (4, 120, 120, 32, 64, 1, True, "conv_patch_32x64s1"),     # stem.6
+    (1, 7, 9, 32, 64, 1, False, "conv_patch_32x64s1"),        # a single, mostly empty tile
+    (1, 33, 250, 32, 64, 1, True, "conv_patch_32x64s1"),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_patch_kernel_matches_torch_and_the_igemm_kernel(case):
+    """conv_patch_kernel against F.conv2d (2e-5 relative) and BIT FOR BIT against conv_igemm_kernel on the same layer (same
+    fragment layout and k order: tap outer, 8-channel groups inside)."""
+    from peanut_amd.ops import FusedConv, to_nhwc_padded, round_up
+    B, H, W, cin, cout, s, relu, family = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.conv2d(x, w, None, stride=s, padding=1) * scale[None, :, None, None] + shift[None, :, None, None]
+    if relu:
+        ref = F.relu(ref)
+    xd = to_nhwc_padded(x.cuda(), round_up(cin, 16))
+    y = FusedConv(w, scale, shift, stride=s, padding=1, relu=relu, conv_algo="direct", options={"patch_mintiles": 1})(xd)
+    assert _last_kernel() == family, _last_kernel()
+    y0 = FusedConv(w, scale, shift, stride=s, padding=1, relu=relu, conv_algo="direct", options={"patch_mintiles": 0})(xd)
+    assert _last_kernel().startswith("conv_igemm_"), _last_kernel()
+    assert torch.equal(y, y0), f"differs from conv_igemm by {(y - y0).abs().max().item():.3e}"
+    out = y.permute(0, 3, 1, 2).cpu()
+    err = (out - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+def test_patch_kernel_lets_nan_and_inf_through():
+    """Out-of-image taps come from the zero page, not from a multiplication by a mask: an Inf next to the border stays an Inf
+    (and does not turn its neighbours' padding into NaN); a NaN input reaches exactly the outputs whose window holds it."""
+    from peanut_amd.ops import FusedConv
+    g = torch.Generator().manual_seed(3)
+    x = _rand((1, 40, 40, 32), g)
+    x[0, 0, 0, 5] = float("inf")
+    x[0, 20, 20, 7] = float("nan")
+    w = _rand((64, 32, 3, 3), g, 0.1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1)
+    y = FusedConv(w, None, None, padding=1, conv_algo="direct", options={"patch_mintiles": 1})(x.cuda()).cpu()
+    assert _last_kernel() == "conv_patch_32x64s1"
+    assert torch.equal(torch.isnan(y), torch.isnan(ref))
+    assert torch.equal(torch.isinf(y), torch.isinf(ref))
+
+
 def test_pw256_kernel_grouped_winograd_gemm():
     """The 36 grouped position GEMMs of a Winograd conv on the 256 x 128 kernel (mt_per_group in 256-row tiles, rows
     padded to whole 256-row tiles per position: the bottleneck's form) against F.conv2d."""
