@@ -86,6 +86,10 @@ bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_sour
 
 // conv_patch.hip: 3x3 convs with 16 / 32 input channels (the deep stem) on the persistent LDS-patch kernel
 bool conv_patch_eligible(const ConvDesc& d, const ConvArgs& a);
+const char* conv_patch_kernel_name(const ConvDesc& d, bool nchw);
+// ... and its NCHW variant: the network's first conv (16 padded channels, stride 2) straight from the caller's [B][creal][H][W] input
+bool conv_patch_nchw_eligible(const ConvDesc& d, int B, int Ho, int Wo, int creal);
+int launch_conv_patch_nchw(const ConvDesc& d, const float* x_nchw, int creal, float* y, int B, int H, int W, int Ho, int Wo, hipStream_t stream);
 
 // ---- Winograd F(4x4,3x3) transforms around the GEMM kernel (winograd.hip) ----
 // tiles per sub-grid (th x tw), tile count and its padding to whole `gran`-row GEMM tiles (128; 256 when the position

@@ -337,6 +337,13 @@ inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
   int th, tw;
   long long n_tiles, m_pad;
   wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, 256, L.wino_m);
+  // ... unless whole 256-row tiles pad the positions by more than a twentieth over 128-row ones (four 480 x 480 maps, F(5x5) at
+  // dilation 4: 576 tiles per position -> 768 rows against 640): the 128-row kernels then execute less
+  {
+    long long n128, m128;
+    wino_geometry(B, H, W, L.d.dil, &th, &tw, &n128, &m128, 128, L.wino_m);
+    if (m_pad * 20 > m128 * 21) return 128;
+  }
   const ConvDesc& g = L.wino;
   const long long np = L.wino_np();
   if (g.rs) return gemm_rs_uses_256(g.cout, np * m_pad, (int)(m_pad / 128), g.bn_tile, g.cin) ? 256 : 128;

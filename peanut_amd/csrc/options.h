@@ -20,10 +20,10 @@ namespace peanut {
 
 enum OptionId {
   OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW_ARES,
-  OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
+  OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
-  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES,
+  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES,
   OPT_COUNT
 };
 
@@ -49,6 +49,7 @@ inline const OptionInfo* option_table() {
       {"pw_ares", 1, false, "K = 128 / 256 pointwise layers on the persistent A-resident kernel (conv_pw_ares.hip)"},
       {"pw_ares_minunits", 512, false, "fewest (m-tile, n-tile) units for that kernel"},
       {"patch_mintiles", 1024, false, "3x3 convs of 16 / 32 input channels on the persistent LDS-patch kernel (conv_patch.hip) from this many 8 x 16 output tiles (0: off)"},
+      {"stem_nchw", 1, false, "prediction forward: the first stem conv reads the NCHW input itself (conv_patch.hip, NCHW variant) instead of a layout pass + NHWC conv (fp32 mode, when the patch kernel takes the layer)"},
       {"bn64_maxk", 256, true, "128 x 64 tiles for layers with at most this many input channels"},
       {"fp32_bk", 0, true, "16: force 16-channel k-tiles in conv_igemm (experiment)"},
       {"nchunk", 8, false, "n-tiles per chunk of the tile order (0: n fastest over all n-tiles)"},
@@ -69,6 +70,7 @@ inline const OptionInfo* option_table() {
       {"wino_narrow_minpix", 100000, false, "layers under 128 channels take their Winograd form from this many input pixels on"},
       {"ppm_overlap", -1, false, "pyramid branch of the PSP head on a side stream: 0 / 1, -1 = by size"},
       {"ppm_grouped", -1, false, "per-scale PSP GEMMs as one grouped launch: 0 / 1, -1 = by size"},
+      {"ppm_term_rows", 1, false, "folded pyramid term: one wave per output row, no barrier in the row loop (0: the workgroup-wide two-phase kernel)"},
       {"rcnn_wino_m", 0, true, "detector front end: 4 / 5 / 6 pins one Winograd form (0: per shape)"},
       {"rcnn_stem_s2d", 1, true, "detector stem 7x7 stride 2 as a space-to-depth 4x4 conv"},
       {"fmm_local32", 1, false, "goal solver: single-precision local solve inside a tile"},

@@ -31,7 +31,7 @@ const char* noted_kernel() { return g_kernel; }
 
 namespace {
 
-enum OpKind { OP_TO_NHWC, OP_CONV, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE, OP_WINO_IN, OP_WINO_GEMM, OP_WINO_OUT };
+enum OpKind { OP_TO_NHWC, OP_CONV, OP_CONV_NCHW, OP_MAXPOOL, OP_PPM_POOL, OP_PPM_UP, OP_PPM_TERM, OP_UPSAMPLE, OP_WINO_IN, OP_WINO_GEMM, OP_WINO_OUT };
 
 struct Op {
   OpKind kind;
@@ -219,7 +219,13 @@ std::unique_ptr<ConvLayer> build_grouped(const std::vector<ConvLayer*>& parts, c
 }
 
 // the kernel symbol family launch_conv will pick (conv_igemm.hip: launch_conv)
-std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long long M = 0, int mt_per_group = 0) {
+std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long long M = 0, int mt_per_group = 0, const Act* out = nullptr,
+                             bool has_res = false) {
+  if (out && !two_source && !has_res) {      // conv_patch.hip: the stem's 3x3 convs
+    ConvArgs a{};
+    a.B = out->B; a.Ho = out->H; a.Wo = out->W;
+    if (conv_patch_eligible(d, a)) return conv_patch_kernel_name(d, false);
+  }
   if (d.rs == 2) return std::string(d.s_planes == 3 ? "conv_rs6_128x" : (d.s_planes == 4 ? "conv_rs3h_128x" : "conv_rs3_128x")) + std::to_string(d.bn_tile);
   if (d.rs) return gemm_rs_kernel_name(d.cout, M, mt_per_group, d.bn_tile, d.cin, d.s_planes);
   if (d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
@@ -273,7 +279,7 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
   }
   Op op;
   op.kind = OP_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
-  op.kernel = conv_kernel_name(L->d, in2 != nullptr, (long long)out.B * out.H * out.W, 0);
+  op.kernel = conv_kernel_name(L->d, in2 != nullptr, (long long)out.B * out.H * out.W, 0, &out, res != nullptr);
   if (in2) { op.in2 = *in2; op.has_in2 = true; }
   if (res) { op.res = *res; op.has_res = true; }
   op.flops = conv_flops(L, out);
@@ -295,9 +301,15 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
   pl->splitk.bytes = kSplitKScratchFloats * sizeof(float);
   pl->splitk.off = ar.alloc(pl->splitk.bytes);
   pl->splitk.B = pl->splitk.H = pl->splitk.W = 1; pl->splitk.C = 0;
-  // input layout change: NCHW -> NHWC, channels zero-padded to a multiple of 16
-  Act x = make_act(ar, B, H, W, h->cin_pad);
-  {
+  // input layout change: NCHW -> NHWC, channels zero-padded to a multiple of 16 -- unless the first stem conv reads the NCHW
+  // input itself (conv_patch.hip, option stem_nchw): one pass over the input instead of two and a half
+  const ConvDesc& d0 = h->stem[0]->d;
+  const int ho0 = conv_out_dim(H, d0.kh, d0.stride, d0.pad, d0.dil), wo0 = conv_out_dim(W, d0.kw, d0.stride, d0.pad, d0.dil);
+  const bool nchw_stem = conv_patch_nchw_eligible(d0, B, ho0, wo0, h->cfg.in_channels);
+  Act x{};
+  x.B = B; x.H = H; x.W = W; x.C = h->cin_pad;
+  if (!nchw_stem) {
+    x = make_act(ar, B, H, W, h->cin_pad);
     Op op; op.kind = OP_TO_NHWC; op.name = "nchw_to_nhwc"; op.kernel = "nchw_to_nhwc"; op.out = x;
     op.bytes = (double)B * H * W * h->cfg.in_channels * 4.0 + (double)x.bytes;      // HBM-bound: read NCHW, write padded NHWC
     pl->ops.push_back(op);
@@ -308,9 +320,17 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
     const ConvDesc& d = h->stem[i]->d;
     Act y = make_act(ar, B, conv_out_dim(x.H, d.kh, d.stride, d.pad, d.dil),
                      conv_out_dim(x.W, d.kw, d.stride, d.pad, d.dil), d.cout);
-    push_conv(*pl, h->stem[i], x, nullptr, nullptr, y);
+    if (i == 0 && nchw_stem) {
+      Op op; op.kind = OP_CONV_NCHW; op.name = h->stem[0]->name; op.kernel = conv_patch_kernel_name(d, true); op.conv = h->stem[0];
+      op.in = x; op.out = y;
+      op.flops = conv_flops(h->stem[0], y);
+      op.bytes = (double)B * H * W * h->cfg.in_channels * 4.0 + (double)y.bytes + (double)conv_packed_floats(d.cin, d.cout, d.kh, d.kw, d.bn_tile) * 4;
+      pl->ops.push_back(op);
+    } else {
+      push_conv(*pl, h->stem[i], x, nullptr, nullptr, y);
+    }
     pl->named["stem" + std::to_string(i)] = y;
-    rel(x);
+    if (!(i == 0 && nchw_stem)) rel(x);
     x = y;
   }
   {
@@ -527,6 +547,8 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
   switch (op.kind) {
     case OP_TO_NHWC:
       return launch_nchw_to_nhwc_pad(in_dev, P(op.out), pl.B, h->cfg.in_channels, pl.H, pl.W, h->cin_pad, s);
+    case OP_CONV_NCHW:
+      return launch_conv_patch_nchw(op.conv->d, in_dev, h->cfg.in_channels, P(op.out), pl.B, pl.H, pl.W, op.out.H, op.out.W, s);
     case OP_CONV: {
       ConvArgs a{};
       a.x = P(op.in);

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "options.h"
 
 namespace peanut {
 
@@ -520,6 +521,104 @@ __global__ __launch_bounds__(256) void ppm_conv_term_lds_kernel(const float* __r
   }
 }
 
+// The same evaluation with ONE WAVE PER OUTPUT ROW and no workgroup barrier inside the row loop (round 4).  The kernel above
+// runs its two phases workgroup-wide: two __syncthreads per row (120 per workgroup), 288 and 480 work items on 256 threads
+// (second passes 12 % / 87 % full) -- 0.28 ms for the headline's 236 MB of output, 0.12 of the HBM rate.  Here each of the 16
+// waves owns whole rows: it folds the vertical taps of its row into a wave-private S buffer (288 items over 64 lanes) and
+// evaluates the row from it (480 items), lanes in lock step, LDS operations of a wave executing in issue order -- the waves
+// drift freely, LDS reads of one overlap the arithmetic of another.  Same arithmetic, operation by operation: bit-identical.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void ppm_conv_term_rows_kernel(const float* __restrict__ Q, float* __restrict__ R,
+                                                                     int H, int W, int C, PpmScales sc, int B, int nbins,
+                                                                     int align_corners) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int CH = 32;
+  float* q = reinterpret_cast<float*>(lds_raw);            // [nbins][9][CH]
+  BlTap* taps = reinterpret_cast<BlTap*>(lds_raw + (size_t)nbins * 9 * CH * sizeof(float));   // [n][2][L+2]
+  const int L = (H > W ? H : W) + 2;
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  {
+    int base = 0;
+    for (int s = 0; s < sc.n; ++s) {
+      const int k = sc.s[s], cells = k * k;
+      const float* src = Q + (ppm_row0(sc, s, base, B) + (size_t)b * cells) * (9 * C) + c0;
+      for (int i = threadIdx.x; i < cells * 9 * (CH / 4); i += blockDim.x) {
+        const int v4 = i % (CH / 4), rt = i / (CH / 4);
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)rt * C + v4 * 4);
+        *reinterpret_cast<float4*>(q + ((size_t)(base * 9 + rt)) * CH + v4 * 4) = v;
+      }
+      base += cells;
+    }
+  }
+  for (int i = threadIdx.x; i < sc.n * 2 * L; i += blockDim.x) {
+    const int s = i / (2 * L), r = i - s * 2 * L, dim = r / L, t = r - dim * L;
+    const int n = dim == 0 ? H : W, coord = t - 1;
+    BlTap tp;
+    tp.i0 = -1; tp.i1 = -1; tp.l = 0.f;
+    if ((unsigned)coord < (unsigned)n) {
+      int i0, i1;
+      float l;
+      bilinear_src(coord, sc.s[s], n, align_corners, &i0, &i1, &l);
+      tp.i0 = (short)i0; tp.i1 = (short)i1; tp.l = l;
+    }
+    taps[i] = tp;
+  }
+  __syncthreads();
+  int slots = 0;
+  for (int s = 0; s < sc.n; ++s) slots += sc.s[s];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* srow = reinterpret_cast<float*>(taps + (size_t)sc.n * 2 * L) + (size_t)wave * slots * 3 * CH;    // this wave's [slots][3][CH]
+  const int rows_per = (H + gridDim.z - 1) / gridDim.z;
+  const int y_begin = blockIdx.z * rows_per, y_end = min(H, y_begin + rows_per);
+  for (int yy = y_begin + wave; yy < y_end; yy += NW) {
+    for (int i = lane; i < slots * 3 * (CH / 4); i += 64) {
+      const int g = i % (CH / 4), r = i / (CH / 4), dx = r % 3, slot = r / 3;
+      int s = 0, gx = slot, base = 0;
+      while (gx >= sc.s[s]) { gx -= sc.s[s]; base += sc.s[s] * sc.s[s]; ++s; }
+      const int k = sc.s[s];
+      const BlTap* ty = taps + (s * 2 + 0) * L + yy;
+      const float* qs = q + (size_t)base * 9 * CH + g * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const BlTap t = ty[dy];
+        if (t.i0 < 0) continue;
+        const float hy = 1.f - t.l;
+        const float4 v0 = *reinterpret_cast<const float4*>(qs + ((t.i0 * k + gx) * 9 + dy * 3 + dx) * CH);
+        const float4 v1 = *reinterpret_cast<const float4*>(qs + ((t.i1 * k + gx) * 9 + dy * 3 + dx) * CH);
+        acc.x += hy * v0.x + t.l * v1.x; acc.y += hy * v0.y + t.l * v1.y;
+        acc.z += hy * v0.z + t.l * v1.z; acc.w += hy * v0.w + t.l * v1.w;
+      }
+      *reinterpret_cast<float4*>(srow + (size_t)r * CH + g * 4) = acc;
+    }
+    // the wave's own S row: written above, read below by other lanes of the SAME wave
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int it = lane; it < W * (CH / 4); it += 64) {
+      const int g = it % (CH / 4), xx = it / (CH / 4);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int slot0 = 0;
+      for (int s = 0; s < sc.n; ++s) {
+        const BlTap* tx = taps + (s * 2 + 1) * L + xx;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const BlTap t = tx[dx];
+          if (t.i0 < 0) continue;
+          const float hx = 1.f - t.l;
+          const float4 v0 = *reinterpret_cast<const float4*>(srow + ((size_t)(slot0 + t.i0) * 3 + dx) * CH + g * 4);
+          const float4 v1 = *reinterpret_cast<const float4*>(srow + ((size_t)(slot0 + t.i1) * 3 + dx) * CH + g * 4);
+          acc.x += hx * v0.x + t.l * v1.x; acc.y += hx * v0.y + t.l * v1.y;
+          acc.z += hx * v0.z + t.l * v1.z; acc.w += hx * v0.w + t.l * v1.w;
+        }
+        slot0 += sc.s[s];
+      }
+      *reinterpret_cast<float4*>(R + (((size_t)b * H + yy) * W + xx) * C + c0 + g * 4) = acc;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the row's S reads, before the next row overwrites the buffer
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, const int* scales, int nscales,
                          int align_corners, hipStream_t s, int scale_rows) {
   if (nscales <= 8 && C % 32 == 0) {
@@ -533,6 +632,24 @@ int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, c
     for (int i = 0; i < nscales; ++i) slots += scales[i];
     const size_t lds = (size_t)nbins * 9 * 32 * sizeof(float) + (size_t)nscales * 2 * L * sizeof(BlTap) +
                        (size_t)slots * 3 * 32 * sizeof(float);
+    // one wave per row (16 waves, each with its own S buffer), when that fits LDS and the option allows
+    constexpr int ROWS_NW = 16;
+    const size_t lds_rows = lds + (size_t)(ROWS_NW - 1) * slots * 3 * 32 * sizeof(float);
+    if (lds_rows <= 150 * 1024 && opt(OPT_PPM_TERM_ROWS) != 0) {
+      static bool raised_rows = false;
+      if (!raised_rows) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppm_conv_term_rows_kernel<ROWS_NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return fail(-3, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        raised_rows = true;
+      }
+      int row_splits = (256 + (C / 32) * B - 1) / ((C / 32) * B);      // one workgroup per CU: aim at >= 256 workgroups
+      row_splits = std::max(1, std::min(row_splits, H / ROWS_NW > 0 ? H / ROWS_NW : 1));
+      hipLaunchKernelGGL(ppm_conv_term_rows_kernel<ROWS_NW>, dim3(C / 32, B, row_splits), dim3(64 * ROWS_NW), lds_rows, s, Q, R, H, W, C,
+                         sc, B, nbins, align_corners);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? 0 : fail(-3, std::string("ppm_conv_term_rows: ") + hipGetErrorString(e));
+    }
     if (lds <= 150 * 1024) {    // the (1,2,3,6) pyramid needs 66 KB at 60x60: above the 64 KB default limit
       static bool raised = false;
       if (!raised) {

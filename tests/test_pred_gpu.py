@@ -316,14 +316,74 @@ def test_b4_480_forward_matches_reference_golden(golden_dir):
         m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
         got = m.get_prediction_batch(xd, apply_sigmoid=False).cpu().numpy()[:, :, 1::4, 2::4]
         err = float(np.abs(got - ref).max())
-        names = [n for n, *_ in m.model.profile(xd)]
+        rows = m.model.profile(xd)
+        names = [n for n, *_ in rows]
         print(f"{precision}: four 480x480 maps vs the reference golden max-abs {err:.3e}")
         assert err <= TOL, precision
-        if precision == "fp32":     # (the emulated modes pad a position's rows to 256 here and stay on F(4x4) at this batch)
+        if precision == "fp32":
+            # the stem runs on the LDS-patch kernels (round 4), its first conv straight from the NCHW input: no layout pass
+            fam = {n: k for n, k, *_ in rows}
+            assert "nchw_to_nhwc" not in fam, list(fam)[:4]
+            assert fam["backbone.stem.0"] == "conv_patch_nchw_16x32s2" and fam["backbone.stem.3"] == "conv_patch_32x32s1" \
+                and fam["backbone.stem.6"] == "conv_patch_32x64s1", [(n, k) for n, k in fam.items() if "stem" in n]
             for layer in ("layer4.1.conv2", "layer4.2.conv2"):
                 assert any(n.endswith(layer + "[wino5_gemm]") for n in names), [n for n in names if layer in n]
             assert any(n.endswith("bottleneck.conv[x][wino6_gemm]") for n in names), [n for n in names if "bottleneck.conv[x]" in n]
         del m
+
+
+def test_pyramid_term_row_kernel_is_bit_identical(golden_dir):
+    """The folded pyramid term (csrc/pspnet_aux.hip) evaluated with one wave per output row (round 4, option ppm_term_rows = 1:
+    no workgroup barrier in the row loop) against the workgroup-wide two-phase kernel: the same operations in the same order,
+    so the logits agree bit for bit -- on the 240 x 240 golden input, an odd size, a rectangle and a batch of three."""
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    m1 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, options={"ppm_term_rows": 1})
+    m0 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, options={"ppm_term_rows": 0})
+    inputs = [torch.from_numpy(z[f"{c}/input"].astype(np.float32)) for c in ("cfg1_240", "odd_100", "rect_72x104")]
+    g = torch.Generator().manual_seed(5)
+    inputs.append((torch.rand((3, 14, 200, 200), generator=g) > 0.7).float())
+    for x in inputs:
+        a = m1.get_prediction_batch(x.cuda(), apply_sigmoid=False)
+        b = m0.get_prediction_batch(x.cuda(), apply_sigmoid=False)
+        assert torch.equal(a, b), float((a - b).abs().max())
+    err = np.abs(m1.get_prediction_batch(inputs[0].cuda(), apply_sigmoid=False).cpu().numpy() - z["cfg1_240/logits"]).max()
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("options,stem0", [({"patch_mintiles": 1}, "conv_patch_nchw_16x32s2"),
+                                           ({"patch_mintiles": 1, "stem_nchw": 0}, "conv_patch_16x32s2"),
+                                           ({"patch_mintiles": 0}, "conv_igemm_128x32x16")])
+def test_stem_kernel_variants_match_reference_goldens(golden_dir, options, stem0):
+    """The stem on the persistent LDS-patch kernels (csrc/conv_patch.hip; gate opened for every size), with its first conv
+    reading the NCHW input itself or an NHWC copy, and on the implicit-GEMM kernels: every case of the reference-generated
+    golden file (240 x 240, odd / rectangular sizes -- tiles hanging over both edges --, 25 input channels -> 32 padded: the
+    NCHW variant does not apply there), same tolerance; the three stacks agree to 2e-5 on the logits."""
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    cases = sorted({k.split("/")[0] for k in z.files if "/" in k})
+    models = {}
+    for case in cases:
+        c_in, seed = int(z[f"{case}/c_in"]), int(z[f"{case}/weight_seed"])
+        if (c_in, seed) not in models:
+            cfg = PredCfg(in_channels=c_in)
+            models[(c_in, seed)] = PEANUT_Prediction_Model(
+                SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg, seed), cfg=cfg, options=options)
+        m = models[(c_in, seed)]
+        x = torch.from_numpy(z[f"{case}/input"].astype(np.float32)).cuda()
+        got = m.get_prediction_batch(x, apply_sigmoid=False).cpu().numpy()
+        err = np.abs(got - z[f"{case}/logits"]).max()
+        assert err <= TOL, f"{case}: max err {err:.3e}"
+        fam = {n: k for n, k, *_ in m.model.profile(x)}
+        if c_in <= 16:
+            assert fam["backbone.stem.0"] == stem0, (case, fam["backbone.stem.0"])
+            assert ("nchw_to_nhwc" in fam) == (not stem0.startswith("conv_patch_nchw")), case
+        if options["patch_mintiles"]:
+            assert fam["backbone.stem.3"] == "conv_patch_32x32s1" and fam["backbone.stem.6"] == "conv_patch_32x64s1", case
 
 
 @pytest.mark.parametrize("tile", [5, 6])
