@@ -39,25 +39,29 @@ struct PatchCfg {
   static constexpr int NW = (TH / 2) * NWN, NT = 64 * NW;                 // waves, threads
   static constexpr int PH = (TH - 1) * STRIDE + 3, PW = (TW - 1) * STRIDE + 3;
   static constexpr int LS = CIN + 4, SLOTS = LS / 4;                      // floats / 16-byte slots per patch pixel (one pad slot)
+  // patch row pitch: a multiple of 64 floats, so that the second row of a wave's 2 x 16-pixel block starts on the bank the 17th
+  // pixel of a straight run would (16 * LS = 0 mod 64): the 16-lane groups of a ds_read_b128 then see 16 distinct bank quads
+  static constexpr int RP = (PW * LS + 63) / 64 * 64, RSLOTS = RP / 4;
   static constexpr int NPX = PH * PW;                                     // pixels of a patch
-  static constexpr int NS = NPX * SLOTS;                                  // 16-byte slots of a patch
+  static constexpr int NS = PH * RSLOTS;                                  // 16-byte slots of a patch (pitch padding included)
   static constexpr int NP = (NS + NT - 1) / NT;                           // LDS-DMA instructions per wave and patch
   static constexpr int PATCH_FLOATS = NP * NT * 4;
-  static constexpr int W_FLOATS = 9 * BN * LS;
   static constexpr int NI = BN / 32 / NWN, NJ = CIN / 8;
+  static constexpr int JH = 2, HS = NJ / JH, STEPS = 9 * HS;              // a step = JH 8-channel groups of one tap
   static constexpr int NPK = (NPX + NT - 1) / NT;                         // NCHW variant: patch pixels per thread
-  static constexpr int SMEM_FLOATS = W_FLOATS + DBUF * PATCH_FLOATS;
+  static constexpr int SMEM_FLOATS = DBUF * PATCH_FLOATS;
 };
 
 // NCHW: p.x is the network input [B][creal][H][W] (creal <= 16 real channels); else NHWC [B][H][W][CIN]
 template <int CIN, int BN, int STRIDE, int TH, int NWN, int DBUF, bool NCHW>
 __global__ __launch_bounds__(64 * (TH / 2) * NWN) void conv_patch_kernel(const ConvKParams p, int tiles_x, int tiles_y, int n_tiles, int creal) {
   using C = PatchCfg<CIN, BN, STRIDE, TH, NWN, DBUF>;
-  constexpr int LS = C::LS, PW = C::PW, NI = C::NI, NJ = C::NJ, NP = C::NP, NW = C::NW, NT = C::NT, NPK = C::NPK;
+  constexpr int LS = C::LS, PW = C::PW, PH = C::PH, RP = C::RP, NI = C::NI, NJ = C::NJ, NP = C::NP, NW = C::NW, NT = C::NT, NPK = C::NPK;
+  constexpr int JH = C::JH, HS = C::HS, STEPS = C::STEPS;
   static_assert(!NCHW || CIN == 16, "the NCHW variant stages 16 channels per pixel");
   static_assert(DBUF == 2 || DBUF == 1, "patch buffers");
+  static_assert(NJ % JH == 0 && 16 % STEPS != 1 && STEPS >= 8, "step layout");
   __shared__ __attribute__((aligned(1024))) float smem[C::SMEM_FLOATS];
-  float* const wsm = smem + DBUF * C::PATCH_FLOATS;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,11 +74,16 @@ __global__ __launch_bounds__(64 * (TH / 2) * NWN) void conv_patch_kernel(const C
   int tile = lw;
   if (tile >= n_tiles) return;
 
-  // ---- weights -> LDS, once: packed [tap][BN][CIN] (pack_conv_weights with bk = CIN: k-tile = tap) -> [tap][BN][LS] ----
-  for (int i = tid; i < 9 * BN * (CIN / 4); i += NT) {
-    const int row = i / (CIN / 4), c4 = i - row * (CIN / 4);
-    *reinterpret_cast<f32x4*>(wsm + row * LS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.w + (size_t)i * 4);
-  }
+  // ---- this lane's weight fragments, ALL taps, in registers for the life of the workgroup: packed [tap][BN][CIN]
+  //      (pack_conv_weights with bk = CIN: k-tile = tap); lane (li, hi) holds channels 8 j + 4 hi .. + 3 of output row li ----
+  f32x4 bw[9][NJ][NI];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int u = 0; u < NI; ++u)
+        bw[t][j][u] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(t * BN + (wn * NI + u) * 32 + li)) * CIN + j * 8 + hi * 4);
 
   const unsigned long long zero_addr = (unsigned long long)p.zeros;
   auto tile_origin = [&](int t, int* b, int* oy0, int* ox0) __attribute__((always_inline)) {
@@ -86,36 +95,44 @@ __global__ __launch_bounds__(64 * (TH / 2) * NWN) void conv_patch_kernel(const C
     *ox0 = (r - ty * tiles_x) * C::TW;
   };
 
-  // ---- NHWC: this lane's patch slots; piece j of wave w covers slots (j * NW + w) * 64 .. + 63 (1 KiB of LDS per instruction) ----
-  int s_py[NP], s_px[NP], s_c[NP];     // patch pixel (row, column) and channel offset of the slot; s_c < 0: pad slot / past the end
+  // ---- NHWC: this lane's patch slots; piece j of wave w covers slots (j * NW + w) * 64 .. + 63 (1 KiB of LDS per instruction).
+  //      s_pos = patch row << 16 | patch column, or -1 for a pad slot; s_off = the slot's float offset from the patch origin ----
+  int s_pos[NP], s_off[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const int s = (j * NW + wave) * 64 + lane;
-    const int pp = s / C::SLOTS, c = s - pp * C::SLOTS;
-    s_py[j] = pp / PW;
-    s_px[j] = pp - s_py[j] * PW;
-    s_c[j] = (s < C::NS && c < C::SLOTS - 1) ? c * 4 : -1;
+    const int py = s / C::RSLOTS, rem = s - py * C::RSLOTS;
+    const int px = rem / C::SLOTS, c = rem - px * C::SLOTS;
+    const bool ok = py < PH && px < PW && c < C::SLOTS - 1;
+    s_pos[j] = ok ? (py << 16 | px) : -1;
+    s_off[j] = (py * p.W + px) * CIN + c * 4;
   }
-  auto request = [&](int t, float* buf) __attribute__((always_inline)) {
-    int b, oy0, ox0;
-    tile_origin(t, &b, &oy0, &ox0);
+  auto request = [&](int b, int oy0, int ox0, float* buf) __attribute__((always_inline)) {
     const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
-    const float* img = p.x + (size_t)b * p.H * p.W * CIN;
+    const float* origin = p.x + ((size_t)b * p.H * p.W + (long long)iy0 * p.W + ix0) * CIN;      // may lie before the image: used with in-range offsets only
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PH <= p.H && ix0 + PW <= p.W;              // uniform
+    if (interior) {
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int iy = iy0 + s_py[j], ix = ix0 + s_px[j];
-      const bool ok = s_c[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned long long a = (unsigned long long)(img + ((size_t)iy * p.W + ix) * CIN + s_c[j]);
-      const unsigned long long m = ok ? ~0ull : 0ull;
-      __builtin_amdgcn_global_load_lds((gptr_t)((a & m) | (zero_addr & ~m)), (lptr_t)(buf + (j * NW + wave) * 256), 16, 0, 0);
+      for (int j = 0; j < NP; ++j) {
+        const unsigned long long a = (unsigned long long)(origin + s_off[j]);
+        const unsigned long long m = s_pos[j] >= 0 ? ~0ull : 0ull;
+        __builtin_amdgcn_global_load_lds((gptr_t)((a & m) | (zero_addr & ~m)), (lptr_t)(buf + (j * NW + wave) * 256), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int iy = iy0 + (s_pos[j] >> 16), ix = ix0 + (s_pos[j] & 0xffff);
+        const bool ok = s_pos[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned long long a = (unsigned long long)(origin + s_off[j]);
+        const unsigned long long m = ok ? ~0ull : 0ull;
+        __builtin_amdgcn_global_load_lds((gptr_t)((a & m) | (zero_addr & ~m)), (lptr_t)(buf + (j * NW + wave) * 256), 16, 0, 0);
+      }
     }
   };
 
   // ---- NCHW: thread t stages patch pixels t, t + NT, ...: sixteen channel values each, one load per plane ----
   float stg[NCHW ? NPK : 1][16];
-  auto load_regs = [&](int t) __attribute__((always_inline)) {
-    int b, oy0, ox0;
-    tile_origin(t, &b, &oy0, &ox0);
+  auto load_regs = [&](int b, int oy0, int ox0) __attribute__((always_inline)) {
     const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
     const size_t plane = (size_t)p.H * p.W;
     const float* img = p.x + (size_t)b * creal * plane;
@@ -138,40 +155,44 @@ __global__ __launch_bounds__(64 * (TH / 2) * NWN) void conv_patch_kernel(const C
 #pragma unroll
     for (int k = 0; k < (NCHW ? NPK : 1); ++k) {
       const int pp = tid + NT * k;
+      const int py = pp / PW, px = pp - py * PW;
       if (pp < C::NPX) {
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4)
-          *reinterpret_cast<f32x4*>(buf + pp * LS + c4 * 4) = f32x4{stg[k][c4 * 4], stg[k][c4 * 4 + 1], stg[k][c4 * 4 + 2], stg[k][c4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(buf + py * RP + px * LS + c4 * 4) = f32x4{stg[k][c4 * 4], stg[k][c4 * 4 + 1], stg[k][c4 * 4 + 2], stg[k][c4 * 4 + 3]};
       }
     }
   };
 
   // ---- MFMA fragment coordinates: row li of the wave's 32-pixel block = tile pixel (2 * wp + li / 16, li % 16) ----
   const int trow = 2 * wp + (li >> 4), tcol = li & 15;
-  const int a_base = ((trow * STRIDE) * PW + tcol * STRIDE) * LS + hi * 4;
-  const int b_base = (wn * NI * 32 + li) * LS + hi * 4;
+  const int a_base = (trow * STRIDE) * RP + (tcol * STRIDE) * LS + hi * 4;
 
-  f32x16 acc[NI], prev[NI];
+  // two accumulator chains per output block (even / odd k-steps of a group): consecutive MFMAs never depend on each other, so an
+  // LDS read or a store issued between them costs an issue slot, not the dependent-accumulator latency
+  f32x16 acc0[NI], acc1[NI], prev[NI];
 #pragma unroll
   for (int u = 0; u < NI; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[u][r] = 0.f; prev[u][r] = 0.f; }
-  bool prev_valid = false;
-  int prev_b = 0, prev_oy0 = 0, prev_ox0 = 0;
+    for (int r = 0; r < 16; ++r) { acc0[u][r] = 0.f; acc1[u][r] = 0.f; prev[u][r] = 0.f; }
+  bool prev_valid = false, prev_full = false;
+  int prev_oy0 = 0, prev_ox0 = 0;
+  float* prev_out = p.y;         // this lane's first output element of the previous tile: pixel (oy0 + 2 wp, ox0 + 4 hi), its first column
 
   // scale / shift of this lane's columns (gate: cout == BN)
   float sc[NI], sh[NI];
 #pragma unroll
   for (int u = 0; u < NI; ++u) { sc[u] = p.scale[(wn * NI + u) * 32 + li] * p.alpha; sh[u] = p.shift[(wn * NI + u) * 32 + li]; }
   const bool relu = p.relu != 0;
+  const int row_pitch = p.Wo * BN;
 
-  // accumulator register r = block row (r & 3) + 8 * (r >> 2) + 4 * hi -> tile pixel; a wave instruction writes two pixels x 32
-  // consecutive channels = two whole 128-byte lines
+  // accumulator register r = block row (r & 3) + 8 * (r >> 2) + 4 * hi -> tile pixel (2 wp + (r >> 3), (r & 3) + 8 * ((r >> 2) & 1) + 4 hi);
+  // a wave instruction writes two pixels x 32 consecutive channels = two whole 128-byte lines
   auto store_prev_row = [&](int r) __attribute__((always_inline)) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    const int oy = prev_oy0 + 2 * wp + (row >> 4), ox = prev_ox0 + (row & 15);
-    if (oy < p.Ho && ox < p.Wo) {
-      float* o = p.y + (((size_t)prev_b * p.Ho + oy) * p.Wo + ox) * BN + wn * NI * 32 + li;
+    const int rr = r >> 3, cc = (r & 3) + 8 * ((r >> 2) & 1);
+    float* o = prev_out + (rr ? row_pitch : 0) + cc * BN;
+    const bool ok = prev_full || (prev_oy0 + 2 * wp + rr < p.Ho && prev_ox0 + 4 * hi + cc < p.Wo);
+    if (ok) {
 #pragma unroll
       for (int u = 0; u < NI; ++u) {
         float v = prev[u][r] * sc[u] + sh[u];
@@ -181,51 +202,60 @@ __global__ __launch_bounds__(64 * (TH / 2) * NWN) void conv_patch_kernel(const C
     }
   };
 
-  if constexpr (NCHW) load_regs(tile);
-  else if constexpr (DBUF == 2) request(tile, smem);
+  int cb, coy, cox;                       // origin of the current tile
+  tile_origin(tile, &cb, &coy, &cox);
+  if constexpr (NCHW) load_regs(cb, coy, cox);
+  else if constexpr (DBUF == 2) request(cb, coy, cox, smem);
   int cur = 0;
   for (; tile < n_tiles; tile += G) {
     const bool more = tile + G < n_tiles;
+    int nb = 0, noy = 0, nox = 0;
+    if (more) tile_origin(tile + G, &nb, &noy, &nox);
     float* const patch_w = smem + cur * C::PATCH_FLOATS;
     if constexpr (DBUF == 2 && !NCHW) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's patch (the stores of the previous tile are long gone)
       __syncthreads();                                    // every wave's pieces have landed; the other buffer is free
-      if (more) request(tile + G, smem + (cur ^ 1) * C::PATCH_FLOATS);
     } else {
       if constexpr (DBUF == 1) __syncthreads();           // everybody is done with the previous tile's patch
       if constexpr (NCHW) {
         write_regs(patch_w);
-        if (more) load_regs(tile + G);
+        if (more) load_regs(nb, noy, nox);
       } else {
-        request(tile, patch_w);
+        request(cb, coy, cox, patch_w);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
     }
     const float* const patch = patch_w;
-    __builtin_amdgcn_sched_barrier(0);
 
-    f32x4 af[2][NJ], bf[2][NJ][NI];
-#define PATCH_READ(set, tap)                                                                                          \
-  _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                    \
-    af[set][j] = *reinterpret_cast<const f32x4*>(patch + a_base + (((tap) / 3) * PW + (tap) % 3) * LS + j * 8);        \
-    _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                                    \
-      bf[set][j][u] = *reinterpret_cast<const f32x4*>(wsm + b_base + ((tap) * BN + u * 32) * LS + j * 8);             \
-  }
-#define PATCH_MFMA(set)                                                                                               \
-  _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                      \
+    f32x4 af[2][JH];
+#define PATCH_READ(set, step)                                                                                         \
+  _Pragma("unroll") for (int jj = 0; jj < JH; ++jj)                                                                   \
+    af[set][jj] = *reinterpret_cast<const f32x4*>(patch + a_base + (((step) / HS) / 3) * RP + (((step) / HS) % 3) * LS + (((step) % HS) * JH + jj) * 8);
+#define PATCH_MFMA(set, step)                                                                                         \
+  _Pragma("unroll") for (int jj = 0; jj < JH; ++jj)                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                                  \
-      _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                                  \
-        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][j][kk], bf[set][j][u][kk], acc[u], 0, 0, 0);
+      _Pragma("unroll") for (int u = 0; u < NI; ++u) {                                                                \
+        if ((kk & 1) == 0) acc0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][jj][kk], bw[(step) / HS][((step) % HS) * JH + jj][u][kk], acc0[u], 0, 0, 0); \
+        else acc1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][jj][kk], bw[(step) / HS][((step) % HS) * JH + jj][u][kk], acc1[u], 0, 0, 0); \
+      }
     PATCH_READ(0, 0)
-    static_for<9>([&](auto T) __attribute__((always_inline)) {
-      constexpr int tap = decltype(T)::value;
-      if constexpr (tap + 1 < 9) { PATCH_READ((tap + 1) & 1, tap + 1) }
+    static_for<STEPS>([&](auto T) __attribute__((always_inline)) {
+      constexpr int step = decltype(T)::value;
+      if constexpr (step + 1 < STEPS) { PATCH_READ((step + 1) & 1, step + 1) }
+      if constexpr (step == 0 && DBUF == 2 && !NCHW) {
+        if (more) request(nb, noy, nox, smem + (cur ^ 1) * C::PATCH_FLOATS);   // under the first MFMAs, not ahead of them
+      }
       __builtin_amdgcn_sched_barrier(0);
-      PATCH_MFMA(tap & 1)
+      PATCH_MFMA(step & 1, step)
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (tap < 8) {
-        if (prev_valid) { store_prev_row(2 * tap); store_prev_row(2 * tap + 1); }
+      // the previous tile's 16 accumulator rows leave spread over the steps
+      constexpr int R0 = step * 16 / STEPS, R1 = (step + 1) * 16 / STEPS;
+      if constexpr (R1 > R0) {
+        if (prev_valid) {
+#pragma unroll
+          for (int r = R0; r < R1; ++r) store_prev_row(r);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     });
@@ -233,12 +263,15 @@ __global__ __launch_bounds__(64 * (TH / 2) * NWN) void conv_patch_kernel(const C
 #undef PATCH_MFMA
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-      prev[u] = acc[u];
+      prev[u] = acc0[u] + acc1[u];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc0[u][r] = 0.f; acc1[u][r] = 0.f; }
     }
-    tile_origin(tile, &prev_b, &prev_oy0, &prev_ox0);
+    prev_oy0 = coy; prev_ox0 = cox;
+    prev_full = coy + TH <= p.Ho && cox + C::TW <= p.Wo;
+    prev_out = p.y + (((size_t)cb * p.Ho + coy + 2 * wp) * p.Wo + cox + 4 * hi) * BN + wn * NI * 32 + li;
     prev_valid = true;
+    cb = nb; coy = noy; cox = nox;
     if constexpr (DBUF == 2) cur ^= 1;
   }
 #pragma unroll
