@@ -59,6 +59,8 @@ struct ConvArgs {
   int mt_per_group;        // grouped GEMM: 128-row m-tile mt reads weight block mt / mt_per_group (0 = single block)
   size_t w_group_stride;   // floats between weight blocks (bytes for the pre-split weights of a register-split layer)
   int ss_group_stride;     // floats between the scale (and shift) blocks of the weight groups (0: one block for all)
+  int group_valid_rows;    // grouped GEMM: rows of each group that hold data, the rest up to the group's whole tiles being zero padding
+                           // (Winograd positions: tiles before padding); 0 = unknown / all.  A kernel may skip work on the padding.
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 partial 128x128 tiles and then some

@@ -287,11 +287,26 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
   // head of every k-tile.  Calibrated on the bare loop (tools/micro/pw256_loop.hip, profiles/r5a): 132-136 -> 143 TF/s
   // (no requests at all: 149); spreading the requests between the MFMAs instead: 120.
   const bool late = p.phase_shift && wave >= 4;
+  // Grouped GEMM whose groups end in zero padding (Winograd positions: 3 200 tiles in 13 x 256 rows): a wave whose 64 rows are
+  // all padding reads no fragments and issues no MFMAs -- its SIMD then carries one wave instead of two and the tile takes
+  // about half the time.  The wave keeps requesting its share of the k-tiles and meets every barrier; its accumulators stay zero.
+  const bool idle = p.group_valid > 0 && p.mt_per_group > 0 && (mt % p.mt_per_group) * BM + wm * TM >= p.group_valid;
 #define PW256_MFMA_GROUP(j)                                                                               \
   _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                        \
     _Pragma("unroll") for (int t = 0; t < MI; ++t)                                                        \
       _Pragma("unroll") for (int u = 0; u < NI; ++u)                                                      \
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][t][kk], bf[j][u][kk], acc[t][u], 0, 0, 0);
+  if (idle) {
+    // no fragments, no MFMAs: this wave only keeps the ring going (its share of every k-tile's requests, every barrier)
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      if (more) PW256_DMA_TILE(smem + o_fill);
+      if (more) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      PW256_BARRIER();
+      { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+    }
+  } else {
   for (int kt = 0; kt < nk; ++kt) {
     const float* const cur = smem + o_cur;
     const bool more = kt + 2 < nk;
@@ -317,6 +332,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256_kernel(const ConvKParams 
     else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     PW256_BARRIER();
     { const int t = o_cur; o_cur = o_mid; o_mid = o_fill; o_fill = t; }
+  }
   }
 #undef PW256_DMA_TILE
 #undef PW256_BARRIER
@@ -505,6 +521,7 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
     ConvKParams q = p;
     if (q.mt_per_group) q.mt_per_group /= 2;       // 256-row tiles per weight group
     q.phase_shift = phase_shift_w;
+    if (opt(OPT_PW256_SKIP_PAD) == 0) q.group_valid = 0;
     note_kernel("conv_pw_glds_256x128");
     return launch_with_tail_split<decltype(&conv_pw_glds256_kernel), 256, 128, 512>(&conv_pw_glds256_kernel, q, ws, ws_floats, stream,
                                                                                      &slots256);

@@ -337,12 +337,13 @@ inline int wino_gran_for(const ConvLayer& L, int B, int H, int W) {
   int th, tw;
   long long n_tiles, m_pad;
   wino_geometry(B, H, W, L.d.dil, &th, &tw, &n_tiles, &m_pad, 256, L.wino_m);
-  // ... unless whole 256-row tiles pad the positions by more than a twentieth over 128-row ones (four 480 x 480 maps, F(5x5) at
-  // dilation 4: 576 tiles per position -> 768 rows against 640): the 128-row kernels then execute less
+  // ... unless whole 256-row tiles pad the positions by more than an eighth over 128-row ones (four 480 x 480 maps, F(5x5) at
+  // dilation 4: 576 tiles per position -> 768 rows against 640): the 128-row kernels then execute less.  (Sixteen maps' PSP
+  // bottleneck, 1 600 tiles -> 1 792 against 1 664, stays on the 256-row kernel: faster per row, and its waves skip padding rows.)
   {
     long long n128, m128;
     wino_geometry(B, H, W, L.d.dil, &th, &tw, &n128, &m128, 128, L.wino_m);
-    if (m_pad * 20 > m128 * 21) return 128;
+    if (m_pad * 8 > m128 * 9) return 128;
   }
   const ConvDesc& g = L.wino;
   const long long np = L.wino_np();

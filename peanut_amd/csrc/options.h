@@ -19,7 +19,7 @@
 namespace peanut {
 
 enum OptionId {
-  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW_ARES,
+  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW_ARES,
   OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
@@ -40,6 +40,7 @@ inline const OptionInfo* option_table() {
       {"pw256_mink", 1024, false, "fewest input channels for the 256 x 128 three-stage kernel"},
       {"pw256_mintiles", 256, false, "fewest 256 x 128 tiles for that kernel"},
       {"pw256_phase", 1, false, "the two waves of a SIMD request their LDS-DMA pieces half an iteration apart"},
+      {"pw256_skip_pad", 1, false, "256 x 128 kernel, grouped GEMMs: waves whose rows are all group padding issue no MFMAs (0: compute the zero rows)"},
       {"pw256w_mink", 768, false, "fewest input channels for the 256 x 256 two-stage kernel (0: off)"},
       {"pw256w_mintiles", 1536, false, "fewest 256 x 256 tiles for that kernel"},
       {"pw256p_mink", 512, false, "fewest input channels for the persistent 256 x 128 kernel (conv_pw256p.hip; 0: off)"},

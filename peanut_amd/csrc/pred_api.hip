@@ -43,6 +43,7 @@ struct Op {
   double flops = 0;
   double bytes = 0;            // algorithmic HBM bytes: every operand read once, the result written once
   int wino_mt_per_group = 0;   // OP_WINO_GEMM: 128-row tiles per Winograd position
+  int wino_valid_rows = 0;     // OP_WINO_GEMM: tiles per position before the padding to whole GEMM tiles
   int wino_gran = 128;         // row padding of the Winograd position GEMMs
   // two-stream schedule of the PSP head (build_plan): branch 1 ops run on the handle's side stream; the first of them
   // waits for everything enqueued so far on the caller's stream (fork), join_before makes the caller's stream wait for
@@ -263,7 +264,7 @@ void push_conv(Plan& pl, const ConvLayer* L, const Act& in, const Act* in2, cons
     a.bytes = (double)in.bytes + np * (double)n_tiles * in.C * 4.0;
     pl.ops.push_back(a);
     Op g; g.kind = OP_WINO_GEMM; g.name = L->name + tag + "gemm]"; g.kernel = conv_kernel_name(L->wino, false, npl * m_pad, (int)(m_pad / 128)); g.conv = L;
-    g.in = v; g.in.W = (int)(npl * m_pad); g.in.C = in.C; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran;
+    g.in = v; g.in.W = (int)(npl * m_pad); g.in.C = in.C; g.out = m; g.wino_mt_per_group = (int)(m_pad / 128); g.wino_gran = gran; g.wino_valid_rows = (int)n_tiles;
     g.flops = 2.0 * np * (double)m_pad * L->d.cout * L->cin_real;     // executed, not the direct-form count
     g.bytes = np * (double)m_pad * (in.C * 4.0 + L->d.cout * 4.0) +
               np * (rs_gemm ? (double)L->wino_group_bytes : (double)L->wino_group_floats * 4);
@@ -574,6 +575,7 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
       a.B = 1; a.H = 1; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = 1; a.Wo = op.in.W;
       a.ws = P(op.branch ? pl.splitk2 : pl.splitk); a.ws_floats = kSplitKScratchFloats;
       a.mt_per_group = op.wino_mt_per_group;
+      a.group_valid_rows = op.wino_valid_rows;
       a.w_group_stride = op.conv->wino.rs ? op.conv->wino_group_bytes : op.conv->wino_group_floats;
       return launch_conv(op.conv->wino, a, s);
     }

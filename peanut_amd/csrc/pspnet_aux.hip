@@ -10,6 +10,7 @@
 //   models/segmentors/encoder_decoder.py:75-79 resize(out, size=img.shape[2:], bilinear)
 //   nav/agent/prediction.py:158               scipy.special.expit (optional fused sigmoid)
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "options.h"
@@ -163,15 +164,23 @@ struct PpmSlots { short x0[PPM_MAX_SLOTS], x1[PPM_MAX_SLOTS]; int n; };
 // a segment lies inside at most one bin-column per scale.  Per segment: a branch-free run of 16-byte loads summed in
 // registers, then ONE round of (wave-uniform) slot tests -- per pixel the loop is a load and four adds.
 struct PpmSegs { short x0[2 * PPM_MAX_SLOTS], x1[2 * PPM_MAX_SLOTS]; unsigned mask[2 * PPM_MAX_SLOTS]; int n; };
+// Row groups (round 4): runs of at most PPM_GROUP_ROWS consecutive rows that lie inside ONE bin-row of every scale (between two
+// consecutive y edges of the pyramid).  A workgroup of the row pass adds up a whole group, so the intermediate holds one
+// partial per group instead of one per row (60 rows of a 480 x 480 map's feature map: 12 groups of 5) -- the second pass reads
+// a fifth of the bytes, and the row pass writes a fifth.
+#define PPM_MAX_GROUPS 128
+#define PPM_GROUP_ROWS 5
+struct PpmGroups { short y0[PPM_MAX_GROUPS], y1[PPM_MAX_GROUPS]; int n; };
 
 __global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict__ x, float* __restrict__ rowsum, int H,
-                                                         int W, int C, PpmSlots sl, PpmSegs sg) {
-  const int y = blockIdx.x, b = blockIdx.y;
+                                                         int W, int C, PpmSlots sl, PpmSegs sg, PpmGroups gr) {
+  const int grp = blockIdx.x, b = blockIdx.y;
   const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
   if (c >= C) return;
   float4 acc[PPM_MAX_SLOTS];
 #pragma unroll
   for (int s = 0; s < PPM_MAX_SLOTS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int y = gr.y0[grp]; y < gr.y1[grp]; ++y) {
   const float* row = x + (((size_t)b * H + y) * W) * C + c;
   for (int g = 0; g < sg.n; ++g) {
     const int x0 = sg.x0[g], x1 = sg.x1[g];
@@ -198,14 +207,15 @@ __global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict
     for (int s = 0; s < PPM_MAX_SLOTS; ++s)
       if ((m >> s) & 1u) { acc[s].x += a.x; acc[s].y += a.y; acc[s].z += a.z; acc[s].w += a.w; }
   }
-  float* out = rowsum + (((size_t)b * H + y) * sl.n) * C + c;
+  }
+  float* out = rowsum + (((size_t)b * gr.n + grp) * sl.n) * C + c;
 #pragma unroll
   for (int s = 0; s < PPM_MAX_SLOTS; ++s)
     if (s < sl.n) *reinterpret_cast<float4*>(out + (size_t)s * C) = acc[s];
 }
 
 __global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict__ rowsum, float* __restrict__ out, int H,
-                                                         int W, int C, PpmScales sc, int nslots) {
+                                                         int W, int C, PpmScales sc, int nslots, PpmGroups gr) {
   const int bin = blockIdx.x, b = blockIdx.y;
   const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
   if (c >= C) return;
@@ -221,8 +231,9 @@ __global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict
   const int y0 = (by * H) / k, y1 = ((by + 1) * H + k - 1) / k;
   const int x0 = (bx * W) / k, x1 = ((bx + 1) * W + k - 1) / k;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int yy = y0; yy < y1; ++yy) {
-    const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)b * H + yy) * nslots + slot0 + bx) * C + c);
+  for (int g = 0; g < gr.n; ++g) {                       // the groups inside this bin's rows (a group never straddles a bin edge)
+    if (gr.y0[g] < y0 || gr.y1[g] > y1) continue;
+    const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)b * gr.n + g) * nslots + slot0 + bx) * C + c);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   const float cnt = (float)((y1 - y0) * (x1 - x0));
@@ -278,9 +289,40 @@ int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, i
       ++sg.n;
     }
   }
+  // row groups: cut [0, H) at every bin-row edge of every scale, then into runs of at most PPM_GROUP_ROWS rows
+  PpmGroups gr;
+  gr.n = 0;
   const int slabs = (C / 4 + 255) / 256;
-  hipLaunchKernelGGL(ppm_rowsum_kernel, dim3(H, B, slabs), dim3(256), 0, s, x, scratch, H, W, C, sl, sg);
-  hipLaunchKernelGGL(ppm_binsum_kernel, dim3(nbins, B, slabs), dim3(256), 0, s, scratch, out, H, W, C, sc, sl.n);
+  // rows per group: as many as still leave ~768 workgroups for the row pass (small batches keep one row per workgroup: their
+  // pass is latency-bound, not traffic-bound)
+  const int group_rows = std::max(1, std::min(PPM_GROUP_ROWS, (int)((long long)H * B * slabs / 768)));
+  {
+    std::vector<int> edges;
+    for (int i = 0; i < nscales; ++i)
+      for (int by = 0; by < scales[i]; ++by) {
+        edges.push_back((by * H) / scales[i]);
+        edges.push_back(((by + 1) * H + scales[i] - 1) / scales[i]);
+      }
+    edges.push_back(0);
+    edges.push_back(H);
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    bool fits = true;
+    for (size_t i = 0; i + 1 < edges.size() && fits; ++i)
+      for (int y = edges[i]; y < edges[i + 1]; y += group_rows) {
+        if (gr.n >= PPM_MAX_GROUPS) { fits = false; break; }
+        gr.y0[gr.n] = (short)y;
+        gr.y1[gr.n] = (short)std::min(y + group_rows, edges[i + 1]);
+        ++gr.n;
+      }
+    if (!fits) {                      // very tall maps: one row per group (the scratch is sized for H rows)
+      if (H > PPM_MAX_GROUPS) return launch_ppm_pool(x, out, B, H, W, C, scales, nscales, s, scale_rows);
+      gr.n = H;
+      for (int y = 0; y < H; ++y) { gr.y0[y] = (short)y; gr.y1[y] = (short)(y + 1); }
+    }
+  }
+  hipLaunchKernelGGL(ppm_rowsum_kernel, dim3(gr.n, B, slabs), dim3(256), 0, s, x, scratch, H, W, C, sl, sg, gr);
+  hipLaunchKernelGGL(ppm_binsum_kernel, dim3(nbins, B, slabs), dim3(256), 0, s, scratch, out, H, W, C, sc, sl.n, gr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(-3, std::string("ppm_pool2: ") + hipGetErrorString(e));
 }
