@@ -55,6 +55,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // PACK = rows of one packed weight tile (the layer's bn_tile: 128 or 64); the n-tile of the kernel may be wider (256 = two
 // packed tiles) or narrower (64 rows of a 128-row packed tile)
+// (Round 4, profiles/r5q / r5y: the waves of the 256 x 256 kernel sit 41 % of their time at s_waitcnt / s_barrier; a four-stage
+// variant that read TWO k-tiles per barrier and requested the next two at the top of the iteration -- half the barriers, the same
+// lead time -- was slower, 1 642 -> 1 588 maps/s in fp16x3: the waits are for operands arriving, not for the barrier itself.)
 template <int BM, int BN, int WM, int WN, int KIND, int PACK>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams p) {
   constexpr int NP = rs_pieces(KIND);
@@ -205,6 +208,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   if (more) { RS_WAIT_ALL_BUT_LAST_TILE(); RS_BARRIER(); }          \
   else { RS_DMA_LANDED_BARRIER(); }
 
+  ResPrefetch rp;
+  rp.on = false;
+  u32x4 ap[MI][NP], bf[NP][NI];
   RS_DMA_TILE(smem);
   if (nk > 1) {
     RS_DMA_TILE(smem + STAGE);
@@ -213,10 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_rs_kernel(const ConvKParams
   } else {
     RS_DMA_LANDED_BARRIER();
   }
-  ResPrefetch rp;
-  rp.on = false;
   int o_cur = 0, o_fill = 2 * STAGE, o_mid = STAGE;
-  u32x4 ap[MI][NP], bf[NP][NI];
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* const cur = smem + o_cur;
     const bool more = kt + 2 < nk;
