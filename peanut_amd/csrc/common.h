@@ -68,7 +68,7 @@ constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 parti
 inline int conv_out_dim(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 
 // choose (bn_tile, bk) for a layer
-void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk);
+void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk, bool pointwise = false);
 // host-side packing: w is OIHW [cout][cin_real][kh][kw]; returns floats written
 size_t conv_packed_floats(int cin_pad, int cout, int kh, int kw, int bn_tile);
 void pack_conv_weights(const float* w_oihw, int cout, int cin_real, int cin_pad, int kh, int kw,
@@ -81,6 +81,8 @@ bool conv_pw_uses_256(int cout, long long M, int mt_per_group, int bn_tile, int 
 int conv_pw_256_min_k();
 // conv_pw.hip: ... on the 256 x 256 two-stage kernel (flush_ktiles: k-tiles per partial sum of the two-level accumulation, 0 = none)
 bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
+// conv_pw.hip: a 128-wide-packed short-K layer on 128 x 64 tiles (few tiles: batch-1 shapes)
+bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_per_group);
 // conv_pw256p.hip: ... on the persistent 256 x 128 kernel (epilogue of the previous tile inside the next tile's k-loop)
 bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
 // conv_pw_ares.hip: ... on the persistent A-resident kernel (K = 128 / 256)

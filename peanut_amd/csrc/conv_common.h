@@ -44,6 +44,7 @@ struct ConvKParams {
   float alpha;                // y = relu(alpha * acc * scale + shift + res): 1 / the pack scale of fp16-piece weights, else 1
   int ares_pbn;               // conv_pw_ares_kernel: the n-tile the weights were packed with (64 / 128)
   int phase_shift;            // conv_pw_glds256_kernel: waves 4-7 request their LDS-DMA pieces half an iteration after waves 0-3
+  int pack_bn;                // conv_pw_glds_kernel: rows of a PACKED weight tile when wider than the kernel's n-tile (128 for the 64-wide kernel on 128-wide packing); 0 = the kernel's
   int group_valid;            // grouped GEMM: rows of every weight group that hold data (the rest of the group's rows is padding); 0 = all
   int p_order;                // conv_pw_glds256p_kernel: item order (option pw256p_order)
   int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*

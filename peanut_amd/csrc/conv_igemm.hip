@@ -277,7 +277,7 @@ const float* zero_page() {
   return pages[dev];
 }
 
-void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk) {
+void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk, bool pointwise) {
   const int forced_bk = (int)opt(OPT_FP32_BK);
   *bk = (cin_pad % 32 == 0) ? 32 : 16;
   if (forced_bk == 16) *bk = 16;   // experiment knob: 3 workgroups/CU instead of 2 in the fp32 kernel
@@ -286,7 +286,9 @@ void conv_pick_tiles(int cin_pad, int cout, int* bn_tile, int* bk) {
   // time goes to the epilogue's memory phases (output + residual per few k-tiles), which more resident workgroups
   // overlap better.  Measured (profiles/r2h): layer1 conv3 0.37 -> 0.30 ms, layer2 conv3 0.24 -> 0.20, layer3 conv3
   // 0.645 -> 0.573; larger K loses (the matrix-core share grows).  Option bn64_maxk overrides the threshold.
-  const int bn64_maxk = (int)opt(OPT_BN64_MAXK);
+  // Pointwise layers (round 4): only up to pw_bn64_maxk (128) channels are PACKED 64 wide; a 129..256-channel layer is packed 128
+  // wide and launch_conv_pw picks the 64-wide tile per shape (conv_pw_glds_kernel<64> reads halves of the 128-row packed tiles).
+  const int bn64_maxk = (int)opt(pointwise ? OPT_PW_BN64_MAXK : OPT_BN64_MAXK);
   if (*bn_tile == 128 && cin_pad <= bn64_maxk) *bn_tile = 64;
 }
 

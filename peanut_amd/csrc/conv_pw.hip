@@ -74,8 +74,11 @@ void conv_pw_glds_kernel(const ConvKParams p) {
   int to_switch = p.c2 ? p.c1 / BK - wk.kt0 : 0x7fffffff;     // k-tiles until the A source changes (<= 0: already on x2)
   const float* b_src[B_INSTR];
   {
+    // the n-tile may be a part of a wider PACKED tile (64 columns of a 128-row tile): k-tiles are then pack rows apart
+    const int pack = p.pack_bn > BN ? p.pack_bn : BN;
+    const int n_row = nt * BN;
     const float* wtile = p.w + (p.mt_per_group ? (size_t)(mt / p.mt_per_group) * p.w_group_stride : 0) +
-                         ((size_t)nt * p.nkt + wk.kt0) * (BN * BK);
+                         ((size_t)(n_row / pack) * p.nkt + wk.kt0) * ((size_t)pack * BK) + (size_t)(n_row % pack) * BK;
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
       const int r = (wave * B_INSTR + j) * 8 + lr;
@@ -83,6 +86,7 @@ void conv_pw_glds_kernel(const ConvKParams p) {
       b_src[j] = wtile + r * BK + c * 4;
     }
   }
+  const int b_step = (p.pack_bn > BN ? p.pack_bn : BN) * BK;
 #define PEANUT_DMA_TILE(stage)                                                                                   \
   {                                                                                                              \
     if (to_switch-- == 0) {                                                                                      \
@@ -94,7 +98,7 @@ void conv_pw_glds_kernel(const ConvKParams p) {
     }                                                                                                            \
     _Pragma("unroll") for (int j = 0; j < B_INSTR; ++j) {                                                        \
       __builtin_amdgcn_global_load_lds((gptr_t)b_src[j], (lptr_t)((stage) + A_FLOATS + (wave * B_INSTR + j) * 256), 16, 0, 0); \
-      b_src[j] += BN * BK;                                                                                       \
+      b_src[j] += b_step;                                                                                        \
     }                                                                                                            \
   }
 #define PEANUT_DMA_LANDED_BARRIER()          \
@@ -501,6 +505,15 @@ bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int
          ((M + 255) / 256) * (cout / 256) >= min_tiles;
 }
 
+// A 128-wide-packed layer with few input channels (<= bn64_maxk: its time is its epilogue's traffic) runs 128 x 64 tiles -- three
+// workgroups per CU -- while the 128 x 128 tiling would not give every CU its two workgroups (one 240 x 240 map: layer3 conv3 is 64
+// tiles of 128 x 128); from pw64_maxtiles tiles on the wider tile wins (one 720 x 720 map: 512 tiles, 65 -> 50 us; profiles/r5z).
+bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_per_group) {
+  (void)mt_per_group;
+  if (bn_tile != 128 || cin > opt(OPT_BN64_MAXK) || cout % 128 != 0) return false;
+  return ((M + 127) / 128) * (cout / 128) < opt(OPT_PW64_MAXTILES);
+}
+
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
   const int phase_shift_w = opt(OPT_PW256_PHASE) != 0;
@@ -525,6 +538,13 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
     note_kernel("conv_pw_glds_256x128");
     return launch_with_tail_split<decltype(&conv_pw_glds256_kernel), 256, 128, 512>(&conv_pw_glds256_kernel, q, ws, ws_floats, stream,
                                                                                      &slots256);
+  }
+  if (conv_pw_narrow_tiles(p.c1 + p.c2, p.cout, p.M, bn_tile, p.mt_per_group)) {      // 64-wide tiles over 128-wide packing
+    ConvKParams q = p;
+    q.pack_bn = 128;
+    q.ntiles = p.ntiles * 2;
+    note_kernel("conv_pw_glds_128x64");
+    return launch_pw_t<64, 2, 2>(q, ws, ws_floats, stream);
   }
   note_kernel(bn_tile == 128 ? "conv_pw_glds_128x128" : (bn_tile == 64 ? "conv_pw_glds_128x64" : "conv_pw_glds_128x32"));
   if (bn_tile == 128) return launch_pw_t<128, 2, 2>(p, ws, ws_floats, stream);

@@ -130,7 +130,7 @@ inline int upload_conv(ConvLayer& L, const float* w_oihw, const float* scale, co
   if (cin_pad % 16 != 0 || cin_pad < cin) return fail(PEANUT_EINVAL, L.name + ": cin_pad must be a multiple of 16 and >= cin");
   ConvDesc& d = L.d;
   d.cin = cin_pad; d.cout = cout; d.kh = kh; d.kw = kw; d.stride = stride; d.pad = pad; d.dil = dil; d.relu = relu;
-  conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk);
+  conv_pick_tiles(cin_pad, cout, &d.bn_tile, &d.bk, kh == 1 && kw == 1 && pad == 0);
   // emulated-fp32 modes: the pointwise layers run on gemm_rs.hip (every other layer stays on the fp32 MFMA kernels)
   d.rs = 0;
   d.s_planes = 0;
@@ -258,7 +258,7 @@ inline int upload_wino(ConvLayer& L, const float* w_oihw, int cout, int cin, int
   L.wino_m = wino_tile_for(L.d.dil, wino_m);
   const int np = L.wino_np();
   g.cin = cin_pad; g.cout = cout; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; g.relu = 0;
-  conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk);
+  conv_pick_tiles(cin_pad, cout, &g.bn_tile, &g.bk, true);
   g.rs = 0;
   g.s_planes = 0;
   g.s_alpha = 1.f;

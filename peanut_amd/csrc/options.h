@@ -8,7 +8,7 @@
 // thread's "active" set (OptionScope); the gates in the kernel sources read opt(OPT_...).
 //
 // Options that shape the UPLOADED weights (wino_m, wino_head_m, wino6_maxdil, wino5_mindil, wino_flush_ch, wino_min_cin,
-// bn64_maxk, fp32_bk, rs_conv, rs_bn64_maxk, rcnn_wino_m, rcnn_stem_s2d) are read while a handle is created: set them as
+// bn64_maxk, pw_bn64_maxk, fp32_bk, rs_conv, rs_bn64_maxk, rcnn_wino_m, rcnn_stem_s2d) are read while a handle is created: set them as
 // defaults before the create call (the Python mirrors take `options=`); changing them on a live handle is refused.
 #pragma once
 #include <stdlib.h>
@@ -20,7 +20,7 @@ namespace peanut {
 
 enum OptionId {
   OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW_ARES,
-  OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
+  OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_PW_BN64_MAXK, OPT_PW64_MAXTILES, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
   OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES,
@@ -52,6 +52,8 @@ inline const OptionInfo* option_table() {
       {"patch_mintiles", 1024, false, "3x3 convs of 16 / 32 input channels on the persistent LDS-patch kernel (conv_patch.hip) from this many 8 x 16 output tiles (0: off)"},
       {"stem_nchw", 1, false, "prediction forward: the first stem conv reads the NCHW input itself (conv_patch.hip, NCHW variant) instead of a layout pass + NHWC conv (fp32 mode, when the patch kernel takes the layer)"},
       {"bn64_maxk", 256, true, "128 x 64 tiles for layers with at most this many input channels"},
+      {"pw_bn64_maxk", 128, true, "pointwise layers / Winograd position GEMMs: weights PACKED 64 wide up to this many input channels (wider layers: 128-wide packing, 64-wide tiles chosen per shape)"},
+      {"pw64_maxtiles", 512, false, "a 128-wide-packed pointwise layer with at most bn64_maxk input channels runs 128 x 64 tiles while its 128 x 128 tiling has fewer tiles than this (two per CU)"},
       {"fp32_bk", 0, true, "16: force 16-channel k-tiles in conv_igemm (experiment)"},
       {"nchunk", 8, false, "n-tiles per chunk of the tile order (0: n fastest over all n-tiles)"},
       {"res_prefetch", 1, false, "request the first residual rows before the last k-tile's MFMAs"},

@@ -235,8 +235,9 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long lo
     if (conv_pw_uses_ares(d.cin, d.cout, M, d.stride, two_source, flush, d.bn_tile)) return "conv_pw_ares_128x128";
     if (conv_pw_uses_256w(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush)) return "conv_pw_glds_256x256";
     if (conv_pw_uses_256p(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush)) return "conv_pw_glds_256x128p";
-    return conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin) ? std::string("conv_pw_glds_256x128")
-                                                                         : "conv_pw_glds_128x" + std::to_string(d.bn_tile);
+    if (conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return "conv_pw_glds_256x128";
+    if (conv_pw_narrow_tiles(d.cin, d.cout, M, d.bn_tile, mt_per_group)) return "conv_pw_glds_128x64";
+    return "conv_pw_glds_128x" + std::to_string(d.bn_tile);
   }
   return "conv_igemm_128x" + std::to_string(d.bn_tile) + "x" + std::to_string(d.bk);
 }

@@ -231,8 +231,15 @@ __global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict
   const int y0 = (by * H) / k, y1 = ((by + 1) * H + k - 1) / k;
   const int x0 = (bx * W) / k, x1 = ((bx + 1) * W + k - 1) / k;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int g = 0; g < gr.n; ++g) {                       // the groups inside this bin's rows (a group never straddles a bin edge)
-    if (gr.y0[g] < y0 || gr.y1[g] > y1) continue;
+  // the groups inside this bin's rows: a contiguous run (groups are sorted and never straddle a bin edge); the run is found
+  // first so that the loads below form a plain loop the compiler can keep several of in flight
+  int g0 = 0, g1 = 0;
+  for (int g = 0; g < gr.n; ++g) {
+    if (gr.y1[g] <= y0) g0 = g + 1;
+    if (gr.y0[g] < y1) g1 = g + 1;
+  }
+#pragma unroll 4
+  for (int g = g0; g < g1; ++g) {
     const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)b * gr.n + g) * nslots + slot0 + bx) * C + c);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
@@ -677,7 +684,9 @@ int launch_ppm_conv_term(const float* Q, float* R, int B, int H, int W, int C, c
     // one wave per row (16 waves, each with its own S buffer), when that fits LDS and the option allows
     constexpr int ROWS_NW = 16;
     const size_t lds_rows = lds + (size_t)(ROWS_NW - 1) * slots * 3 * 32 * sizeof(float);
-    if (lds_rows <= 150 * 1024 && opt(OPT_PPM_TERM_ROWS) != 0) {
+    // (small batches keep the kernel below: with fewer than ~256 (image, channel chunk) pairs the rows of an image have to be split
+    // over several workgroups, and every one of these 1024-thread workgroups stages the image's whole 58 KB table first)
+    if (lds_rows <= 150 * 1024 && opt(OPT_PPM_TERM_ROWS) != 0 && (long long)(C / 32) * B >= 128) {
       static bool raised_rows = false;
       if (!raised_rows) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ppm_conv_term_rows_kernel<ROWS_NW>),

@@ -809,18 +809,22 @@ def test_pointwise_kernel_families_are_bit_identical():
     switched per handle through the option API (csrc/options.h), the kernel family asserted by name."""
     from peanut_amd.ops import FusedConv
     cases = [  # (B, H, W, cin, cout, stride, residual), options of the alternative handle, family of the default / the alternative
-        ((1, 31, 29, 256, 128, 1, False), {"pw_glds": 0}, "conv_pw_glds_128x64", "conv_igemm_128x64x32"),
-        ((2, 17, 17, 256, 320, 2, False), {"pw_glds": 0}, "conv_pw_glds_128x64", "conv_igemm_128x64x32"),
+        # K = 256 layers are packed 128 wide (round 4): few tiles -> 128 x 64 tiles over halves of the packed tiles (pack_bn)
+        # (these two pairs tile the output differently, so their tail split-K plans may cut K differently: 2e-5 instead of bit equality)
+        ((1, 31, 29, 256, 128, 1, False, "close"), {"pw_glds": 0}, "conv_pw_glds_128x64", "conv_igemm_128x128x32"),
+        ((2, 17, 17, 256, 320, 2, False), {"pw_glds": 0}, "conv_pw_glds_128x128", "conv_igemm_128x128x32"),
+        ((2, 17, 17, 256, 384, 2, False, "close"), {"pw64_maxtiles": 0}, "conv_pw_glds_128x64", "conv_pw_glds_128x128"),
         ((3, 13, 13, 512, 6, 1, False), {"pw_glds": 0}, "conv_pw_glds_128x32", "conv_igemm_128x32x32"),
         ((1, 12, 12, 64, 256, 1, True), {"pw_glds": 0}, "conv_pw_glds_128x64", "conv_igemm_128x64x32"),
-        ((8, 64, 64, 256, 1024, 1, True), {"pw_ares": 0}, "conv_pw_ares_128x128", "conv_pw_glds_128x64"),
+        ((8, 64, 64, 256, 1024, 1, True), {"pw_ares": 0}, "conv_pw_ares_128x128", "conv_pw_glds_128x128"),
         ((8, 64, 64, 128, 512, 1, True), {"pw_ares": 0}, "conv_pw_ares_128x128", "conv_pw_glds_128x64"),
         ((8, 64, 64, 1024, 1024, 1, True), {"pw256w_mink": 0, "pw256p_mink": 0}, "conv_pw_glds_256x256", "conv_pw_glds_256x128"),
         ((8, 64, 64, 1024, 512, 1, True), {"pw256p_mink": 0}, "conv_pw_glds_256x128p", "conv_pw_glds_256x128"),
         ((8, 64, 64, 512, 1024, 1, True), {"pw256p_mink": 0}, "conv_pw_glds_256x128p", "conv_pw_glds_128x128"),
     ]
     for i, (case, alt, fam0, fam1) in enumerate(cases):
-        B, H, W, cin, cout, s, residual = case
+        B, H, W, cin, cout, s, residual = case[:7]
+        close = len(case) > 7
         g = torch.Generator().manual_seed(100 + i)
         x = _rand((B, H, W, cin), g).cuda()
         w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
@@ -832,7 +836,10 @@ def test_pointwise_kernel_families_are_bit_identical():
         assert _last_kernel() == fam0, (case, _last_kernel())
         y1 = FusedConv(w, None, shift, stride=s, relu=True, options={**base, **alt})(x, residual=res)
         assert _last_kernel() == fam1, (case, _last_kernel())
-        assert torch.equal(y0, y1), (case, float((y0 - y1).abs().max()))
+        if close:
+            assert float((y0 - y1).abs().max()) <= 2e-5, (case, float((y0 - y1).abs().max()))
+        else:
+            assert torch.equal(y0, y1), (case, float((y0 - y1).abs().max()))
 
 
 def test_options_are_per_handle():
@@ -851,7 +858,7 @@ def test_options_are_per_handle():
     ya = a(x)
     assert _last_kernel() == "conv_pw_ares_128x128"
     yb = b(x)
-    assert _last_kernel() == "conv_pw_glds_128x64"
+    assert _last_kernel() == "conv_pw_glds_128x128"
     a(x)
     assert _last_kernel() == "conv_pw_ares_128x128"          # a is untouched by b's option
     assert torch.equal(ya, yb)
@@ -867,7 +874,7 @@ def test_options_are_per_handle():
     _lib.check(lib.peanut_get_default_option(b"PEANUT_PW_ARES", C.byref(v)))       # the env-style spelling names the same option
     assert v.value == 1
     c(x)
-    assert _last_kernel() == "conv_pw_glds_128x64"
+    assert _last_kernel() == "conv_pw_glds_128x128"
     text = lib.peanut_option_list().decode()
     assert "pw256_mink=1024" in text and "wino_m=0 [create-time]" in text
 
