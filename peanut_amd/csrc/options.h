@@ -23,7 +23,7 @@ enum OptionId {
   OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_PW_BN64_MAXK, OPT_PW64_MAXTILES, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
-  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES,
+  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_PPM_GROUP_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES,
   OPT_COUNT
 };
 
@@ -74,6 +74,7 @@ inline const OptionInfo* option_table() {
       {"ppm_overlap", -1, false, "pyramid branch of the PSP head on a side stream: 0 / 1, -1 = by size"},
       {"ppm_grouped", -1, false, "per-scale PSP GEMMs as one grouped launch: 0 / 1, -1 = by size"},
       {"ppm_term_rows", 1, false, "folded pyramid term: one wave per output row, no barrier in the row loop (0: the workgroup-wide two-phase kernel)"},
+      {"ppm_group_rows", 0, false, "pyramid pooling, row pass: rows added up per workgroup (1..5; 0 = by size: as many as still leave ~768 workgroups)"},
       {"rcnn_wino_m", 0, true, "detector front end: 4 / 5 / 6 pins one Winograd form (0: per shape)"},
       {"rcnn_stem_s2d", 1, true, "detector stem 7x7 stride 2 as a space-to-depth 4x4 conv"},
       {"fmm_local32", 1, false, "goal solver: single-precision local solve inside a tile"},

@@ -302,7 +302,9 @@ int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, i
   const int slabs = (C / 4 + 255) / 256;
   // rows per group: as many as still leave ~768 workgroups for the row pass (small batches keep one row per workgroup: their
   // pass is latency-bound, not traffic-bound)
-  const int group_rows = std::max(1, std::min(PPM_GROUP_ROWS, (int)((long long)H * B * slabs / 768)));
+  const int forced_rows = (int)opt(OPT_PPM_GROUP_ROWS);
+  const int group_rows = forced_rows > 0 ? std::min(forced_rows, PPM_GROUP_ROWS)
+                                         : std::max(1, std::min(PPM_GROUP_ROWS, (int)((long long)H * B * slabs / 768)));
   {
     std::vector<int> edges;
     for (int i = 0; i < nscales; ++i)

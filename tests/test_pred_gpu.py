@@ -354,6 +354,32 @@ def test_pyramid_term_row_kernel_is_bit_identical(golden_dir):
     assert err <= TOL
 
 
+@pytest.mark.parametrize("rows", [2, 5])
+def test_pyramid_pooling_row_groups_match_the_row_pass(golden_dir, rows):
+    """csrc/pspnet_aux.hip, round 4: the row pass of the pyramid pooling adds up groups of rows that share every scale's bin-row
+    (option ppm_group_rows; the default picks 5 at 32 maps, 1 at small batches).  Forced here on the golden inputs -- 240 x 240
+    (30 feature rows: groups of 5 exactly), an odd size and a rectangle (13 / 9 rows: bins overlap, groups of 1-3 rows) -- the
+    pooled table against one row per workgroup (same bins, another summation order: 1e-6 relative) and the logits against the
+    reference golden."""
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    z = np.load(os.path.join(golden_dir, "pspnet_golden.npz"))
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    mg = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, options={"ppm_group_rows": rows})
+    m1 = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, options={"ppm_group_rows": 1})
+    for m in (mg, m1):
+        m.model.debug_keep(True)
+    for case in ("cfg1_240", "odd_100", "rect_72x104"):
+        x = torch.from_numpy(z[f"{case}/input"].astype(np.float32)).cuda()
+        got = mg.get_prediction_batch(x, apply_sigmoid=False).cpu().numpy()
+        tg = mg.model.debug_tensor("ppm_table").cpu()
+        m1.get_prediction_batch(x, apply_sigmoid=False)
+        t1 = m1.model.debug_tensor("ppm_table").cpu()
+        assert float((tg - t1).abs().max()) <= 1e-6 * (1.0 + float(t1.abs().max())), case
+        assert np.abs(got - z[f"{case}/logits"]).max() <= TOL, case
+
+
 @pytest.mark.parametrize("options,stem0", [({"patch_mintiles": 1}, "conv_patch_nchw_16x32s2"),
                                            ({"patch_mintiles": 1, "stem_nchw": 0}, "conv_patch_16x32s2"),
                                            ({"patch_mintiles": 0}, "conv_igemm_128x32x16")])
