@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 // y[pixel][n] = relu(scale[n] * (A^T M A)[a][b] + shift[n] + res[pixel][n])
+template <bool RES>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ res,
                                                           float* __restrict__ y, const WinoGeom g, int relu) {
@@ -159,8 +160,27 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ng * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ng * 4);
     const size_t img = (size_t)b * g.H * g.W;
+    // the residual of output column j + 1 is requested before column j is finished (see wino6_output_kernel)
+    f32x4 rn[4];
+    auto res_column = [&](int j, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+      const int c = c0 + j * g.d;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = r0 + a * g.d;
+        const bool ok = c < g.W && r < g.H;
+        const size_t off = ok ? (img + (size_t)r * g.W + c) * g.C + ng * 4 : 0;
+        dst[a] = *reinterpret_cast<const f32x4*>(res + off);
+      }
+    };
+    if constexpr (RES) res_column(0, rn);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      f32x4 rc[4];
+      if constexpr (RES) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) rc[a] = rn[a];
+        if (j + 1 < 4) res_column(j + 1, rn);
+      }
       f32x4 o0, o1, o2, o3;
       at6(q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], o0, o1, o2, o3);
       const int c = c0 + j * g.d;
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         if (r >= g.H) continue;
         const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 4;
         f32x4 v = o[a] * sc + sh;
-        if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+        if constexpr (RES) v += rc[a];
         if (relu) v = relu_keep_nan(v);
         *reinterpret_cast<f32x4*>(y + off) = v;
       }
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const float* __restric
 }
 
 // y[pixel][n] = relu(scale[n] * (A^T M A)[a][b] + shift[n] + res[pixel][n]),  M: 64 positions
+template <bool RES>
 __global__ __launch_bounds__(256) void wino6_output_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ res,
                                                            float* __restrict__ y, const WinoGeom g, int relu) {
@@ -288,8 +309,30 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const float* __restri
     const f32x2 sc = *reinterpret_cast<const f32x2*>(scale + ng * 2);
     const f32x2 sh = *reinterpret_cast<const f32x2*>(shift + ng * 2);
     const size_t img = (size_t)b * g.H * g.W;
+    // The residual of output column j + 1 is requested before column j is finished (round 4): with the loads sitting right
+    // before their use, behind the runtime `res` test, every column waited out a memory round trip -- the PSP bottleneck's
+    // transform (the only one with a residual: the folded pyramid term) ran at 3.8 TB/s against 6.0 for the same shape without.
+    // Out-of-range elements read the tensor's first element (a valid address; the value is never used).
+    f32x2 rn[6];
+    auto res_column = [&](int j, f32x2 (&dst)[6]) __attribute__((always_inline)) {
+      const int c = c0 + j * g.d;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int r = r0 + a * g.d;
+        const bool ok = c < g.W && r < g.H;
+        const size_t off = ok ? (img + (size_t)r * g.W + c) * g.C + ng * 2 : 0;
+        dst[a] = *reinterpret_cast<const f32x2*>(res + off);
+      }
+    };
+    if constexpr (RES) res_column(0, rn);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
+      f32x2 rc[6];
+      if constexpr (RES) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rc[a] = rn[a];
+        if (j + 1 < 6) res_column(j + 1, rn);
+      }
       f32x2 o[6];
       at8(q[0][j], q[1][j], q[2][j], q[3][j], q[4][j], q[5][j], q[6][j], q[7][j], o[0], o[1], o[2], o[3], o[4], o[5]);
       const int c = c0 + j * g.d;
@@ -300,7 +343,7 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const float* __restri
         if (r >= g.H) continue;
         const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 2;
         f32x2 v = o[a] * sc + sh;
-        if (res) v += *reinterpret_cast<const f32x2*>(res + off);
+        if constexpr (RES) v += rc[a];
         if (relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); }
         *reinterpret_cast<f32x2*>(y + off) = v;
       }
@@ -511,9 +554,11 @@ int launch_wino_output(const float* Mb, const float* scale, const float* shift, 
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
   const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
-  if (m == 6) hipLaunchKernelGGL(wino6_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  if (m == 6 && res) hipLaunchKernelGGL(wino6_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  else if (m == 6) hipLaunchKernelGGL(wino6_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   else if (m == 5) hipLaunchKernelGGL(wino5_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
-  else hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  else if (res) hipLaunchKernelGGL(wino_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  else hipLaunchKernelGGL(wino_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("wino_output launch: ") + hipGetErrorString(e));
   return 0;
