@@ -44,6 +44,10 @@ struct ConvKParams {
   float alpha;                // y = relu(alpha * acc * scale + shift + res): 1 / the pack scale of fp16-piece weights, else 1
   int ares_pbn;               // conv_pw_ares_kernel: the n-tile the weights were packed with (64 / 128)
   int phase_shift;            // conv_pw_glds256_kernel: waves 4-7 request their LDS-DMA pieces half an iteration after waves 0-3
+  // conv_pw_glds256p_kernel, stream-K tail (round 4): the tail's sk_units k-tiles (tail tiles x nkt) are dealt out as ONE stream of
+  // equal contiguous runs to the first sk_g workgroups; a run may end one tile and begin the next, a tile has at most sk_maxp
+  // fragments (raw partial tiles j * sk_maxp + fragment index).  sk_units = 0: the uniform split above (split_p parts per tile)
+  int sk_units, sk_maxp, sk_g;
   int pack_bn;                // conv_pw_glds_kernel: rows of a PACKED weight tile when wider than the kernel's n-tile (128 for the 64-wide kernel on 128-wide packing); 0 = the kernel's
   int group_valid;            // grouped GEMM: rows of every weight group that hold data (the rest of the group's rows is padding); 0 = all
   int p_order;                // conv_pw_glds256p_kernel: item order (option pw256p_order)
@@ -93,6 +97,14 @@ int launch_conv_rs(const ConvKParams& p, int bn_tile, int planes, float* ws, siz
 //    by conv_splitk_reduce_kernel (deterministic, no atomics).  The split parts are spread evenly over
 //    the XCD runs (they are shorter than full tiles, so lumping them on one XCD would unbalance it).
 struct Work { int mt, nt, kt0, kt1, item; };   // item >= 0: split part -> partial tile #item
+
+// stream-K tail: run of workgroup w = units [U * w / G, U * (w + 1) / G); the workgroup whose run holds unit u
+__host__ __device__ __forceinline__ int sk_owner(long long U, int G, long long u) {
+  int w = (int)(u * G / U);
+  while (w + 1 < G && U * (w + 1) / G <= u) ++w;
+  while (w > 0 && U * w / G > u) --w;
+  return w;
+}
 
 // tile -> (mt, nt).  Plain order: n fastest.  With more than `nchunk` n-tiles the n range is cut into chunks that are
 // walked one after the other (all m-tiles of chunk 0, then chunk 1, ...): the 64 workgroups resident on an XCD then
@@ -338,14 +350,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
   tile_to_mn(p, tile, &mt, &nt);
   const int m0 = mt * BM, n0 = nt * BN;
   constexpr int NV = BN / 4, SLAB = 16;
+  // partial tiles of this tail tile: split_p of them, or -- stream-K -- one per workgroup whose run touches the tile
+  int parts = p.split_p;
   const float* base = p.partial + (size_t)j * p.split_p * (BM * BN);
+  if (p.sk_units > 0) {
+    const int w0 = sk_owner(p.sk_units, p.sk_g, (long long)j * p.nkt), w1 = sk_owner(p.sk_units, p.sk_g, (long long)(j + 1) * p.nkt - 1);
+    parts = w1 - w0 + 1;
+    base = p.partial + (size_t)j * p.sk_maxp * (BM * BN);
+  }
   const bool vec_ok = (p.cout & 3) == 0;
   for (int i = threadIdx.x; i < SLAB * NV; i += 256) {
     const int row = blockIdx.y * SLAB + i / NV, c4 = (i % NV) * 4;
     const int m = m0 + row, n = n0 + c4;
     if (m >= p.M) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(base + row * BN + c4);
-    for (int s = 1; s < p.split_p; ++s) v += *reinterpret_cast<const f32x4*>(base + (size_t)s * (BM * BN) + row * BN + c4);
+    for (int s = 1; s < parts; ++s) v += *reinterpret_cast<const f32x4*>(base + (size_t)s * (BM * BN) + row * BN + c4);
     const int ss_off = (p.mt_per_group && p.ss_group_stride) ? (mt / p.mt_per_group) * p.ss_group_stride : 0;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n) * p.alpha;
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);

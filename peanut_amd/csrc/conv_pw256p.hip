@@ -77,12 +77,23 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   const int lw = (bid & 7) * (G >> 3) + (bid >> 3);                    // neighbouring runs on one XCD (G is a multiple of 8)
   const int nf = p.n_full / G;                                         // the launcher makes n_full a multiple of G
   const int sp0 = (int)((long long)p.n_sp * lw / G), sp1 = (int)((long long)p.n_sp * (lw + 1) / G);
-  const int n_items = nf + (sp1 - sp0);
+  // stream-K tail: this workgroup's run of the tail's k-tiles, as fragments of consecutive tail tiles
+  const long long skU = p.sk_units;
+  const int u0 = (skU > 0 && lw < p.sk_g) ? (int)(skU * lw / p.sk_g) : 0, u1 = (skU > 0 && lw < p.sk_g) ? (int)(skU * (lw + 1) / p.sk_g) : 0;
+  const int n_frag = u1 > u0 ? (u1 - 1) / p.nkt - u0 / p.nkt + 1 : 0;
+  const int n_items = nf + (skU > 0 ? n_frag : sp1 - sp0);
   if (n_items == 0) return;
   auto item_at = [&](int i) {
     PItem it;
     int tile;
-    if (i < nf) {
+    if (i >= nf && skU > 0) {
+      const int j = u0 / p.nkt + (i - nf);                  // tail tile of this fragment
+      const int t0 = j * p.nkt;
+      it.kt0 = (u0 > t0 ? u0 : t0) - t0;
+      it.kt1 = (u1 < t0 + p.nkt ? u1 : t0 + p.nkt) - t0;
+      it.part = j * p.sk_maxp + (lw - sk_owner(skU, p.sk_g, (long long)t0));   // fragments of a tile in workgroup order
+      tile = p.n_full + j;
+    } else if (i < nf) {
       // p_order: the G/8 workgroups of an XCD take consecutive tiles of the XCD's run at every step -- co-resident workgroups
       // then share A panels (n fastest) and walk the weights together, as a tile-per-workgroup launch does; else one
       // contiguous run per workgroup (each A panel fetched once per n-tile: 2.7 x the algorithmic traffic at N = 512)
@@ -457,6 +468,26 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
   p.split_p = sp;
   p.n_sp = t * sp;
   p.n_full = T - t;
+  // Stream-K for the tail (round 4): its t * nkt k-tiles as one stream, cut into equal runs for the first sk_g workgroups (runs of
+  // at least four k-tiles).  Against the uniform split above -- whose parts come in whole multiples per workgroup (132 tail tiles
+  // cut three ways = 396 parts over 256 workgroups: two parts for most, 21 k-tiles where 16.5 would do) -- every workgroup ends
+  // within one k-tile of the others.  A tile then has up to sk_maxp fragments; the reduce sums them in workgroup order.
+  p.sk_units = 0; p.sk_maxp = 0; p.sk_g = 0;
+  // (only for tails of at least a quarter of a round: measured per layer, profiles/r6b -- 132 tail tiles of 32 k-tiles 0.502 -> 0.489 ms,
+  // 8 or 32 tail tiles level or 1 % slower: their runs are a few k-tiles long and all fragments)
+  if (t * 4 >= G && opt(OPT_PW256P_STREAMK) != 0 && ws != nullptr) {
+    const long long U = (long long)t * p.nkt;
+    const int Gs = (int)std::min<long long>(G, std::max<long long>(1, U / 4));
+    const int run = (int)(U / Gs);                                  // shortest run
+    const int maxp = (p.nkt + run - 1) / run + 1;
+    const double parts_now = (double)(((long long)t * sp + G - 1) / G);
+    const double cost_now = parts_now * ((double)p.nkt / sp + 1.5 + (p.nkt / sp < 8 ? 2.0 : 0.0));
+    const double cost_stream = (double)((U + Gs - 1) / Gs) + 3.0;  // a run is at most two fragments on average: two raw stores / cursor switches
+    if (run >= 4 && (size_t)t * maxp * 256 * 128 <= ws_floats && cost_stream < cost_now - 0.5) {
+      p.sk_units = (int)U; p.sk_maxp = maxp; p.sk_g = Gs;
+      p.n_sp = 0; p.split_p = 1;
+    }
+  }
   if (p.n_sp > 0 && (!ws || (size_t)p.n_sp * 256 * 128 > ws_floats)) return fail(-2, "conv_pw256p: split-K scratch too small");
   p.partial = ws;
   p.mtiles = mtiles;
@@ -474,7 +505,7 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
     if (ragged) hipLaunchKernelGGL((conv_pw_glds256p_kernel<true, false>), dim3((unsigned)G), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((conv_pw_glds256p_kernel<false, false>), dim3((unsigned)G), dim3(512), 0, stream, p);
   }
-  if (p.n_sp > 0)
+  if (p.n_sp > 0 || p.sk_units > 0)
     hipLaunchKernelGGL((conv_splitk_reduce_kernel<256, 128>), dim3((unsigned)t, 256 / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("conv_pw256p launch: ") + hipGetErrorString(e));
