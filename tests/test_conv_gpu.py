@@ -300,6 +300,50 @@ def test_pw256p_kernel_grouped_winograd_gemm_with_two_level_accumulation(case):
     assert float((y - y2).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("case", [(11, 64, 64, 1024, 256, 1, True, True),      # 352 tiles: one whole tile per workgroup + 96 tail tiles of 32 k-tiles -> runs of 12
+                                  (13, 64, 64, 512, 256, 1, True, False),      # 416 tiles: 160 tail tiles of 16 k-tiles -> runs of 10, up to three fragments per tile
+                                  (7, 57, 61, 1024, 384, 1, False, True)],     # ragged M, three n-tiles, 288 tiles: 32 tail tiles -> below the gate: uniform split
+                         ids=lambda c: "x".join(map(str, c[:6])))
+def test_pw256p_stream_k_tail(case):
+    """Round 4: the persistent kernel deals the tail tiles' k-tiles out as ONE stream in equal runs per workgroup (option
+    pw256p_streamk, tails of at least a quarter of a round); a run may end one tile and begin the next, the reduce kernel adds a
+    tile's fragments in workgroup order.  Against F.conv2d and against the uniform split (another cut of K: 2e-5)."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout, stride, relu, residual = case
+    _pw_case(case, "fp32", "conv_pw_glds_256x128p", 2e-5, options=P256P_OPTS)
+    g = torch.Generator().manual_seed(sum(case[:6]) + 7)
+    x = _rand((B, H, W, cin), g).cuda()
+    w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    res = _rand((B, H, W, cout), g).cuda() if residual else None
+    y1 = FusedConv(w, None, shift, relu=relu, options={**P256P_OPTS, "pw256p_streamk": 1})(x, residual=res)
+    assert _last_kernel() == "conv_pw_glds_256x128p"
+    y0 = FusedConv(w, None, shift, relu=relu, options={**P256P_OPTS, "pw256p_streamk": 0})(x, residual=res)
+    assert float((y1 - y0).abs().max()) <= 2e-5
+    ya = FusedConv(w, None, shift, relu=relu, options={**P256P_OPTS, "pw256p_streamk": 1})(x, residual=res)
+    assert torch.equal(y1, ya)                       # deterministic: fragments are added in a fixed order
+
+
+def test_pw256p_stream_k_tail_in_the_grouped_two_level_variant():
+    """The same in the FLUSH variant on a grouped GEMM: a Winograd conv with 384 output channels -- 64 positions x 2 m-tiles x 3
+    n-tiles = 384 tiles, 128 of them tail -- against F.conv2d and the uniform split."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, cin, cout = 2, 88, 88, 512, 384
+    g = torch.Generator().manual_seed(91)
+    x = _rand((B, cin, H, W), g)
+    w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(x, w, None, padding=1) + shift[None, :, None, None])
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    opts = {"pw256p_flush": 4096, "pw256p_mintiles": 8}
+    y1 = FusedConv(w, None, shift, padding=1, relu=True, options={**opts, "pw256p_streamk": 1})(xd)
+    assert _last_kernel() == "conv_pw_glds_256x128p", _last_kernel()
+    err = (y1.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+    y0 = FusedConv(w, None, shift, padding=1, relu=True, options={**opts, "pw256p_streamk": 0})(xd)
+    assert float((y1 - y0).abs().max()) <= 2e-5
+
+
 # conv_patch.hip: the stem's 3x3 convs on the persistent LDS-patch kernel.  patch_mintiles = 1 sends every eligible shape to it;
 # the cases cover all four instantiations, ragged widths / heights (16-column x 8-row output tiles hanging over both
 # edges), odd input sizes under stride 2, more tiles than CUs (the double-buffered patch ring and the deferred epilogue
