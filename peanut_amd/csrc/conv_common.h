@@ -47,7 +47,9 @@ struct ConvKParams {
   // conv_pw_glds256p_kernel, stream-K tail (round 4): the tail's sk_units k-tiles (tail tiles x nkt) are dealt out as ONE stream of
   // equal contiguous runs to the first sk_g workgroups; a run may end one tile and begin the next, a tile has at most sk_maxp
   // fragments (raw partial tiles j * sk_maxp + fragment index).  sk_units = 0: the uniform split above (split_p parts per tile)
-  int sk_units, sk_maxp, sk_g;
+  // sk_q: k-tiles per unit of the stream (2 for the two-level accumulation: fragments then start and end on a 64-channel boundary and
+  // are never shorter than the two iterations its register epilogue needs)
+  int sk_units, sk_maxp, sk_g, sk_q;
   int pack_bn;                // conv_pw_glds_kernel: rows of a PACKED weight tile when wider than the kernel's n-tile (128 for the 64-wide kernel on 128-wide packing); 0 = the kernel's
   int group_valid;            // grouped GEMM: rows of every weight group that hold data (the rest of the group's rows is padding); 0 = all
   int p_order;                // conv_pw_glds256p_kernel: item order (option pw256p_order)
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
   int parts = p.split_p;
   const float* base = p.partial + (size_t)j * p.split_p * (BM * BN);
   if (p.sk_units > 0) {
-    const int w0 = sk_owner(p.sk_units, p.sk_g, (long long)j * p.nkt), w1 = sk_owner(p.sk_units, p.sk_g, (long long)(j + 1) * p.nkt - 1);
+    const int upt = p.nkt / p.sk_q;                      // units per tile
+    const int w0 = sk_owner(p.sk_units, p.sk_g, (long long)j * upt), w1 = sk_owner(p.sk_units, p.sk_g, (long long)(j + 1) * upt - 1);
     parts = w1 - w0 + 1;
     base = p.partial + (size_t)j * p.sk_maxp * (BM * BN);
   }

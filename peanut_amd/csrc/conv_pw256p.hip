@@ -80,17 +80,18 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   // stream-K tail: this workgroup's run of the tail's k-tiles, as fragments of consecutive tail tiles
   const long long skU = p.sk_units;
   const int u0 = (skU > 0 && lw < p.sk_g) ? (int)(skU * lw / p.sk_g) : 0, u1 = (skU > 0 && lw < p.sk_g) ? (int)(skU * (lw + 1) / p.sk_g) : 0;
-  const int n_frag = u1 > u0 ? (u1 - 1) / p.nkt - u0 / p.nkt + 1 : 0;
+  const int upt = skU > 0 ? p.nkt / p.sk_q : 1;           // stream units (sk_q k-tiles each) per tile
+  const int n_frag = u1 > u0 ? (u1 - 1) / upt - u0 / upt + 1 : 0;
   const int n_items = nf + (skU > 0 ? n_frag : sp1 - sp0);
   if (n_items == 0) return;
   auto item_at = [&](int i) {
     PItem it;
     int tile;
     if (i >= nf && skU > 0) {
-      const int j = u0 / p.nkt + (i - nf);                  // tail tile of this fragment
-      const int t0 = j * p.nkt;
-      it.kt0 = (u0 > t0 ? u0 : t0) - t0;
-      it.kt1 = (u1 < t0 + p.nkt ? u1 : t0 + p.nkt) - t0;
+      const int j = u0 / upt + (i - nf);                    // tail tile of this fragment
+      const int t0 = j * upt;
+      it.kt0 = ((u0 > t0 ? u0 : t0) - t0) * p.sk_q;
+      it.kt1 = ((u1 < t0 + upt ? u1 : t0 + upt) - t0) * p.sk_q;
       it.part = j * p.sk_maxp + (lw - sk_owner(skU, p.sk_g, (long long)t0));   // fragments of a tile in workgroup order
       tile = p.n_full + j;
     } else if (i < nf) {
@@ -472,19 +473,24 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
   // at least four k-tiles).  Against the uniform split above -- whose parts come in whole multiples per workgroup (132 tail tiles
   // cut three ways = 396 parts over 256 workgroups: two parts for most, 21 k-tiles where 16.5 would do) -- every workgroup ends
   // within one k-tile of the others.  A tile then has up to sk_maxp fragments; the reduce sums them in workgroup order.
-  p.sk_units = 0; p.sk_maxp = 0; p.sk_g = 0;
+  p.sk_units = 0; p.sk_maxp = 0; p.sk_g = 0; p.sk_q = 1;
   // (only for tails of at least a quarter of a round: measured per layer, profiles/r6b -- 132 tail tiles of 32 k-tiles 0.502 -> 0.489 ms,
   // 8 or 32 tail tiles level or 1 % slower: their runs are a few k-tiles long and all fragments)
-  if (t * 4 >= G && opt(OPT_PW256P_STREAMK) != 0 && ws != nullptr) {
-    const long long U = (long long)t * p.nkt;
-    const int Gs = (int)std::min<long long>(G, std::max<long long>(1, U / 4));
-    const int run = (int)(U / Gs);                                  // shortest run
-    const int maxp = (p.nkt + run - 1) / run + 1;
+  // The two-level accumulation variant streams in units of TWO k-tiles (one partial sum of 64 channels): its register epilogue
+  // hands the previous item's totals out during the next item's first two iterations, so no fragment may be shorter, and partial
+  // sums then cover the same channel groups as in an uncut tile.
+  const int q = p.flush ? 2 : 1;
+  if (t * 4 >= G && opt(OPT_PW256P_STREAMK) != 0 && ws != nullptr && p.nkt % q == 0) {
+    const int upt = p.nkt / q;                                      // stream units per tile
+    const long long U = (long long)t * upt;
+    const int Gs = (int)std::min<long long>(G, std::max<long long>(1, U * q / 4));
+    const int run = (int)(U / Gs);                                  // shortest run, in units
+    const int maxp = run > 0 ? (upt + run - 1) / run + 1 : 0;
     const double parts_now = (double)(((long long)t * sp + G - 1) / G);
     const double cost_now = parts_now * ((double)p.nkt / sp + 1.5 + (p.nkt / sp < 8 ? 2.0 : 0.0));
-    const double cost_stream = (double)((U + Gs - 1) / Gs) + 3.0;  // a run is at most two fragments on average: two raw stores / cursor switches
-    if (run >= 4 && (size_t)t * maxp * 256 * 128 <= ws_floats && cost_stream < cost_now - 0.5) {
-      p.sk_units = (int)U; p.sk_maxp = maxp; p.sk_g = Gs;
+    const double cost_stream = (double)((U + Gs - 1) / Gs) * q + 3.0;  // a run is two fragments on average: two raw stores / cursor switches
+    if (run * q >= 4 && (size_t)t * maxp * 256 * 128 <= ws_floats && cost_stream < cost_now - 0.5) {
+      p.sk_units = (int)U; p.sk_maxp = maxp; p.sk_g = Gs; p.sk_q = q;
       p.n_sp = 0; p.split_p = 1;
     }
   }

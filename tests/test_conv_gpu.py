@@ -324,11 +324,16 @@ def test_pw256p_stream_k_tail(case):
     assert torch.equal(y1, ya)                       # deterministic: fragments are added in a fixed order
 
 
-def test_pw256p_stream_k_tail_in_the_grouped_two_level_variant():
+@pytest.mark.parametrize("shape", [(2, 88, 88, 512, 384), (3, 120, 120, 512, 384)], ids=lambda c: "x".join(map(str, c)))
+def test_pw256p_stream_k_tail_in_the_grouped_two_level_variant(shape):
     """The same in the FLUSH variant on a grouped GEMM: a Winograd conv with 384 output channels -- 64 positions x 2 m-tiles x 3
-    n-tiles = 384 tiles, 128 of them tail -- against F.conv2d and the uniform split."""
+    n-tiles = 384 tiles, 128 of them tail, runs of exactly half a tile -- and one whose runs cut the tiles at changing offsets (64
+    positions x 5 m-tiles x 3 n-tiles = 960 tiles, 192 of them tail: eight units per tile in runs of six).  The stream
+    is dealt in units of TWO k-tiles in this variant: its register epilogue needs two iterations of the next item, and a
+    one-k-tile fragment corrupted the second-level sums (found by the ten-map forward test, profiles/r6c).  Against F.conv2d and
+    the uniform split."""
     from peanut_amd.ops import FusedConv
-    B, H, W, cin, cout = 2, 88, 88, 512, 384
+    B, H, W, cin, cout = shape
     g = torch.Generator().manual_seed(91)
     x = _rand((B, cin, H, W), g)
     w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
