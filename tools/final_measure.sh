@@ -25,7 +25,7 @@ python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision b
 cd /tmp; export TMPDIR=/tmp
 for m in fp32 bf16x6 fp16x3; do
 rm -rf /tmp/fm_trace
-rocprofv3 --kernel-trace --stats -d /tmp/fm_trace -- python $R/bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --no-probe --also "" --traffic none > /tmp/fm_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/fm_trace -- python $R/bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --no-probe --also "" --traffic none --configs "" > /tmp/fm_trace.log 2>&1
 db=$(find /tmp/fm_trace -name '*.db' | head -1); [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $R/$OUT/trace_$m.txt
 done
 rm -rf /tmp/fm_trace2

@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 run() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_$name -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --also "" --traffic none $BENCH_ARGS > /tmp/pmc_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_$name -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --also "" --traffic none --configs "" $BENCH_ARGS > /tmp/pmc_$name.log 2>&1
   local db=$(find /tmp/pmc_$name -name '*.db' | head -1)
   if [ -n "$db" ]; then python $REPO/tools/rocpd_summary.py "$db" > "$REPO/$OUT/pmc_$name.txt" 2>&1; else tail -5 /tmp/pmc_$name.log > "$REPO/$OUT/pmc_$name.txt"; fi
 }
