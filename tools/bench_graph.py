@@ -36,13 +36,16 @@ def main():
 def run():
     cfg = PredCfg()
     m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg, 0), cfg=cfg)
-    for name, s in (("config1 240x240 B=1", 240), ("480x480 B=1", 480), ("deployed 720x720 B=1", 720)):
-        x = (torch.rand((1, 14, s, s), device="cuda") > 0.7).float()
-        y = torch.empty((1, 6, s, s), device="cuda")
+    for name, s, b, reps in (("config1 240x240 B=1", 240, 1, 50), ("480x480 B=1", 480, 1, 50), ("deployed 720x720 B=1", 720, 1, 50),
+                             ("headline 480x480 B=32", 480, 32, 10)):
+        x = (torch.rand((b, 14, s, s), device="cuda") > 0.7).float()
+        y = torch.empty((b, 6, s, s), device="cuda")
         row = {"case": name}
-        for g in (False, True):
+        for g in (False, True, False, True):
             m.model.use_graph(g)
-            row["graph_ms" if g else "plain_ms"] = round(timed(lambda: m.get_prediction_batch(x, out=y), 50), 3)
+            key = "graph_ms" if g else "plain_ms"
+            v = round(timed(lambda: m.get_prediction_batch(x, out=y), reps), 3)
+            row[key] = min(row.get(key, 1e9), v)
         print(json.dumps(row), flush=True)
     args = SimpleNamespace(device=torch.device("cuda:0"), frame_height=120, frame_width=160, map_resolution=5,
                            map_size_cm=4800, global_downscaling=2, vision_range=100, hfov=79.0, du_scale=1,
