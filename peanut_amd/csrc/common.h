@@ -63,7 +63,7 @@ struct ConvArgs {
                            // (Winograd positions: tiles before padding); 0 = unknown / all.  A kernel may skip work on the padding.
 };
 
-constexpr size_t kSplitKScratchFloats = (size_t)16 << 20;   // 64 MiB: 512 partial 128x128 tiles and then some
+constexpr size_t kSplitKScratchFloats = (size_t)48 << 20;   // 192 MiB: 768 partial 256x256 tiles (the stream-K tail of the persistent 256 x 256 kernel: up to 3 fragments for each of < 256 tail tiles)
 
 inline int conv_out_dim(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 
@@ -85,6 +85,9 @@ bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int
 bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_per_group);
 // conv_pw256p.hip: ... on the persistent 256 x 128 kernel (epilogue of the previous tile inside the next tile's k-loop)
 bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
+// conv_pw256wp.hip: ... on the persistent 256 x 256 kernel (in-place epilogue inside the next tile's first iteration); stride 1
+// only, c1 / c2 the channels of the two sources
+bool conv_pw_uses_256wp(int cout, long long M, int stride, int mt_per_group, int bn_tile, int c1, int c2, int flush_ktiles);
 // conv_pw_ares.hip: ... on the persistent A-resident kernel (K = 128 / 256)
 bool conv_pw_uses_ares(int cin, int cout, long long M, int stride, bool two_source, int flush_ktiles, int bn_tile);
 

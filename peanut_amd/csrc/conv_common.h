@@ -53,6 +53,8 @@ struct ConvKParams {
   int pack_bn;                // conv_pw_glds_kernel: rows of a PACKED weight tile when wider than the kernel's n-tile (128 for the 64-wide kernel on 128-wide packing); 0 = the kernel's
   int group_valid;            // grouped GEMM: rows of every weight group that hold data (the rest of the group's rows is padding); 0 = all
   int p_order;                // conv_pw_glds256p_kernel: item order (option pw256p_order)
+  float* dump;                // conv_pw_glds256wp_kernel: one 256 x 256 tile of scratch behind the partial tiles (target of a workgroup's first, empty epilogue)
+  int stagger;                // conv_pw_glds256wp_kernel: spread of the workgroups' start times, in sleeps of ~3.4 us (option pw256wp_stagger)
   int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*
 };
 
@@ -80,6 +82,8 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
 int launch_conv_pw_ares(const ConvKParams& p, int bn_tile, hipStream_t stream);
 // conv_pw256p.hip: persistent 256 x 128 kernel (p.ntiles = 128-wide n-tiles)
 int launch_conv_pw256p(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream);
+// conv_pw256wp.hip: persistent 256 x 256 kernel (returns 1 without launching when the tail's partial tiles do not fit the scratch)
+int launch_conv_pw256wp(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream);
 // conv_patch.hip: persistent LDS-patch kernel for the 3x3 convs with 16 / 32 input channels (gate: conv_patch_eligible)
 int launch_conv_patch(const ConvKParams& p, const ConvDesc& d, int B, hipStream_t stream);
 // gemm_rs.hip: pointwise layer / grouped GEMM emulated on the bf16 matrix cores: fp32 A (p.x, p.x2) split into bf16 pieces in

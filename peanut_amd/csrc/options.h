@@ -19,7 +19,7 @@
 namespace peanut {
 
 enum OptionId {
-  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW256P_STREAMK, OPT_PW_ARES,
+  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW256P_STREAMK, OPT_PW256WP_MINK, OPT_PW256WP_MINTILES, OPT_PW256WP_NPRE, OPT_PW256WP_STAGGER, OPT_PW_ARES,
   OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_PW_BN64_MAXK, OPT_PW64_MAXTILES, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
@@ -48,6 +48,10 @@ inline const OptionInfo* option_table() {
       {"pw256p_flush", 512, false, "most input channels of a Winograd position GEMM (two-level accumulation) that runs on the persistent kernel (0: none)"},
       {"pw256p_order", 1, false, "persistent 256 x 128 kernel: 1 = the workgroups of an XCD walk its run of tiles side by side (neighbours share operand panels in L2), 0 = one contiguous run per workgroup"},
       {"pw256p_streamk", 1, false, "persistent 256 x 128 kernel: the tail tiles' k-tiles as one stream in equal runs per workgroup (0: every tail tile cut into the same number of parts)"},
+      {"pw256wp_mink", 512, false, "fewest input channels for the persistent 256 x 256 kernel (conv_pw256wp.hip; 0: off)"},
+      {"pw256wp_mintiles", 768, false, "fewest 256 x 256 tiles for that kernel"},
+      {"pw256wp_npre", 0, false, "persistent 256 x 256 kernel: accumulator blocks per in-place epilogue group (2 or 4; 0 = two with a residual, four without)"},
+      {"pw256wp_stagger", 0, false, "persistent 256 x 256 kernel: spread of the workgroups' start times in sleeps of ~3.4 us (their tile boundaries -- 512 KiB of epilogue traffic per CU -- then fall at different times)"},
       {"pw_ares", 1, false, "K = 128 / 256 pointwise layers on the persistent A-resident kernel (conv_pw_ares.hip)"},
       {"pw_ares_minunits", 512, false, "fewest (m-tile, n-tile) units for that kernel"},
       {"patch_mintiles", 1024, false, "3x3 convs of 16 / 32 input channels on the persistent LDS-patch kernel (conv_patch.hip) from this many 8 x 16 output tiles (0: off)"},

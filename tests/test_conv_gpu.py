@@ -153,7 +153,7 @@ WIDE_PW_CASES = [
     (8, 64, 64, 512, 768, 1, False, False),      # 384 tiles over 256 CUs: the 128-tile tail runs split-K + the ordered reduce
     (4, 150, 150, 512, 768, 2, True, False),     # strided 1x1 (the downsample form), M = 22 500
 ]
-WIDE_OPTS = {"pw256w_mink": 512, "pw256w_mintiles": 256}
+WIDE_OPTS = {"pw256w_mink": 512, "pw256w_mintiles": 256, "pw256wp_mink": 0}
 
 
 @pytest.mark.parametrize("case", WIDE_PW_CASES, ids=lambda c: "x".join(map(str, c[:6])))
@@ -218,6 +218,72 @@ def test_pw_ares_kernel_grouped_winograd_gemm(case):
     assert bool((err <= 1.5e-4 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
 
 
+WP_CASES = [
+    # (B, H, W, cin, cout, stride, relu, residual): csrc/conv_pw256wp.hip conv_pw_uses_256wp -- stride 1, whole 256 x 256 tiles, one
+    # running sum; the tile gate is lowered for these handles (option pw256wp_mintiles)
+    (8, 64, 64, 512, 2048, 1, True, True),       # layer4 conv3 class: 1024 tiles, four per workgroup, residual + ReLU; no tail
+    (8, 64, 64, 2048, 512, 1, True, False),      # layer4 conv1 class: 256 tiles, one per workgroup: the epilogue only in the drain
+    (9, 64, 64, 1024, 512, 1, True, False),      # 288 tiles: one whole tile each + 32 tail tiles in uniform split parts (raw partial tiles + reduce)
+    (13, 64, 64, 512, 512, 1, True, True),       # 416 tiles: 160 tail tiles of 16 k-tiles as ONE stream (units of two k-tiles), residual added by the reduce
+    (8, 64, 64, 512, 768, 1, False, True),       # 384 tiles, no ReLU (the lower clamp is -inf), stream-K tail
+    (2, 64, 64, 512, 256, 1, True, True),        # 32 tiles < 256 CUs: every workgroup gets one two-k-tile part, nothing but raw partial tiles
+    (1, 32, 32, 64, 256, 1, True, True),         # the smallest legal layer: K = 64 (two k-tiles per tile), four tiles
+]
+WP_OPTS = {"pw256wp_mink": 64, "pw256wp_mintiles": 1, "pw_ares": 0}
+
+
+@pytest.mark.parametrize("npre", [0, 2, 4])
+@pytest.mark.parametrize("case", WP_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_pw256wp_kernel_matches_torch(case, npre):
+    """conv_pw_glds256wp_kernel (round 5: persistent 256 x 256 tiles; the previous tile's epilogue runs IN PLACE inside the next
+    tile's first iteration, group of accumulator blocks by group, each restarted by an MFMA with C = 0) against F.conv2d, in both
+    group sizes, and against the persistent 256 x 128 kernel on the same layer."""
+    from peanut_amd.ops import FusedConv
+    opts = {**WP_OPTS, "pw256wp_npre": npre}
+    if case[3] <= 128:
+        opts["pw_bn64_maxk"] = 0                  # pack this narrow layer 128 wide (the kernel reads 128-wide packed weights)
+    _pw_case(case, "fp32", "conv_pw_glds_256x256p", 2e-5, options=opts)
+    B, H, W, cin, cout, stride, relu, residual = case
+    g = torch.Generator().manual_seed(sum(case[:6]) + 3)
+    x = _rand((B, H, W, cin), g).cuda()
+    w = _rand((cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+    shift = _rand((cout,), g, 0.1)
+    res = _rand((B, H, W, cout), g).cuda() if residual else None
+    y0 = FusedConv(w, None, shift, relu=relu, options=opts)(x, residual=res)
+    assert _last_kernel() == "conv_pw_glds_256x256p"
+    y1 = FusedConv(w, None, shift, relu=relu, options={**opts, "pw256wp_mink": 0})(x, residual=res)
+    assert _last_kernel() != "conv_pw_glds_256x256p"
+    if (B * H * W // 256) * (cout // 256) % 256 == 0 and cin >= 256:      # no tail on either side: bit for bit
+        assert torch.equal(y0, y1)
+    else:
+        assert float((y0 - y1).abs().max()) <= 2e-5
+
+
+def test_pw256wp_kernel_two_sources():
+    """The persistent 256 x 256 kernel reading its A k-tiles from two tensors of different widths (layer4.0's conv3 + downsample
+    form) against a conv over the concatenation; 448 tiles: one each + a 192-tile stream-K tail whose fragments start on either side
+    of the source switch.  NaN and Inf in the input must reach the output (the clamp is `v < lo ? lo : v`)."""
+    from peanut_amd.ops import FusedConv
+    B, H, W, c1, c2, cout = 7, 64, 64, 512, 1024, 1024
+    g = torch.Generator().manual_seed(12)
+    xa, xb = _rand((B, c1, H, W), g), _rand((B, c2, H, W), g)
+    w = _rand((cout, c1 + c2, 1, 1), g, (2.0 / (c1 + c2)) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = _rand((cout,), g, 0.1)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w) * scale[None, :, None, None] + shift[None, :, None, None])
+    conv = FusedConv(w, scale, shift, relu=True, options={"pw256wp_mintiles": 1})
+    xad, xbd = xa.permute(0, 2, 3, 1).contiguous().cuda(), xb.permute(0, 2, 3, 1).contiguous().cuda()
+    y = conv(xad, x2=xbd)
+    assert _last_kernel() == "conv_pw_glds_256x256p", _last_kernel()
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+    xad[3, 5, 7, 100] = float("nan")
+    xbd[0, 0, 0, 0] = float("inf")
+    y = conv(xad, x2=xbd)
+    assert bool(torch.isnan(y[3, 5, 7]).all()) and not bool(torch.isfinite(y[0, 0, 0]).all())
+    assert bool(torch.isfinite(y[3, 5, 8]).all())
+
+
 P256P_CASES = [
     # (B, H, W, cin, cout, stride, relu, residual): csrc/conv_pw256p.hip conv_pw_uses_256p -- whole 256 x 128 tiles, >= 256 input
     # channels, one running sum; the tile gate is lowered for these handles (option pw256p_mintiles)
@@ -230,7 +296,7 @@ P256P_CASES = [
     (1, 90, 90, 1024, 256, 1, True, False),      # one 720 x 720 map's layer3 conv1: 64 tiles < 256 CUs -> every tile in split parts, ragged M = 8 100
     (1, 90, 90, 512, 2048, 1, True, True),       # its layer4 conv3: 512 tiles, two per workgroup, ragged last m-tile, residual
 ]
-P256P_OPTS = {"pw256p_mink": 256, "pw256p_mintiles": 8, "pw_ares": 0, "pw256w_mink": 0, "bn64_maxk": 128}   # K = 256 layers packed 128 wide
+P256P_OPTS = {"pw256p_mink": 256, "pw256p_mintiles": 8, "pw_ares": 0, "pw256w_mink": 0, "pw256wp_mink": 0, "bn64_maxk": 128}   # K = 256 layers packed 128 wide
 
 
 @pytest.mark.parametrize("case", P256P_CASES, ids=lambda c: "x".join(map(str, c[:6])))
@@ -870,6 +936,9 @@ def test_pointwise_kernel_families_are_bit_identical():
         ((8, 64, 64, 1024, 1024, 1, True), {"pw256w_mink": 0, "pw256p_mink": 0}, "conv_pw_glds_256x256", "conv_pw_glds_256x128"),
         ((8, 64, 64, 1024, 512, 1, True), {"pw256p_mink": 0}, "conv_pw_glds_256x128p", "conv_pw_glds_256x128"),
         ((8, 64, 64, 512, 1024, 1, True), {"pw256p_mink": 0}, "conv_pw_glds_256x128p", "conv_pw_glds_128x128"),
+        # round 5: the persistent 256 x 256 kernel (in-place epilogue) against the persistent 256 x 128 one; 512 / 1024 tiles: no tail
+        ((8, 64, 64, 512, 1024, 1, True), {"pw256wp_mink": 0, "pw256w_mink": 0}, "conv_pw_glds_256x256p", "conv_pw_glds_256x128p"),
+        ((8, 64, 64, 1024, 2048, 1, False), {"pw256wp_mink": 0, "pw256w_mink": 0}, "conv_pw_glds_256x256p", "conv_pw_glds_256x128p"),
     ]
     for i, (case, alt, fam0, fam1) in enumerate(cases):
         B, H, W, cin, cout, s, residual = case[:7]
@@ -880,7 +949,9 @@ def test_pointwise_kernel_families_are_bit_identical():
         shift = _rand((cout,), g, 0.1)
         ho, wo = (H - 1) // s + 1, (W - 1) // s + 1
         res = _rand((B, ho, wo, cout), g).cuda() if residual else None
-        base = {"pw256w_mintiles": 256} if "256x256" in fam0 else {"pw256w_mink": 0}
+        base = {"pw256w_mintiles": 256, "pw256wp_mink": 0} if "256x256" in fam0 else {"pw256w_mink": 0, "pw256wp_mink": 0}
+        if fam0.endswith("256x256p"):
+            base = {"pw256wp_mintiles": 1}
         y0 = FusedConv(w, None, shift, stride=s, relu=True, options=base)(x, residual=res)
         assert _last_kernel() == fam0, (case, _last_kernel())
         y1 = FusedConv(w, None, shift, stride=s, relu=True, options={**base, **alt})(x, residual=res)

@@ -18,9 +18,13 @@ SHAPES = [  # name, rows M (as B x H x W), cin, cout, residual
     ("layer2.conv3", (32, 60, 60), 128, 512, True),
     ("layer3.conv1", (32, 60, 60), 1024, 256, False),
     ("layer3.conv3", (32, 60, 60), 256, 1024, True),
+    ("layer4.0.conv1", (32, 60, 60), 1024, 512, False),
     ("layer4.conv1", (32, 60, 60), 2048, 512, False),
     ("layer4.conv3", (32, 60, 60), 512, 2048, True),
+    ("layer3.0.conv3ds", (32, 60, 60), 768, 1024, False),      # K = 256 + 512 as one source (the fused conv3 + downsample GEMM)
+    ("layer4.0.conv3ds", (32, 60, 60), 1536, 2048, False),
 ]
+OPTS = json.loads(os.environ.get("OPTS", "{}"))      # tuning options of the handles (csrc/options.h), e.g. OPTS='{"pw256wp_mink": 0}'
 only = os.environ.get("SHAPES", "")
 precisions = sys.argv[1:] or ["fp32", "bf16x6"]
 g = torch.Generator().manual_seed(0)
@@ -34,7 +38,7 @@ for name, (b, h, w), cin, cout, residual in SHAPES:
         wt.zero_()
     res = torch.randn((b, h, w, cout), generator=g).cuda() if residual else None
     for prec in precisions:
-        conv = FusedConv(wt, None, None, relu=True, precision=prec)
+        conv = FusedConv(wt, None, None, relu=True, precision=prec, options=OPTS)
         for _ in range(3):
             conv(x, residual=res)
         torch.cuda.synchronize()
@@ -49,5 +53,5 @@ for name, (b, h, w), cin, cout, residual in SHAPES:
         by = 4.0 * b * h * w * (cin + cout * (2 if residual else 1))
         print(json.dumps({"shape": name, "M": b * h * w, "K": cin, "N": cout, "precision": prec,
                           "kernel": _lib.load().peanut_last_conv_kernel().decode(), "ms": round(ms, 4),
-                          "tflops": round(fl / ms / 1e9, 1), "gb_s": round(by / ms / 1e6)}), flush=True)
+                          "tflops": round(fl / ms / 1e9, 1), "gb_s": round(by / ms / 1e6), "opts": OPTS}), flush=True)
         del conv
