@@ -143,11 +143,16 @@ def cpu_baseline(cfg: PredCfg, sd, s: int, budget_s: float = 40.0):
                       f"(B={top['batch']}, {top['threads']} threads)"}
 
 
+# the family that carries most of the fp32 headline's step time (round 5: the persistent 256 x 256 kernel); profiles/hbm_traffic.json
+# must hold its traffic for the N > 1 lines (tests/test_dist_cpu.py checks the file, tests/test_pred_gpu.py the family)
+DOMINANT_FAMILY_FP32 = "conv_pw_glds_256x256p"
+
 # bench kernel family -> substring of the rocprofv3 kernel name
 FAMILY_KERNEL = {
     "conv_pw_glds_256x128": "conv_pw_glds256_kernel(",
     "conv_pw_glds_256x256": "conv_pw_glds256w_kernel",
     "conv_pw_glds_256x128p": "conv_pw_glds256p_kernel",
+    "conv_pw_glds_256x256p": "conv_pw_glds256wp_kernel",
     "conv_pw_ares_128x128": "conv_pw_ares_kernel",
     "conv_pw_glds_128x128": "conv_pw_glds_kernel<128, 2, 2>",
     "conv_pw_glds_128x64": "conv_pw_glds_kernel<64, 2, 2>",
@@ -454,7 +459,8 @@ def main(argv=None, backend_factory=HipBackend):
     gather_failed = False
     if world > 1 or args.config == 5:
         gather = pdist.allgather_maps                  # peanut_allgather_maps (the library's RCCL entry point)
-        gather_path = "peanut_allgather_maps (RCCL)"
+        # one rank (--config 5 at N = 1): peanut_amd.dist.allgather_maps returns its input untouched -- nothing goes through RCCL
+        gather_path = "peanut_allgather_maps (RCCL)" if world > 1 else "identity (1 rank: RCCL not used)"
         try:
             gather(out)                                # warm-up (communicator set-up, collective)
         except Exception as e:                         # reporting only: never lose the bench line over the logging collective

@@ -9,7 +9,9 @@
  *     not synchronise unless stated;
  *   - return 0 on success, a negative PEANUT_E* code otherwise; peanut_last_error() returns a
  *     thread-local message for the last failure;
- *   - a handle is not thread-safe, distinct handles are.
+ *   - a handle is not thread-safe, distinct handles are; the process DEFAULTS of the tuning options (peanut_set_default_option) are
+ *     one unlocked table that every peanut_*_create snapshots: callers that create handles on several threads while changing
+ *     defaults serialise those calls themselves (the Python mirrors do, under one lock).
  */
 #ifndef PEANUT_HIP_H_
 #define PEANUT_HIP_H_
@@ -97,7 +99,12 @@ typedef struct peanut_pred_cfg {
 #define PEANUT_ALGO_AUTO 0
 #define PEANUT_ALGO_DIRECT 1
 
-/* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32, exact fp32 (bit-identical to an fmaf chain).
+/* Conv arithmetic.  FP32: v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulation.  The pointwise GEMM families sum
+ * a layer's products in ONE order and agree bit for bit with each other and with an fmaf chain in that order (only a tail
+ * split-K cuts K differently by tile size); the summation order of the other kernels is kernel-dependent: the LDS-patch stem
+ * kernel (csrc/conv_patch.hip) keeps two accumulator chains, the Winograd position GEMMs accumulate in two levels, and the
+ * row groups of the pyramid pooling (option ppm_group_rows = 0: chosen from H * B, so that ~768 workgroups run) make the last
+ * bits of the PSP pooling sums depend on the BATCH SIZE as well as on the position in the batch -- all within ~1e-6 relative.
  * BF16X6: fp32 emulated on the bf16 matrix cores.  Activations stay fp32 in HBM and LDS -- the forward's tensors,
  * Winograd transforms and fusions are exactly the fp32 mode's; every fp32 value is split into three bf16 pieces (3 x 8 =
  * 24 mantissa bits: the split is exact; the activations in registers after the fragment read, the weights once at load
@@ -290,6 +297,18 @@ int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, i
  * kernels point to storage owned by the handle (valid until the next probe or plan change).  Returns the op count. */
 int peanut_rcnn_probe_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, int reps, int max_ops,
                             const char** names, const char** kernels, double* ms, double* flops, void* stream);
+
+/* Stage timing of peanut_rcnn_inference / peanut_rcnn_semantic (bench.py: the roofline of stage 1's BACK half -- proposal
+ * selection, ROI heads, mask paste: nav/agent/utils/segmentation.py:41-62 around detectron2's GeneralizedRCNN.inference).  While
+ * enabled, every call records a HIP event on its stream at the nine stage boundaries: front_end | rpn_selection | roi_align_7x7 |
+ * box_head_fc | box_postprocess_nms | host_read_detection_counts | roi_align_14x14 | mask_head_convs | mask_probabilities_paste
+ * (a call without detections ends after the sixth).  peanut_rcnn_stage_times reports, for the LAST call, each stage's name, the
+ * roof that bounds it ("mfma" | "hbm" | "host"; static strings), its milliseconds and its algorithmic work (FLOPs for "mfma"
+ * stages -- the front end's are the direct-form count of its convs (nominal: its Winograd layers execute fewer), the heads'
+ * are the executed ones; bytes with every operand read once and every result written once for "hbm" stages); returns the
+ * stage count. */
+int peanut_rcnn_set_stage_timing(peanut_rcnn_t* h, int on);
+int peanut_rcnn_stage_times(peanut_rcnn_t* h, int max_stages, const char** names, const char** bounds, double* ms, double* work);
 
 /* The detector's input transform alone (DefaultPredictor.__call__: ResizeShortestEdge.get_transform(img).apply_image,
  * i.e. PIL.Image.resize(BILINEAR) for uint8 frames -- Pillow's two-pass fixed-point resample, restated bit for bit --

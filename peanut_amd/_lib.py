@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 11    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 12    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -103,6 +103,8 @@ SIGNATURES = {
                                             C.POINTER(_P), _P]),
     "peanut_rcnn_probe_front": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "peanut_rcnn_set_stage_timing": (C.c_int, [_P, C.c_int]),
+    "peanut_rcnn_stage_times": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "peanut_rcnn_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "peanut_rcnn_inference": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _P, _P, _P, _P, _P]),
     "peanut_rcnn_semantic": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int32), _P,
@@ -215,7 +217,12 @@ class default_options:
     tuning options (csrc/options.h; ``peanut_option_list()`` names them) for the handles CREATED inside the block and
     restores them afterwards.  A handle snapshots the defaults when it is created, so this is how the create-time options
     (Winograd forms, packing tiles) reach one handle without touching the environment; run-time options can also be changed
-    on a live handle (``peanut_pred_set_option`` / ``peanut_conv_set_option`` / ``peanut_rcnn_set_option``)."""
+    on a live handle (``peanut_pred_set_option`` / ``peanut_conv_set_option`` / ``peanut_rcnn_set_option``).
+
+    The block holds a process-wide re-entrant lock: the library's defaults are one global table without locking of its own, and a
+    handle created on another thread in the middle of someone's block would inherit their values.  EVERY Python mirror therefore
+    creates its handle inside a (possibly empty) ``default_options()`` block; direct C callers that create handles from several
+    threads while changing defaults must serialise those calls themselves (include/peanut_hip.h)."""
 
     def __init__(self, **options):
         self.options = {k: int(v) for k, v in options.items()}

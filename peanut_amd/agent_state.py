@@ -242,6 +242,7 @@ class Agent_State:
                                 self.target_pred, float(getattr(args, "dist_weight_temperature", 500)), int(args.map_resolution))
         self.value_max = res["value_max"]
         self.goal_rounds = res["rounds"]
+        self.goal_passes, self.goal_converged = self._goal.passes, self._goal.converged
         new_global_goal = [res["goal"]]
         if new_global_goal != self.last_global_goal:      # avoid repeating the last goal
             self.last_global_goal = self.global_goals

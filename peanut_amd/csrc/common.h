@@ -84,7 +84,7 @@ bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int
 // conv_pw.hip: a 128-wide-packed short-K layer on 128 x 64 tiles (few tiles: batch-1 shapes)
 bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_per_group);
 // conv_pw256p.hip: ... on the persistent 256 x 128 kernel (epilogue of the previous tile inside the next tile's k-loop)
-bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles);
+bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles, long long in_pixels = 0);
 // conv_pw256wp.hip: ... on the persistent 256 x 256 kernel (in-place epilogue inside the next tile's first iteration); stride 1
 // only, c1 / c2 the channels of the two sources
 bool conv_pw_uses_256wp(int cout, long long M, int stride, int mt_per_group, int bn_tile, int c1, int c2, int flush_ktiles);

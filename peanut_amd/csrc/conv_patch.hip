@@ -20,7 +20,10 @@
 // every store / LDS-DMA issue stall idles the matrix pipe (profiles/r5r: 115 TF/s with four waves and the stores in one burst).
 // LDS rows are padded by one 16-byte slot (row = CIN + 4 floats), as in conv_igemm: conflict-free ds_read_b128 for 8 / 16
 // consecutive pixels.  Same fragment layout and k order (tap outer; 8-channel groups; lanes 0-31 / 32-63 take channels
-// 0-3 / 4-7 of a group) as conv_igemm_kernel: bit-identical to it wherever that launch does not cut a tail tile along K.
+// 0-3 / 4-7 of a group) as conv_igemm_kernel, and exact fp32 products -- but NOT the same summation order: the weight fragments
+// of all nine taps live in REGISTERS (bw[9][NJ][NI], not LDS) and even / odd k-steps accumulate in two chains (acc0 / acc1) that
+// are added at the end, so the result differs from conv_igemm's single chain in the last bits (~1e-6 relative; the tests hold the
+// two kernels to 1e-5 of each other, and the fp32 stem's last bits therefore depend on patch_mintiles / stem_nchw).
 #include <stdlib.h>
 
 #include "common.h"

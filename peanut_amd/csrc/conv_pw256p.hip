@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   // ---- the request cursor: runs two k-tiles ahead of the compute cursor, across item boundaries.  Per lane it holds only
   // the pixel index of its four A rows; everything else is a lane constant or wave-uniform.  A piece's address is
   //   source base (uniform) + pixel * channels * 4 + k-tile offset (uniform) + chunk constant.
-  // The launcher guarantees every tensor is smaller than 4 GiB (32-bit byte offsets).
+  // conv_pw_uses_256p guarantees that the input (B*H*W rows of the wider source) and the output stay below 4 GiB (32-bit byte offsets).
   unsigned a_pix[A_INSTR], a_chunk[A_INSTR], b_off[B_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
 // Which pointwise layers take the persistent 256 x 128 kernel: one running sum (no two-level accumulation), no weight
 // groups, whole 128-wide packed n-tiles, at least pw256p_mink input channels (8 k-tiles: the previous item's epilogue is spread
 // over the first eight iterations of the next) and at least pw256p_mintiles tiles.
-bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles) {
+bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles, long long in_pixels) {
   const int min_k = (int)opt(OPT_PW256P_MINK);
   if (min_k <= 0 || bn_tile != 128 || cin < min_k || cin < 256) return false;
   // Winograd position GEMMs (partial sums of 64 channels): measured per layer (profiles/r5o) K = 512 +2.5 %, K = 2048 -4 % (the
@@ -439,7 +439,10 @@ bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int
   if (flush_ktiles != 0 && (flush_ktiles != 2 || cin > opt(OPT_PW256P_FLUSH))) return false;
   if (mt_per_group % 2 != 0) return false;                                 // grouped GEMM: whole 256-row tiles per weight group
   if (cout % 128 != 0) return false;                                       // whole 128-wide n-tiles: the register epilogue checks no column bounds
-  if (M * (long long)cin * 4 >= (1LL << 32) || M * (long long)cout * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets
+  // 32-bit byte offsets: into the output (M rows) and into the INPUT, whose pixel indices b*H*W + oy*stride*W + ox*stride run over
+  // in_pixels = B*H*W rows -- four times M for a stride-2 layer (0: the caller has no geometry; a stride-1 layer has in_pixels = M)
+  const long long in_rows = in_pixels > M ? in_pixels : M;
+  if (in_rows * (long long)cin * 4 >= (1LL << 32) || M * (long long)cout * 4 >= (1LL << 32)) return false;
   return ((M + 255) / 256) * (cout / 128) >= opt(OPT_PW256P_MINTILES);
 }
 

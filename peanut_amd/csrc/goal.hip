@@ -51,7 +51,7 @@ namespace {
 constexpr int TILE = 32, HALO = 2, LT = TILE + 2 * HALO;   // 36
 constexpr int MAX_SWEEPS = 96;                             // per round and tile (a front crosses a tile in <= 64)
 constexpr int ROUNDS_PER_CHECK = 8, MAX_ROUNDS_PER_CHECK = 96;
-constexpr int MAX_ORDER_PASSES = 6;     // default of option fmm_max_passes; measured distance to the heap-ordered march: 3 passes 0.39 / 0.70 cell (maze / cluttered map), 4 passes 0.14 / 0.47, fixed point (5-6) 0.14 / 0.03
+constexpr int MAX_ORDER_PASSES = 24;    // default of option fmm_max_passes: a ceiling, the passes end at their fixed point (round 5; a cap of six left the deployed 960 x 960 map unconverged); measured distance to the heap-ordered march: 3 passes 0.39 / 0.70 cell (maze / cluttered map), 4 passes 0.14 / 0.47, fixed point (5-6) 0.14 / 0.03
 
 enum : unsigned char { ST_MASKED = 0, ST_FREE = 1, ST_SEED = 2 };
 

@@ -83,7 +83,7 @@ inline const OptionInfo* option_table() {
       {"rcnn_wino_m", 0, true, "detector front end: 4 / 5 / 6 pins one Winograd form (0: per shape)"},
       {"rcnn_stem_s2d", 1, true, "detector stem 7x7 stride 2 as a space-to-depth 4x4 conv"},
       {"fmm_local32", 1, false, "goal solver: single-precision local solve inside a tile"},
-      {"fmm_max_passes", 6, false, "goal solver: cap of the second-order ordering passes (peanut_goal_converged reports whether they reached their fixed point)"},
+      {"fmm_max_passes", 24, false, "goal solver: hard ceiling of the second-order ordering passes; they stop as soon as a pass changes nothing (6-10 passes on the agent's 960 x 960 map; peanut_goal_converged reports whether they reached their fixed point)"},
   };
   return t;
 }

@@ -236,7 +236,7 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long lo
     if (conv_pw_uses_256wp(d.cout, M, d.stride, mt_per_group, d.bn_tile, d.cin, 0, flush))
       return "conv_pw_glds_256x256p";
     if (conv_pw_uses_256w(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush)) return "conv_pw_glds_256x256";
-    if (conv_pw_uses_256p(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush)) return "conv_pw_glds_256x128p";
+    if (conv_pw_uses_256p(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush, M * d.stride * d.stride)) return "conv_pw_glds_256x128p";
     if (conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return "conv_pw_glds_256x128";
     if (conv_pw_narrow_tiles(d.cin, d.cout, M, d.bn_tile, mt_per_group)) return "conv_pw_glds_128x64";
     return "conv_pw_glds_128x" + std::to_string(d.bn_tile);
@@ -607,7 +607,7 @@ extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
-int peanut_abi_version(void) { return 11; }
+int peanut_abi_version(void) { return 12; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 #ifndef PEANUT_SOURCE_HASH
 #define PEANUT_SOURCE_HASH ""

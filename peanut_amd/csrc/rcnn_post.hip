@@ -700,6 +700,17 @@ struct peanut_rcnn::PostBufs {
   DevBuf det_in, det_out, det_score, det_cls, det_count;
   DevBuf mrois, mlevel, mx0, mx1, mdeconv, mlogits, mprobs, splitk, wino_v, wino_m;
   DevBuf range_flag;   // fp16x3: set when a checked stage output is not finite (see flag_nonfinite)
+  // stage timing (peanut_rcnn_set_stage_timing): one event per stage boundary of the last call, and what each stage had to do
+  static constexpr int kStages = 9;
+  bool timing = false;
+  hipEvent_t ev[kStages + 1] = {};
+  bool ev_made = false;
+  int ev_count = 0;                    // boundaries recorded by the last call (a call without detections ends early)
+  double work[kStages] = {};           // FLOPs (mfma stages) or algorithmic bytes (hbm stages) of the last call
+  ~PostBufs() {
+    if (ev_made)
+      for (auto& e : ev) (void)hipEventDestroy(e);
+  }
 };
 
 namespace {
@@ -888,6 +899,17 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
       (rc = pb.splitk.ensure(kSplitKScratchFloats * sizeof(float))))
     return rc;
 
+  // stage timing: an event on the call's stream at every stage boundary (bench.py's roofline of stage 1's back half)
+  if (pb.timing && !pb.ev_made) {
+    for (auto& e : pb.ev) PEANUT_HIP_CHECK(hipEventCreate(&e));
+    pb.ev_made = true;
+  }
+  pb.ev_count = 0;
+  auto mark = [&]() {
+    if (pb.timing && pb.ev_count <= peanut_rcnn::PostBufs::kStages) (void)hipEventRecord(pb.ev[pb.ev_count++], s);
+  };
+  for (double& w : pb.work) w = 0.0;
+  mark();
   // ---- front end: pyramid p2..p6, objectness, anchor deltas ----
   float *pyr[5], *obj[5], *dl[5];
   for (int l = 0; l < kLevels; ++l) { pyr[l] = (float*)pb.pyr[l].p; obj[l] = (float*)pb.obj[l].p; dl[l] = (float*)pb.dl[l].p; }
@@ -900,6 +922,15 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
     for (int l = 0; l < kLevels; ++l) flag_nonfinite(obj[l], (size_t)B * lv.n[l], (int*)pb.range_flag.p, s);
   }
 
+  {
+    double fl = 0.0;
+    (void)peanut_rcnn_plan(h, B, H, W, nullptr, nullptr, nullptr, nullptr, &fl);
+    pb.work[0] = fl * B;                                                          // front end: direct-form (NOMINAL) conv FLOPs
+    long long anchors = 0;
+    for (int l = 0; l < kLevels; ++l) anchors += lv.n[l];
+    pb.work[1] = (double)B * anchors * 20.0;                                      // RPN selection: objectness + deltas read once
+  }
+  mark();
   // ---- RPN: per-level top-k, decode, per-image sort, NMS (per level), post-NMS top-k ----
   hipLaunchKernelGGL(rpn_topk_kernel, dim3(kLevels, B), dim3(1024), 0, s, lv, Ktot, (int*)pb.sel_idx.p, (float*)pb.sel_score.p);
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(blocks_for((long long)B * Kpad)), dim3(256), 0, s, lv, B, Ktot, Kpad, (const int*)pb.sel_idx.p,
@@ -915,12 +946,22 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
                      (const unsigned char*)pb.keep.p, (const int*)pb.nvalid.p, Ktot, cap, (float*)pb.rois.p, (int*)pb.roi_level.p,
                      (float*)pb.roi_logit.p, (int*)pb.prop_count.p, (int*)pb.dkeys.p);
 
+  mark();
   // ---- box head: ROIAlignV2 7x7 over p2..p5, two FC layers, class scores and box deltas ----
   const float* feats[4] = {pyr[0], pyr[1], pyr[2], pyr[3]};
   const int fhw[8] = {lv.h[0], lv.w[0], lv.h[1], lv.w[1], lv.h[2], lv.w[2], lv.h[3], lv.w[3]};
   const float fsc[4] = {1.f / 4, 1.f / 8, 1.f / 16, 1.f / 32};
   const int P = c.box_pooler_resolution;
   if ((rc = peanut_roi_align(feats, fhw, fsc, 4, F, (const float*)pb.rois.p, (const int*)pb.roi_level.p, N, P, 0, 1, (float*)pb.x7.p, stream))) return rc;
+  {
+    double pyr_bytes = 0.0;
+    for (int l = 0; l < 4; ++l) pyr_bytes += (double)B * lv.h[l] * lv.w[l] * F * 4.0;
+    pb.work[2] = pyr_bytes + (double)N * P * P * F * 4.0;                         // ROIAlign 7x7: the pyramid once + its output
+    const double fc = c.fc_dim;
+    pb.work[3] = 2.0 * N * ((double)P * P * F * fc + fc * fc + fc * (K + 1) + fc * 4.0 * K);   // box head: the four FC GEMMs
+    pb.work[4] = (double)N * ((K + 1) + 4.0 * K) * 4.0 + (double)B * Kc * 24.0;   // class candidates, sort keys, boxes
+  }
+  mark();
   float* sk = (float*)pb.splitk.p;
   if ((rc = conv_on(h->fc1, (const float*)pb.x7.p, (float*)pb.f1.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
   if ((rc = conv_on(h->fc2, (const float*)pb.f1.p, (float*)pb.f2.p, N, 1, 1, sk, nullptr, nullptr, s))) return rc;
@@ -931,6 +972,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
     flag_nonfinite((const float*)pb.bbox.p, (size_t)N * 4 * K, (int*)pb.range_flag.p, s);
   }
 
+  mark();
   // ---- fast_rcnn_inference: class candidates, per-image sort, class-wise NMS, top detections ----
   hipLaunchKernelGGL(box_post_kernel, dim3(blocks_for(N)), dim3(256), 0, s, (const float*)pb.cls.p, (const float*)pb.bbox.p, (const float*)pb.rois.p,
                      (const int*)pb.prop_count.p, B, cap, K, Kcpad, (float)nh, (float)nw, c.roi_bbox_weights[0], c.roi_bbox_weights[1],
@@ -949,6 +991,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
                      (const unsigned char*)pb.dkeep.p, (const int*)pb.dnvalid.p, Kc, D, sx, sy, (float)H, (float)W, (float*)pb.det_in.p,
                      (float*)pb.det_out.p, (float*)pb.det_score.p, (int*)pb.det_cls.p, (int*)pb.det_count.p);
 
+  mark();
   // ---- the one host read: detections per image ----
   PEANUT_HIP_CHECK(hipMemcpyAsync(n_det_host, pb.det_count.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   int range_bad = 0;
@@ -977,6 +1020,31 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
       (rc = pb.mdeconv.ensure((size_t)n * Pm * Pm * 4 * mc * 4)) || (rc = pb.mlogits.ensure((size_t)n * Pm * Pm * 4 * K * 4)) ||
       (rc = pb.mprobs.ensure((size_t)n * 4 * Pm * Pm * 4)) || (vf && (rc = pb.wino_v.ensure(vf * 4))) || (mf && (rc = pb.wino_m.ensure(mf * 4))))
     return rc;
+  mark();
+  {
+    double pyr_bytes = 0.0;
+    for (int l = 0; l < 4; ++l) pyr_bytes += (double)B * lv.h[l] * lv.w[l] * F * 4.0;
+    pb.work[6] = pyr_bytes + (double)n * Pm * Pm * F * 4.0;                       // ROIAlign 14x14
+    double fl = 0.0;
+    int cin = F;
+    for (const ConvLayer* L : h->mask_fcn) {
+      // EXECUTED FLOPs: a layer that runs as Winograd F(m x m, 3 x 3) multiplies (m + 2)^2 positions per m x m output tile
+      // instead of 9 taps per output pixel
+      const ConvLayer* R = L->has_wino ? wino_pick_form(L, n, Pm, Pm) : L;
+      if (R->has_wino) {
+        const double tiles = (double)n * ((Pm + R->wino_m - 1) / R->wino_m) * ((Pm + R->wino_m - 1) / R->wino_m);
+        fl += 2.0 * tiles * R->wino_np() * (double)cin * L->d.cout;
+      } else {
+        fl += 2.0 * n * Pm * Pm * (double)cin * L->d.cout * 9.0;
+      }
+      cin = L->d.cout;
+    }
+    fl += 2.0 * n * Pm * Pm * (double)cin * mc * 4.0;                             // 2x2 stride-2 transposed conv
+    fl += 2.0 * n * 4.0 * Pm * Pm * (double)mc * K;                               // class logits
+    pb.work[7] = fl;
+    pb.work[8] = (double)n * 4.0 * Pm * Pm * (K + 1) * 4.0 + (sem.out ? (double)B * H * W * (sem.n_cats + 1) * 4.0 : 0.0) +
+                 (masks ? (double)n * H * W : 0.0);                               // logits -> probabilities, paste / accumulate
+  }
   hipLaunchKernelGGL(pack_dets_kernel, dim3(blocks_for(n)), dim3(256), 0, s, (const float*)pb.det_in.p, (const float*)pb.det_out.p,
                      (const float*)pb.det_score.p, (const int*)pb.det_cls.p, D, B, of, (float*)pb.mrois.p, (int*)pb.mlevel.p, boxes, scores, classes);
   if (!masks && !sem.out) {
@@ -985,6 +1053,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   }
   // ---- mask head: ROIAlignV2 14x14, conv stack, 2x2 transposed conv, class logits, sigmoid; paste at 0.5 ----
   if ((rc = peanut_roi_align(feats, fhw, fsc, 4, F, (const float*)pb.mrois.p, (const int*)pb.mlevel.p, n, Pm, 0, 1, (float*)pb.mx0.p, stream))) return rc;
+  mark();
   float *cur = (float*)pb.mx0.p, *nxt = (float*)pb.mx1.p;
   for (const ConvLayer* L : h->mask_fcn) {
     if ((rc = conv_on(L, cur, nxt, n, Pm, Pm, sk, L->has_wino ? (float*)pb.wino_v.p : nullptr, L->has_wino ? (float*)pb.wino_m.p : nullptr, s))) return rc;
@@ -992,6 +1061,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   }
   if ((rc = conv_on(h->deconv, cur, (float*)pb.mdeconv.p, n, Pm, Pm, sk, nullptr, nullptr, s))) return rc;
   if ((rc = conv_on(h->mask_pred, (const float*)pb.mdeconv.p, (float*)pb.mlogits.p, n, Pm, Pm * 4, sk, nullptr, nullptr, s))) return rc;
+  mark();
   hipLaunchKernelGGL(mask_prob_kernel, dim3(blocks_for((long long)n * 4 * Pm * Pm)), dim3(256), 0, s, (const float*)pb.mlogits.p, (const int*)classes, n,
                      Pm, K, (float*)pb.mprobs.p);
   if (range_check) flag_nonfinite((const float*)pb.mlogits.p, (size_t)n * Pm * Pm * 4 * K, (int*)pb.range_flag.p, s);
@@ -1004,6 +1074,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
                        (const float*)scores, (const int*)classes, of, 2 * Pm, H, W, c.mask_threshold, sem.n_cats, sem.thr, sem.goal_thr, goal,
                        sem.out, total);
   }
+  mark();
   if (range_check) {      // the mask head's own overflow: one more 4-byte read (fp16x3 only)
     PEANUT_HIP_CHECK(hipMemcpyAsync(&range_bad, pb.range_flag.p, 4, hipMemcpyDeviceToHost, s));
     PEANUT_HIP_CHECK(hipStreamSynchronize(s));
@@ -1026,6 +1097,35 @@ extern "C" int peanut_rcnn_semantic(peanut_rcnn_t* h, const uint8_t* img_bgr, in
   SemanticOut so;
   so.out = semantic; so.n_cats = n_cats; so.thr = sem_pred_prob_thr; so.goal_thr = goal_thr; so.goal_cat = goal_cat_host;
   return rcnn_inference_impl(h, img_bgr, B, H, W, n_det_host, boxes, scores, classes, masks, so, stream);
+}
+
+extern "C" int peanut_rcnn_set_stage_timing(peanut_rcnn_t* h, int on) {
+  if (!h) return fail(PEANUT_EINVAL, "peanut_rcnn_set_stage_timing: null handle");
+  if (!h->post) h->post = std::make_shared<peanut_rcnn::PostBufs>();
+  h->post->timing = on != 0;
+  h->post->ev_count = 0;
+  return 0;
+}
+
+extern "C" int peanut_rcnn_stage_times(peanut_rcnn_t* h, int max_stages, const char** names, const char** bounds, double* ms, double* work) {
+  if (!h || !h->post || !h->post->timing) return fail(PEANUT_EINVAL, "peanut_rcnn_stage_times: stage timing is not enabled on this handle");
+  peanut_rcnn::PostBufs& pb = *h->post;
+  static const char* const kNames[peanut_rcnn::PostBufs::kStages] = {
+      "front_end", "rpn_selection", "roi_align_7x7", "box_head_fc", "box_postprocess_nms", "host_read_detection_counts",
+      "roi_align_14x14", "mask_head_convs", "mask_probabilities_paste"};
+  static const char* const kBounds[peanut_rcnn::PostBufs::kStages] = {"mfma", "hbm", "hbm", "mfma", "hbm", "host", "hbm", "mfma", "hbm"};
+  const int n = pb.ev_count - 1;
+  if (n < 1) return fail(PEANUT_EINVAL, "peanut_rcnn_stage_times: no timed call has run");
+  if (hipEventSynchronize(pb.ev[n]) != hipSuccess) return fail(PEANUT_EHIP, "peanut_rcnn_stage_times: event synchronise failed");
+  for (int i = 0; i < n && i < max_stages; ++i) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, pb.ev[i], pb.ev[i + 1]);
+    if (names) names[i] = kNames[i];
+    if (bounds) bounds[i] = kBounds[i];
+    if (ms) ms[i] = t;
+    if (work) work[i] = pb.work[i];
+  }
+  return n;
 }
 
 // test / bisect hook: device pointers of the stage outputs of the last peanut_rcnn_inference call

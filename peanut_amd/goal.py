@@ -34,7 +34,9 @@ class GeodesicSolver:
         self.device = torch.device(device)
         self.H, self.W, self.col_rad = int(full_h), int(full_w), int(col_rad)
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        # (an empty default_options block = the option lock: a handle snapshots the process defaults while it is created, and must
+        # not do so in the middle of another thread's `with default_options(...)`)
+        with _lib.default_options(), torch.cuda.device(self.device):
             _lib.check(self._lib.peanut_goal_create(C.byref(self._h), self.H, self.W, self.col_rad), "peanut_goal_create")
 
     def __del__(self):
@@ -89,9 +91,10 @@ class GeodesicSolver:
         return out
 
     def _note_convergence(self):
-        """The ordering passes of the second-order stage stop at a cap (library option ``fmm_max_passes``, default 6); a
-        solve that hit it with its last pass still changing tiles returns the last iterate, not the fixed point (measured
-        effect: a few hundredths of a cell).  Said once per solver instead of passing silently."""
+        """The ordering passes of the second-order stage run until a pass changes nothing, under a hard ceiling (library
+        option ``fmm_max_passes``, default 24: the agent's maps need 6-10); a solve that hit the ceiling with its last pass
+        still changing tiles returns the last iterate, not the fixed point (measured effect of stopping after six: a few
+        hundredths of a cell).  Said once per solver instead of passing silently."""
         if not self.converged and not getattr(self, "_warned_unconverged", False):
             import warnings
             self._warned_unconverged = True

@@ -40,7 +40,7 @@ class Semantic_Mapping(nn.Module):
             setattr(c, f, getattr(args, f))
         self.num_sem_categories = args.num_sem_categories
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with _lib.default_options(), torch.cuda.device(self.device):     # (the option lock: see _lib.default_options)
             _lib.check(self._lib.peanut_map_create(C.byref(self._h), C.byref(c)), "peanut_map_create")
         dims = (C.c_int * 4)()
         _lib.check(self._lib.peanut_map_dims(self._h, C.byref(dims)), "peanut_map_dims")

@@ -55,7 +55,7 @@ class MaskRCNNFront:
         c.score_thresh_test, c.nms_thresh_test = cfg.score_thresh_test, cfg.nms_thresh_test
         c.detections_per_image, c.mask_threshold = cfg.detections_per_image, cfg.mask_threshold
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with _lib.default_options(), torch.cuda.device(self.device):     # (the option lock: see _lib.default_options)
             _lib.check(self._lib.peanut_rcnn_create(C.byref(self._h), C.byref(c), arr, len(tensors)), "peanut_rcnn_create")
 
     def _extra_keys(self, cfg, state_dict):
@@ -266,7 +266,24 @@ class MaskRCNN(MaskRCNNFront):
                                                 goals, sem.data_ptr(), n_det, boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(), None,
                                                 _lib.current_stream_ptr(dev))
         _lib.check(rc, "peanut_rcnn_semantic")
+        self.last_detection_counts = list(n_det)      # detections per frame of this call (the call's one host read)
         return sem
+
+    def set_stage_timing(self, on: bool = True) -> None:
+        """Record a HIP event at every stage boundary of the following ``inference`` / ``semantic`` calls
+        (``peanut_rcnn_set_stage_timing``; read with ``stage_times``)."""
+        _lib.check(self._lib.peanut_rcnn_set_stage_timing(self._h, int(bool(on))), "peanut_rcnn_set_stage_timing")
+
+    def stage_times(self):
+        """[(stage, bound, ms, work)] of the last timed call: bound is "mfma" (work = FLOPs), "hbm" (work = algorithmic bytes)
+        or "host" (``peanut_rcnn_stage_times``)."""
+        cap = 16
+        names, bounds = (C.c_char_p * cap)(), (C.c_char_p * cap)()
+        ms, work = (C.c_double * cap)(), (C.c_double * cap)()
+        n = self._lib.peanut_rcnn_stage_times(self._h, cap, names, bounds, ms, work)
+        if n < 0:
+            _lib.check(n, "peanut_rcnn_stage_times")
+        return [(names[i].decode(), bounds[i].decode(), float(ms[i]), float(work[i])) for i in range(min(n, cap))]
 
     def debug_stage(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         """Copy of a stage buffer of the last ``inference`` call (peanut_rcnn_debug_stage)."""

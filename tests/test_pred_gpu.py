@@ -528,6 +528,15 @@ def test_full_size_batch_properties(model_and_sd):
     p = m.get_prediction_batch(x, apply_sigmoid=True)
     assert bool(((p > 0) & (p < 1)).all())
     assert (p - torch.sigmoid(y)).abs().max().item() <= 1e-6
+    # (e) the kernel family that carries most of this step is the one bench.py names (bench.DOMINANT_FAMILY_FP32): its HBM
+    # traffic in profiles/hbm_traffic.json is what an N > 1 bench line reports (tests/test_dist_cpu.py checks the file side)
+    import bench
+    fam = {}
+    for name, kern, ms, fl, by in m.model.profile(x, repeats=2):
+        fam[kern] = fam.get(kern, 0.0) + ms
+    top = max(fam, key=fam.get)
+    print(f"dominant family at B=32 480x480: {top} ({fam[top]:.2f} ms of {sum(fam.values()):.2f})")
+    assert top == bench.DOMINANT_FAMILY_FP32, sorted(fam.items(), key=lambda kv: -kv[1])[:4]
 
 
 @pytest.mark.slow
@@ -593,9 +602,11 @@ def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
     """Sixteen 480 x 480 maps against the ORACLE at a size where the round-4 kernels carry the layers they carry in the
     headline benchmark -- asserted by kernel family per op: the persistent A-resident kernel (csrc/conv_pw_ares.hip) runs
     layer2 / layer3 conv3 and the position GEMMs of their Winograd conv2 (57 600 rows = 450 whole 128-row tiles), the
-    256 x 256 kernel (csrc/conv_pw.hip) layer4.0's conv3 + downsample (1 800 tiles), the persistent 256 x 128 kernel
-    (csrc/conv_pw256p.hip) the K >= 512 layers with at least 512 tiles.  Then the same maps through a handle
-    with the three kernels switched off by option (csrc/options.h): the families sum in the same k order (bit-identical at
+    persistent 256 x 256 kernel of round 5 (csrc/conv_pw256wp.hip: stride 1, K >= 512, at least 768 tiles) layer4's conv3
+    (1 800 tiles) and the conv3 + downsample GEMMs of layer3.0 / layer4.0, the persistent 256 x 128 kernel (csrc/conv_pw256p.hip)
+    the remaining K >= 512 layers with at least 512 tiles (layer4 conv1: 450 tiles of 256 x 256 are below the new kernel's gate
+    at this batch; at the headline's 32 maps they run on it).  Then the same maps through a handle with the four kernels
+    switched off by option (csrc/options.h): the families sum in the same k order (bit-identical at
     operator level, tests/test_conv_gpu.py), but the tile-per-workgroup kernels cut the k range of their LAST round's tiles
     (tail split-K) and which tiles those are depends on the tile size -- so the two handles agree to rounding, not to the
     bit -- and the options of one handle must not leak into the other."""
@@ -612,12 +623,12 @@ def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
     ops = {name: kern for name, kern, *_ in m.model.profile(xd)}
     print(f"fp32: B=16 480x480 vs oracle max-abs {err:.3e}; "
           f"{sum(k == 'conv_pw_ares_128x128' for k in ops.values())} ops on conv_pw_ares_128x128, "
-          f"{sum(k == 'conv_pw_glds_256x256' for k in ops.values())} on conv_pw_glds_256x256")
+          f"{sum(k == 'conv_pw_glds_256x256p' for k in ops.values())} on conv_pw_glds_256x256p")
     assert err <= TOL
     want = {"conv_pw_ares_128x128": ["layer2.1.conv3", "layer2.3.conv2[wino6_gemm]", "layer3.1.conv3", "layer3.5.conv3",
                                      "layer3.2.conv2[wino6_gemm]", "layer2.0.conv1"],
-            "conv_pw_glds_256x256": ["layer4.0.conv3+downsample"],
-            "conv_pw_glds_256x128p": ["layer4.0.conv1", "layer4.1.conv1", "layer4.1.conv3", "layer4.2.conv3", "layer3.0.conv3+downsample"],
+            "conv_pw_glds_256x256p": ["layer4.0.conv3+downsample", "layer3.0.conv3+downsample", "layer4.1.conv3", "layer4.2.conv3"],
+            "conv_pw_glds_256x128p": ["layer4.0.conv1", "layer4.1.conv1"],
             "conv_pw_glds_256x128": ["layer3.1.conv1", "bottleneck.conv[x][wino6_gemm]"]}
     for family, layers in want.items():
         for layer in layers:
@@ -627,13 +638,14 @@ def test_b16_480_forward_vs_oracle_on_the_round4_kernels(model_and_sd):
     plain.model.set_option("pw_ares", 0)
     plain.model.set_option("pw256w_mink", 0)
     plain.model.set_option("pw256p_mink", 0)
+    plain.model.set_option("pw256wp_mink", 0)
     assert plain.model.get_option("pw_ares") == 0 and m.model.get_option("pw_ares") == 1
     got2 = plain.get_prediction_batch(xd, apply_sigmoid=False)
     ops2 = {name: kern for name, kern, *_ in plain.model.profile(xd)}
-    assert not any(k in ("conv_pw_ares_128x128", "conv_pw_glds_256x256", "conv_pw_glds_256x128p") for k in ops2.values())
+    assert not any(k in ("conv_pw_ares_128x128", "conv_pw_glds_256x256", "conv_pw_glds_256x128p", "conv_pw_glds_256x256p") for k in ops2.values())
     err2 = (got2.cpu() - ref).abs().max().item()
     diff = float((got - got2).abs().max())
-    print(f"same maps with pw_ares = 0, pw256w_mink = 0, pw256p_mink = 0: vs oracle {err2:.3e}, between the two handles {diff:.3e}")
+    print(f"same maps with pw_ares = 0, pw256w_mink = 0, pw256p_mink = 0, pw256wp_mink = 0: vs oracle {err2:.3e}, between the two handles {diff:.3e}")
     assert err2 <= TOL and diff <= 3e-5
     del plain
 

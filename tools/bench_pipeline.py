@@ -48,7 +48,7 @@ def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, 
     from peanut_amd.agent_state import default_args   # nav/arguments.py defaults
     args = default_args(only_explore=0, sem_gpu_id=dev.index, pred_precision=precision, select_goal=goal)
     st = Agent_State(args, state_dict=make_seeded_state_dict(PredCfg(), 0))
-    goal_ms, goal_n, goal_rounds = [0.0], [0], [0]
+    goal_ms, goal_n, goal_rounds, goal_passes, goal_unconverged = [0.0], [0], [0], [0], [0]
     if goal:      # time the goal selection separately (it synchronises anyway: the goal cell goes to the host)
         inner = st.update_global_goal
 
@@ -59,6 +59,8 @@ def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, 
             goal_ms[0] += (time.perf_counter() - t) * 1e3
             goal_n[0] += 1
             goal_rounds[0] += st.goal_rounds
+            goal_passes[0] += st.goal_passes
+            goal_unconverged[0] += 0 if st.goal_converged else 1
         st.update_global_goal = timed
     mine = episode_shard(episodes)
     eps = {e: synth_episode(1000 + e, frames, dev) for e in mine}
@@ -75,7 +77,7 @@ def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, 
         run_episode(st, eps[mine[0]][:12], goal_cat=3, detector=det)     # warm-up (plans, workspaces)
     torch.cuda.synchronize()
     pdist.barrier()
-    goal_ms[0], goal_n[0], goal_rounds[0] = 0.0, 0, 0
+    goal_ms[0], goal_n[0], goal_rounds[0], goal_passes[0], goal_unconverged[0] = 0.0, 0, 0, 0, 0
     t0 = time.perf_counter()
     n_pred = 0
     for e in mine:
@@ -91,7 +93,9 @@ def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, 
             "n_gpus": world, "steps_per_s": round(steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "predictions_rank0": n_pred, "precision": precision,
             "goal_selection_ms_per_call": round(goal_ms[0] / goal_n[0], 3) if goal_n[0] else None,
-            "goal_selection_rounds_per_call": round(goal_rounds[0] / goal_n[0], 1) if goal_n[0] else None}
+            "goal_selection_rounds_per_call": round(goal_rounds[0] / goal_n[0], 1) if goal_n[0] else None,
+            "goal_selection_passes_per_call": round(goal_passes[0] / goal_n[0], 1) if goal_n[0] else None,
+            "goal_selection_calls_unconverged": goal_unconverged[0] if goal_n[0] else None}
 
 
 def main():
