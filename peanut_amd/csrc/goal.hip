@@ -385,7 +385,7 @@ struct peanut_goal {
   int last_lw = 0, last_lh = 0;
   int last_rounds = 0, last_passes = 0;
   bool last_converged = true;      // false: the ordering passes hit MAX_ORDER_PASSES with the last one still changing tiles
-  int round_hint[1 + 8] = {0};     // rounds each stage needed in the previous solve (run_stage)
+  int round_hint[1 + 64] = {0};    // rounds each stage needed in the previous solve (run_stage); stage 0 + up to 64 ordering passes (fmm_max_passes is clamped to 64)
 };
 
 namespace {
