@@ -517,11 +517,13 @@ bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_pe
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
   const int phase_shift_w = opt(OPT_PW256_PHASE) != 0;
-  if (conv_pw_uses_ares(p.c1, p.cout, p.M, p.stride, p.c2 != 0, p.flush, bn_tile)) return launch_conv_pw_ares(p, bn_tile, stream);
+  // (the persistent 256 x 256 kernel first: its gate starts at 512 input channels by default, above the A-resident kernel's K = 128 / 256
+  // layers; lowering pw256wp_mink hands those to it)
   if (conv_pw_uses_256wp(p.cout, p.M, p.stride, p.mt_per_group, bn_tile, p.c1, p.c2, p.flush)) {
     const int rc = launch_conv_pw256wp(p, ws, ws_floats, stream);
     if (rc != 1) return rc;
   }
+  if (conv_pw_uses_ares(p.c1, p.cout, p.M, p.stride, p.c2 != 0, p.flush, bn_tile)) return launch_conv_pw_ares(p, bn_tile, stream);
   if (conv_pw_uses_256w(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, p.flush)) {
     static SlotCache slots256w;
     ConvKParams q = p;

@@ -232,9 +232,9 @@ std::string conv_kernel_name(const ConvDesc& d, bool two_source = false, long lo
   if (d.bk == 32 && d.kh == 1 && d.kw == 1 && d.pad == 0 && (!two_source || d.stride == 1) && d.cin % 32 == 0 && conv_pw_enabled())
   {
     const int flush = d.flush_ch / d.bk;
-    if (conv_pw_uses_ares(d.cin, d.cout, M, d.stride, two_source, flush, d.bn_tile)) return "conv_pw_ares_128x128";
     if (conv_pw_uses_256wp(d.cout, M, d.stride, mt_per_group, d.bn_tile, d.cin, 0, flush))
       return "conv_pw_glds_256x256p";
+    if (conv_pw_uses_ares(d.cin, d.cout, M, d.stride, two_source, flush, d.bn_tile)) return "conv_pw_ares_128x128";
     if (conv_pw_uses_256w(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush)) return "conv_pw_glds_256x256";
     if (conv_pw_uses_256p(d.cout, M, mt_per_group, d.bn_tile, d.cin, flush, M * d.stride * d.stride)) return "conv_pw_glds_256x128p";
     if (conv_pw_uses_256(d.cout, M, mt_per_group, d.bn_tile, d.cin)) return "conv_pw_glds_256x128";
