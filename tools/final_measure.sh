@@ -5,7 +5,9 @@ OUT=${1:-gpurun_out/final}
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/$OUT
 cd $R
+if [ "${SKIP_PYTEST:-0}" != "1" ]; then
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|max-abs|max \|GPU|final map|vs oracle|fp64|worst" > $OUT/pytest_gpu.txt
+fi
 python bench.py --steps 20 --warmup 5 --op-table $OUT/op_table_fp32.json > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 for m in bf16x6 fp16x3 bf16x3; do python bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --also "" --traffic measure --op-table $OUT/op_table_$m.json 2>/dev/null | grep "^{" ; done > $OUT/bench_modes.json
 python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --also "bf16x6,fp16x3" --traffic none 2>/dev/null | grep "^{" > $OUT/bench_config5.json
@@ -32,6 +34,12 @@ rm -rf /tmp/fm_trace2
 rocprofv3 --kernel-trace -d /tmp/fm_trace2 -- python $R/tools/measure_mapping.py > $R/$OUT/mapping_measure.json 2>/dev/null
 db=$(find /tmp/fm_trace2 -name '*.db' | head -1); [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $R/$OUT/mapping_trace.txt
 cd $R
+# batch-1 gap table (round 5): per op of one 720 x 720 map / one detector frame against the batch rates + the launch timeline
+cd /tmp; rm -rf /tmp/fm_tl
+rocprofv3 --kernel-trace -d /tmp/fm_tl -- python $R/bench.py --batch 1 --size 720 --steps 30 --warmup 5 --no-cpu-baseline --no-probe --also "" --traffic none --configs "" > /tmp/fm_tl.log 2>&1
+db=$(find /tmp/fm_tl -name '*.db' | head -1)
+cd $R
+python tools/gap_b1.py $OUT/gap_b1.json ${db:+--timeline-db $db --timeline-forwards 20} > $OUT/gap_b1_summary.txt 2>/dev/null
 tools/pmc_passes.sh $OUT/pmc_fp32 --precision fp32
 tools/pmc_passes.sh $OUT/pmc_bf16x6 --precision bf16x6
 tools/pmc_passes.sh $OUT/pmc_fp16x3 --precision fp16x3
