@@ -63,7 +63,11 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   constexpr int BM = 256, BN = 128, BK = 32, WN = 2;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;   // 48 KiB
   constexpr int A_INSTR = 4, B_INSTR = 2;
-  __shared__ __attribute__((aligned(1024))) float smem[3 * STAGE];
+  // ONE LDS object: the three stages and, behind them, the workgroup's plan table (a second __shared__ variable would make hipcc
+  // attach alias scopes to the LDS accesses and wait `vmcnt(0)` between every LDS-DMA request and the fragment reads: conv_pw256wp.hip)
+  constexpr int kMaxItems = 120;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * STAGE + kMaxItems * 8];
+  int* const plan = reinterpret_cast<int*>(smem + 3 * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +88,10 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   const int n_frag = u1 > u0 ? (u1 - 1) / upt - u0 / upt + 1 : 0;
   const int n_items = nf + (skU > 0 ? n_frag : sp1 - sp0);
   if (n_items == 0) return;
-  auto item_at = [&](int i) {
+  // The items are worked out ONCE, one per thread, into the LDS plan table (round 5, as in conv_pw256wp.hip): the 64-bit divisions of
+  // the stream-K bookkeeping were inlined at every use of item_at -- four places -- and cost the kernel 100-170 spilled SGPRs.
+  if (tid < n_items) {
+    const int i = tid;
     PItem it;
     int tile;
     if (i >= nf && skU > 0) {
@@ -109,6 +116,18 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
       it.kt1 = (int)((long long)(part + 1) * p.nkt / p.split_p);
     }
     tile_to_mn(p, tile, &it.mt, &it.nt);
+    int* e = plan + i * 8;
+    e[0] = it.mt; e[1] = it.nt; e[2] = it.kt0; e[3] = it.kt1; e[4] = it.part;
+  }
+  __syncthreads();
+  auto item_at = [&](int i) {
+    const int* e = plan + i * 8;
+    PItem it;
+    it.mt = __builtin_amdgcn_readfirstlane(e[0]);
+    it.nt = __builtin_amdgcn_readfirstlane(e[1]);
+    it.kt0 = __builtin_amdgcn_readfirstlane(e[2]);
+    it.kt1 = __builtin_amdgcn_readfirstlane(e[3]);
+    it.part = __builtin_amdgcn_readfirstlane(e[4]);
     return it;
   };
 
@@ -498,6 +517,7 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
     }
   }
   if (p.n_sp > 0 && (!ws || (size_t)p.n_sp * 256 * 128 > ws_floats)) return fail(-2, "conv_pw256p: split-K scratch too small");
+  if (p.n_full / G + (p.n_sp + G - 1) / G + 4 > 120) return fail(-2, "conv_pw256p: more items per workgroup than the plan table holds");
   p.partial = ws;
   p.mtiles = mtiles;
   p.nchunk = (int)opt(OPT_NCHUNK);
