@@ -287,7 +287,12 @@ int peanut_rcnn_plan(peanut_rcnn_t* h, int B, int H, int W, int resized_hw[2], i
                      size_t* workspace_bytes, double* flops_per_image);
 /* img_bgr: device uint8 [B,H,W,3] (what DefaultPredictor receives, segmentation.py:44-45).  Outputs
  * (device fp32 NHWC, each array has 5 entries for p2..p6, entries or whole arrays may be NULL):
- * pyramid[l] [B,h_l,w_l,fpn_out], objectness[l] [B,h_l,w_l,A], deltas[l] [B,h_l,w_l,4A]. */
+ * pyramid[l] [B,h_l,w_l,fpn_out], objectness[l] [B,h_l,w_l,A], deltas[l] [B,h_l,w_l,4A].
+ * The RPN head runs on all five levels as ONE chain (five Winograd input transforms, one grouped position GEMM, five output
+ * transforms, one objectness and one anchor-delta GEMM over all levels' rows: 12 launches instead of 25; option rcnn_rpn_fused)
+ * whenever objectness[0..4] -- and deltas[0..4] -- are consecutive pieces of ONE buffer in level order (objectness[l + 1] ==
+ * objectness[l] + B*h_l*w_l*A), or are not asked for; scattered buffers get the level-by-level launches.  The small levels may
+ * then take another Winograd tile size than on their own: results agree to ~1e-5. */
 int peanut_rcnn_forward_front(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int H, int W, float* const* pyramid,
                               float* const* objectness, float* const* deltas, void* stream);
 

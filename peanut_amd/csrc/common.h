@@ -105,10 +105,12 @@ void wino_geometry(int B, int H, int W, int dil, int* th, int* tw, long long* n_
 // host: OIHW 3x3 weights -> U [36][cout][cin]
 void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, int m = 4);   // m = 4: U [36]..., m = 6: U [64][cout][cin]
 // x [B,H,W,C] -> V [36][m_pad][C] fp32
-int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran = 128, int m = 4);
+// m_pad_total > 0: the rows of a position are shared by several tensors (the five RPN levels as one grouped GEMM): V / Mb point at this
+// tensor's first tile, positions are m_pad_total rows apart
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran = 128, int m = 4, long long m_pad_total = 0);
 // Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res)
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
-                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran = 128, int m = 4);
+                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran = 128, int m = 4, long long m_pad_total = 0);
 
 // ---- emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers (gemm_rs.hip) ----
 // whether the 256 x 256 kernel runs a [M x cout] output (mt_per_group: 128-row tiles per Winograd position, 0 = plain)

@@ -407,19 +407,61 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
   rel(prev);
   p[4] = make_act(ar, B, (p[3].H - 1) / 2 + 1, (p[3].W - 1) / 2 + 1, p[3].C);
   { ROp op; op.kind = R_SUBSAMPLE; op.name = "p6"; op.kernel = "subsample2"; op.in = p[3]; op.out = p[4]; op.ext_slot = 4; op.in_ext_slot = 3; pl->ops.push_back(op); }
-  // RPN head on p2..p6
+  // RPN head on p2..p6: the fused chain over all levels (RpnFused; taken at run time when the caller's objectness / delta buffers
+  // are contiguous in level order or absent) ...
+  if (h->rpn_conv->has_wino && opt(OPT_RCNN_RPN_FUSED) != 0) {
+    RpnFused& f = pl->rpn;
+    f.form = wino_pick_form(h->rpn_conv, B, p[0].H, p[0].W);
+    const int cin = f.form->d.cin, cout = f.form->d.cout, A = h->rpn_obj->d.cout;
+    long long tiles = 0, rows = 0;
+    double fl = 0.0;
+    for (int lvl = 0; lvl < 5; ++lvl) {
+      int th, tw;
+      long long nt, mp;
+      wino_geometry(B, p[lvl].H, p[lvl].W, 1, &th, &tw, &nt, &mp, 128, f.form->wino_m);
+      f.in[lvl] = p[lvl];
+      f.tile_off[lvl] = tiles; tiles += nt;
+      f.row_off[lvl] = rows; rows += (long long)B * p[lvl].H * p[lvl].W;
+      Act out_l = p[lvl]; out_l.C = cout;
+      fl += conv_flops(h->rpn_conv, out_l);
+      out_l.C = A; fl += conv_flops(h->rpn_obj, out_l);
+      out_l.C = 4 * A; fl += conv_flops(h->rpn_delta, out_l);
+    }
+    f.gran = tiles >= 2048 ? 256 : 128;
+    f.m_pad_total = (tiles + f.gran - 1) / f.gran * f.gran;
+    f.rows = rows;
+    if ((long long)f.form->wino_np() * f.m_pad_total <= 0x7fffffffLL && rows <= 0x7fffffffLL) {
+      f.v = make_act(ar, 1, 1, (int)((long long)f.form->wino_np() * f.m_pad_total), cin);
+      f.m = make_act(ar, 1, 1, (int)((long long)f.form->wino_np() * f.m_pad_total), cout);
+      f.t_all = make_act(ar, 1, 1, (int)rows, cout);
+      f.obj_all = make_act(ar, 1, 1, (int)rows, A);
+      f.dl_all = make_act(ar, 1, 1, (int)rows, 4 * A);
+      f.on = true;
+      ROp op;
+      op.kind = R_RPN_FUSED; op.name = "proposal_generator.rpn_head[p2..p6 fused]"; op.kernel = "rpn_fused"; op.flops = fl;
+      pl->ops.push_back(op);
+      rel(f.v); rel(f.m); rel(f.t_all); rel(f.obj_all); rel(f.dl_all);
+    }
+  }
+  // ... and level by level (fifteen convs; the form that runs when the outputs are scattered buffers, or option rcnn_rpn_fused = 0)
   for (int lvl = 0; lvl < 5; ++lvl) {
     pl->lvl_h[lvl] = p[lvl].H; pl->lvl_w[lvl] = p[lvl].W;
     Act t = conv_out_act(ar, h->rpn_conv, p[lvl]);
     push_rconv(*pl, ar, h->rpn_conv, p[lvl], nullptr, t);
     pl->ops.back().in_ext_slot = lvl;
+    pl->ops.back().rpn_level = true;
     Act o = conv_out_act(ar, h->rpn_obj, t);
     push_rconv(*pl, ar, h->rpn_obj, t, nullptr, o, 5 + lvl);
+    pl->ops.back().rpn_level = true;
     Act dl = conv_out_act(ar, h->rpn_delta, t);
     push_rconv(*pl, ar, h->rpn_delta, t, nullptr, dl, 10 + lvl);
+    pl->ops.back().rpn_level = true;
     rel(t); rel(o); rel(dl);
   }
   size_t hw = pl->splitk.off + Arena::round_up(pl->splitk.bytes);
+  if (pl->rpn.on)
+    for (const Act* a : {&pl->rpn.v, &pl->rpn.m, &pl->rpn.t_all, &pl->rpn.obj_all, &pl->rpn.dl_all})
+      if (a->off + Arena::round_up(a->bytes) > hw) hw = a->off + Arena::round_up(a->bytes);
   for (const auto& op : pl->ops)
     for (const Act* a : {&op.in, &op.in2, &op.res, &op.out, &op.wino_v, &op.wino_m})
       if (a->bytes && a->off + Arena::round_up(a->bytes) > hw) hw = a->off + Arena::round_up(a->bytes);
@@ -560,10 +602,66 @@ static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
   // outputs the caller asked for are written in place (and read from there by the ops that consume them)
   auto OUT = [&](const ROp& op) -> float* { float* e = ext(op.ext_slot); return e ? e : P(op.out); };
   auto IN = [&](const ROp& op) -> float* { float* e = ext(op.in_ext_slot); return e ? e : P(op.in); };
+  // the fused RPN chain needs every level's objectness (and deltas) in ONE buffer, level after level: true for the library's own
+  // scratch and for peanut_rcnn_inference's buffers; a caller with scattered buffers gets the level-by-level launches
+  bool rpn_fused = pl->rpn.on;
+  if (rpn_fused) {
+    const int A = h->rpn_obj->d.cout;
+    for (int pass = 0; pass < 2 && rpn_fused; ++pass) {
+      float* const* arr = pass == 0 ? objectness : deltas;
+      const int w = pass == 0 ? A : 4 * A;
+      if (!arr) continue;
+      int given = 0;
+      for (int l = 0; l < 5; ++l) given += arr[l] != nullptr;
+      if (given == 0) continue;
+      if (given != 5) { rpn_fused = false; break; }
+      for (int l = 1; l < 5; ++l)
+        if (arr[l] != arr[0] + (size_t)pl->rpn.row_off[l] * w) rpn_fused = false;
+    }
+  }
   if (events) PEANUT_HIP_CHECK(hipEventRecord(events[0], s));
   size_t op_index = 0;
   for (const auto& op : pl->ops) {
+    const bool skip = (op.kind == R_RPN_FUSED && !rpn_fused) || (op.rpn_level && rpn_fused);
+    if (skip) {
+      if (families) families[op_index] = "skipped";
+      ++op_index;
+      if (events) PEANUT_HIP_CHECK(hipEventRecord(events[op_index], s));
+      continue;
+    }
     switch (op.kind) {
+      case R_RPN_FUSED: {
+        const RpnFused& f = pl->rpn;
+        const ConvLayer& L = *f.form;
+        const int cin = L.d.cin, cout = L.d.cout, A = h->rpn_obj->d.cout;
+        float* V = P(f.v);
+        float* M = P(f.m);
+        float* T = P(f.t_all);
+        for (int l = 0; l < 5; ++l) {
+          const float* xin = ext(l) ? ext(l) : P(f.in[l]);
+          if ((rc = launch_wino_input(xin, V + (size_t)f.tile_off[l] * cin, B, f.in[l].H, f.in[l].W, cin, 1, s, f.gran, L.wino_m, f.m_pad_total)))
+            return rc;
+        }
+        ConvArgs g{};
+        g.x = V; g.y = M;
+        g.B = 1; g.H = 1; g.W = (int)((long long)L.wino_np() * f.m_pad_total); g.c1 = cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;
+        g.ws = P(pl->splitk); g.ws_floats = kSplitKScratchFloats;
+        g.mt_per_group = (int)(f.m_pad_total / 128); g.w_group_stride = L.wino.rs ? L.wino_group_bytes : L.wino_group_floats;
+        if ((rc = launch_conv(L.wino, g, s))) return rc;
+        for (int l = 0; l < 5; ++l)
+          if ((rc = launch_wino_output(M + (size_t)f.tile_off[l] * cout, L.d.scale, L.d.shift, nullptr, T + (size_t)f.row_off[l] * cout, B,
+                                       f.in[l].H, f.in[l].W, cout, 1, L.d.relu, s, f.gran, L.wino_m, f.m_pad_total)))
+            return rc;
+        ConvArgs a{};
+        a.x = T; a.B = 1; a.H = 1; a.W = (int)f.rows; a.c1 = cout; a.c2 = 0; a.Ho = 1; a.Wo = a.W;
+        a.ws = P(pl->splitk); a.ws_floats = kSplitKScratchFloats;
+        a.y = (objectness && objectness[0]) ? objectness[0] : P(f.obj_all);
+        if ((rc = launch_conv(h->rpn_obj->d, a, s))) return rc;
+        a.y = (deltas && deltas[0]) ? deltas[0] : P(f.dl_all);
+        if ((rc = launch_conv(h->rpn_delta->d, a, s))) return rc;
+        (void)A;
+        break;
+      }
       case R_PREPROCESS: {
         Norm3 nm;
         for (int k = 0; k < 3; ++k) { nm.mean[k] = h->cfg.pixel_mean[k]; nm.inv_std[k] = 1.0f / h->cfg.pixel_std[k]; }
@@ -606,7 +704,7 @@ static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
       }
     }
     if (families) {
-      static const char* const kind_names[] = {"rcnn_preprocess", "conv", "maxpool", "fpn_add_upsampled", "subsample2"};
+      static const char* const kind_names[] = {"rcnn_preprocess", "conv", "maxpool", "fpn_add_upsampled", "subsample2", "wino+rpn_fused"};
       families[op_index] = op.kind == R_CONV ? std::string(op.has_wino ? "wino+" : "") + noted_kernel() : kind_names[op.kind];
     }
     ++op_index;

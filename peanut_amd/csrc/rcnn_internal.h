@@ -5,7 +5,7 @@
 
 namespace peanut {
 
-enum ROpKind { R_PREPROCESS, R_CONV, R_MAXPOOL, R_ADD_UP, R_SUBSAMPLE };
+enum ROpKind { R_PREPROCESS, R_CONV, R_MAXPOOL, R_ADD_UP, R_SUBSAMPLE, R_RPN_FUSED };
 
 struct ROp {
   ROpKind kind;
@@ -18,6 +18,18 @@ struct ROp {
   float* ext_out = nullptr;   // filled at run time for ops that write a caller-owned output
   int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
   int in_ext_slot = -1;       // the input is the caller-owned output of that slot (read there when the caller gave a buffer)
+  bool rpn_level = false;     // one of the fifteen per-level RPN-head launches: skipped when the fused form (R_RPN_FUSED) runs
+};
+
+// The RPN head on all five pyramid levels as ONE chain (round 5): the shared 3x3 conv as Winograd with the levels' tiles side by
+// side in every position's rows -- five input transforms, ONE grouped GEMM, five output transforms into one [rows, C] buffer -- then
+// the objectness and the anchor-delta layer as one pointwise GEMM each over all levels' rows: 12 launches instead of 25.
+struct RpnFused {
+  bool on = false;
+  const ConvLayer* form = nullptr;            // the Winograd form all levels share (the one level p2's shape picks)
+  Act in[5], t_all, obj_all, dl_all, v, m;    // level inputs (p2..p6), conv output of all levels, head outputs, Winograd scratch
+  long long tile_off[5] = {0}, row_off[5] = {0}, rows = 0, m_pad_total = 0;
+  int gran = 128;
 };
 
 struct RPlan {
@@ -26,6 +38,7 @@ struct RPlan {
   size_t bytes = 0;
   std::vector<ROp> ops;
   int lvl_h[5] = {0}, lvl_w[5] = {0};
+  RpnFused rpn;
   // fixed-point coefficients of the resize (rcnn_api.hip: resize_tables): per output column / row the first source
   // index, the tap count and `ks` int32 weights
   DevBuf rz_x, rz_y;

@@ -692,7 +692,7 @@ inline int pow2_at_least(int n) { int p = 2048; while (p < n) p <<= 1; return p;
 using namespace peanut;
 
 struct peanut_rcnn::PostBufs {
-  DevBuf pyr[5], obj[5], dl[5];
+  DevBuf pyr[5], obj_all, dl_all;   // objectness / deltas of the five levels in ONE buffer each, level after level (the fused RPN chain needs that)
   DevBuf sel_idx, sel_score, cbox, ckey, ccat, sbox, scat, sscore, keep, nms_ws, nvalid;
   DevBuf rois, roi_level, roi_logit, prop_count;
   DevBuf x7, f1, f2, cls, bbox;
@@ -877,8 +877,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
 
   // ---- buffers ----
   for (int l = 0; l < kLevels; ++l) {
-    if ((rc = pb.pyr[l].ensure((size_t)B * lv.h[l] * lv.w[l] * F * 4)) || (rc = pb.obj[l].ensure((size_t)B * lv.n[l] * 4)) ||
-        (rc = pb.dl[l].ensure((size_t)B * lv.n[l] * 16)))
+    if ((rc = pb.pyr[l].ensure((size_t)B * lv.h[l] * lv.w[l] * F * 4)))
       return rc;
   }
   const int words = (Ktot + 63) / 64, dwords = (Kc + 63) / 64;
@@ -912,7 +911,18 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   mark();
   // ---- front end: pyramid p2..p6, objectness, anchor deltas ----
   float *pyr[5], *obj[5], *dl[5];
-  for (int l = 0; l < kLevels; ++l) { pyr[l] = (float*)pb.pyr[l].p; obj[l] = (float*)pb.obj[l].p; dl[l] = (float*)pb.dl[l].p; }
+  {
+    size_t anchors = 0;
+    for (int l = 0; l < kLevels; ++l) anchors += (size_t)B * lv.n[l];
+    if ((rc = pb.obj_all.ensure(anchors * 4)) || (rc = pb.dl_all.ensure(anchors * 16))) return rc;
+    size_t off = 0;
+    for (int l = 0; l < kLevels; ++l) {
+      pyr[l] = (float*)pb.pyr[l].p;
+      obj[l] = (float*)pb.obj_all.p + off;
+      dl[l] = (float*)pb.dl_all.p + off * 4;
+      off += (size_t)B * lv.n[l];
+    }
+  }
   if ((rc = peanut_rcnn_forward_front(h, img_bgr, B, H, W, pyr, obj, dl, stream))) return rc;
   for (int l = 0; l < kLevels; ++l) { lv.obj[l] = obj[l]; lv.delta[l] = dl[l]; }
   const bool range_check = c.precision == PEANUT_PREC_FP16X3;

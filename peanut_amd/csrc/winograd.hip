@@ -535,10 +535,11 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, 
     }
 }
 
-int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran, int m) {
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran, int m, long long m_pad_total) {
   if (C % 4 || m < 4 || m > 6) return fail(-2, "wino_input: channels must be a multiple of 4, tiles 4x4, 5x5 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
+  if (m_pad_total > 0) g.m_pad = m_pad_total;     // this tensor's tiles are a sub-range of a position's rows (V already points at its first tile)
   const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
   if (m == 6) hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   else if (m == 5) hipLaunchKernelGGL(wino5_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
@@ -549,10 +550,11 @@ int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int 
 }
 
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
-                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran, int m) {
+                       int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran, int m, long long m_pad_total) {
   if (C % 4 || m < 4 || m > 6) return fail(-2, "wino_output: channels must be a multiple of 4, tiles 4x4, 5x5 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
+  if (m_pad_total > 0) g.m_pad = m_pad_total;
   const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
   if (m == 6 && res) hipLaunchKernelGGL(wino6_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   else if (m == 6) hipLaunchKernelGGL(wino6_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);

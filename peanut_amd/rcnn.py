@@ -90,7 +90,16 @@ class MaskRCNNFront:
         A, F = self.cfg.num_anchors, self.cfg.fpn_out
         mk = lambda ch: [torch.empty((b, hh, ww, ch), dtype=torch.float32, device=img_bgr.device) for hh, ww in lv]  # noqa: E731
         pyr = mk(F) if want_pyramid else None
-        obj, dl = mk(A), mk(4 * A)
+
+        def mk_joined(ch):      # the five levels as views of ONE buffer, level after level: what lets the library run the RPN head
+            flat = torch.empty((sum(b * hh * ww for hh, ww in lv) * ch,), dtype=torch.float32, device=img_bgr.device)   # as one chain
+            out, off = [], 0
+            for hh, ww in lv:
+                n = b * hh * ww * ch
+                out.append(flat[off:off + n].view(b, hh, ww, ch))
+                off += n
+            return out
+        obj, dl = mk_joined(A), mk_joined(4 * A)
         ptrs = lambda ts: (C.c_void_p * 5)(*[t.data_ptr() for t in ts]) if ts is not None else None  # noqa: E731
         with torch.cuda.device(img_bgr.device):
             rc = self._lib.peanut_rcnn_forward_front(self._h, img_bgr.data_ptr(), b, h, w, ptrs(pyr), ptrs(obj), ptrs(dl),

@@ -232,6 +232,39 @@ def test_inference_end_to_end(small_net):
         assert union == 0 or inter / union >= 0.98
 
 
+def test_rpn_head_fused_over_the_levels_equals_the_level_by_level_form(small_net):
+    """Round 5: inside peanut_rcnn_inference the RPN head runs on all five pyramid levels as ONE chain -- five Winograd input
+    transforms into one tensor, ONE grouped position GEMM, five output transforms, one objectness and one anchor-delta GEMM over
+    all levels' rows (option rcnn_rpn_fused, 12 launches instead of 25).  Against the level-by-level form (a handle created with
+    the option off) on the same frames: the same detections, scores / boxes to rounding (the small levels may take another
+    Winograd tile size in the fused chain), the same masks; and the stage outputs the selection reads -- the objectness of all
+    levels -- to 1e-4."""
+    from peanut_amd import _lib
+    from peanut_amd.rcnn import MaskRCNN
+    s = small_net
+    img = s["img"].cuda()
+    with _lib.default_options(rcnn_rpn_fused=1):
+        fused = MaskRCNN(s["cfg"], s["sd"])
+    with _lib.default_options(rcnn_rpn_fused=0):
+        plain = MaskRCNN(s["cfg"], s["sd"])
+    a, b = fused.inference(img), plain.inference(img)
+    fam_f = [k for _, k, _, _ in fused.probe_front(img, reps=1)]
+    fam_p = [k for _, k, _, _ in plain.probe_front(img, reps=1)]
+    assert "wino+rpn_fused" in fam_f and fam_f.count("skipped") == 15     # the fused chain ran, the fifteen level launches did not
+    assert "wino+rpn_fused" not in fam_p and "skipped" not in fam_p
+    assert len(a) == len(b) == 2
+    for x, y in zip(a, b):
+        assert len(x["scores"]) > 0 and x["pred_classes"].cpu().tolist() == y["pred_classes"].cpu().tolist()
+        assert (x["scores"] - y["scores"]).abs().max().item() <= 1e-4
+        assert (x["pred_boxes"] - y["pred_boxes"]).abs().max().item() <= 5e-2
+        inter, union = (x["pred_masks"] & y["pred_masks"]).sum().item(), (x["pred_masks"] | y["pred_masks"]).sum().item()
+        assert union == 0 or inter / union >= 0.98
+    sa = fused.semantic(img, s["cfg"].num_classes, 0.5, 0.5, None)
+    sb = plain.semantic(img, s["cfg"].num_classes, 0.5, 0.5, None)
+    assert (sa - sb).abs().mean().item() <= 1e-3
+    del fused, plain
+
+
 def test_semantic_pred_maskrcnn_args_constructor(small_net, tmp_path):
     """segmentation.py:28-62 call surface: SemanticPredMaskRCNN(args).get_prediction(rgb) with a detectron2-format
     checkpoint on disk; the result equals the oracle detector + the reference's accumulation loop."""
