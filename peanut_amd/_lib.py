@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 12    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 13    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -124,6 +124,7 @@ SIGNATURES = {
     "peanut_goal_reset": (C.c_int, [_P]),
     "peanut_goal_rounds": (C.c_int, [_P]),
     "peanut_goal_passes": (C.c_int, [_P]),
+    "peanut_goal_mark_inputs": (C.c_int, [_P, _P]),
     "peanut_goal_converged": (C.c_int, [_P]),
     "peanut_goal_traversible": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "peanut_fmm_distance": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -210,9 +210,13 @@ class Agent_State:
         self.loc_c = int(c * 100.0 / args.map_resolution)
 
     # ---- agent_state.py:345-373, on the device ----
-    def update_prediction(self):
+    def update_prediction(self, goal_follows=False):
         args = self.args
         self.full_map[:, self.lmb[0]:self.lmb[1], self.lmb[2]:self.lmb[3]] = self.local_map
+        if goal_follows and getattr(args, "goal_overlap", True):
+            # update_global_goal follows at once (update_state, :240-245): its geodesic field needs the map as it is NOW, not
+            # the prediction -- marked here, the solver runs it on its own stream next to the forward below (include/peanut_hip.h)
+            self._goal_solver().mark_inputs()
         if self.full_w == args.prediction_window and self.full_h == args.prediction_window:
             object_preds = self.prediction_model.get_prediction_batch(self.full_map[None].contiguous())[0]
         else:
@@ -230,15 +234,18 @@ class Agent_State:
         target_pred = target_pred * (self.local_map[1] < 0.5)        # unexplored regions only
         self.target_pred = target_pred
 
+    def _goal_solver(self):
+        if self._goal is None:
+            from .goal import GeodesicSolver
+            self._goal = GeodesicSolver(self.full_w, self.full_h, int(self.args.col_rad), device=self.device)
+        return self._goal
+
     # ---- agent_state.py:376-415, on the device ----
     def update_global_goal(self):
         """Geodesic-distance-weighted argmax of the target prediction (csrc/goal.hip).  Needs ``target_pred`` (from
         ``update_prediction``) unless ``dist_weight_temperature == 0``."""
-        from .goal import GeodesicSolver
         args = self.args
-        if self._goal is None:
-            self._goal = GeodesicSolver(self.full_w, self.full_h, int(args.col_rad), device=self.device)
-        res = self._goal.select(self.full_map[0], self.collision_map, self.visited_vis, self.lmb, (self.loc_r, self.loc_c),
+        res = self._goal_solver().select(self.full_map[0], self.collision_map, self.visited_vis, self.lmb, (self.loc_r, self.loc_c),
                                 self.target_pred, float(getattr(args, "dist_weight_temperature", 500)), int(args.map_resolution))
         self.value_max = res["value_max"]
         self.goal_rounds = res["rounds"]
@@ -272,8 +279,9 @@ class Agent_State:
         if (self.step % args.update_goal_freq == args.update_goal_freq - 1 or self.step == 0 or
                 self.dist_to_goal < args.goal_reached_dist) and self.step >= args.switch_step \
                 and self.prediction_model is not None:
-            self.update_prediction()
-            if getattr(args, "select_goal", True):
+            select = getattr(args, "select_goal", True)
+            self.update_prediction(goal_follows=select)
+            if select:
                 self.update_global_goal()
             predicted = True
         self.inc_step()

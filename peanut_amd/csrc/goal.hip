@@ -175,6 +175,36 @@ __device__ __forceinline__ double update_cell_local(const AxisPick& y, const Axi
   return base + (double)r;
 }
 
+// update_cell_local(axis_pick(ym1, ym2, yp1, yp2), axis_pick(xm1, xm2, xp1, xp2)) with the SAME arithmetic, written for a short
+// dependent instruction chain (the blocked round kernel below is bound by the latency of one evaluation: one wave, one
+// front cell per iteration): the picks through min / compare-select instead of nested updates, the two axes ordered by
+// min / max, no structures passed by reference (the form above compiles to ~245 instructions per evaluation).  Values that must
+// not feed the cell arrive as INFINITY (the caller reads them from a slot that holds it).
+__device__ __forceinline__ double update_cell_local_fast(double ym1, double ym2, double yp1, double yp2, double xm1, double xm2,
+                                                          double xp1, double xp2) {
+  // axis_pick: the j = -1 side unless the j = +1 side is strictly closer; the second neighbour of that side when it is not farther
+  const bool ty = yp1 < ym1, tx = xp1 < xm1;
+  const double v1y = ty ? yp1 : ym1, c2y = ty ? yp2 : ym2;
+  const double v1x = tx ? xp1 : xm1, c2x = tx ? xp2 : xm2;
+  const double v2y = (c2y <= v1y) ? c2y : INFINITY, v2x = (c2x <= v1x) ? c2x : INFINITY;
+  // the axis with the smaller neighbour first (y on a tie)
+  const bool y_first = v1y <= v1x;
+  const double s1 = y_first ? v1y : v1x, o1 = y_first ? v1x : v1y;
+  const double s2v = y_first ? v2y : v2x, o2v = y_first ? v2x : v2y;
+  const bool s2 = s2v < INFINITY, o2 = o2v < INFINITY;
+  const float as = s2 ? 2.25f : 1.0f;
+  const float ts = s2 ? (float)(s1 - s2v) * (1.0f / 3.0f) : 0.0f;
+  float r = ts + (s2 ? (2.0f / 3.0f) : 1.0f);
+  const float ov = (float)(o1 - s1);                                       // +inf when the other axis has no upwind neighbour
+  const float ao = o2 ? 2.25f : 1.0f;
+  const float to = o2 ? ov + (float)(o1 - o2v) * (1.0f / 3.0f) : ov;
+  const float A = as + ao, B = as * ts + ao * to, C = as * ts * ts + ao * to * to - 1.0f;
+  const float det = B * B - A * C;
+  const float u2 = (B + sqrtf(det)) / A;
+  if (o1 < INFINITY && ov < r && det >= 0.0f && u2 > ov) r = u2;
+  return s1 < INFINITY ? s1 + (double)r : INFINITY;
+}
+
 // SECOND = false: stage A (first order, monotone).  SECOND = true: stage B (second order on the graph given by ord).
 // Jacobi sweeps of the tile in LDS, one cell per lane.  A cell is only re-evaluated when one of the cells its stencil
 // reads changed in the previous sweep (the update is a pure function of those and of its own value, so skipping it
@@ -275,6 +305,136 @@ __global__ __launch_bounds__(1024) void fmm_round_kernel(double* __restrict__ di
   if (threadIdx.x == 0) {
     atomicAdd(changed_tiles, 1u);
     if (sweeps == MAX_SWEEPS) active_out[tile] = 1;       // not settled inside the budget: go on next round
+    if (ty > 0) active_out[tile - tiles_x] = 1;
+    if (ty + 1 < tiles_y) active_out[tile + tiles_x] = 1;
+    if (tx > 0) active_out[tile - 1] = 1;
+    if (tx + 1 < tiles_x) active_out[tile + 1] = 1;
+  }
+}
+
+// The same round, blocked (round 5).  In the kernel above the front moves one cell per sweep and every sweep costs two
+// workgroup barriers over 16 waves plus the change-tracking reads: ~1.1 us per sweep, 70-90 us for a front to cross a tile,
+// and a round costs exactly that (only a ring of tiles is awake, so rounds are latency, not throughput).  Here a wave owns
+// one 8 x 8 block of the tile and keeps a PRIVATE copy of it with its two-cell ring (12 x 12) in LDS: between two workgroup
+// barriers it relaxes the block to convergence against the frozen ring -- Jacobi iterations inside the wave, which runs in
+// lockstep, so they need no barrier at all (LDS operations of one wave execute in order) -- and then publishes the block.
+// A front crosses a tile in 4-8 barrier pairs instead of 32-64, and an iteration costs the update alone.  A block is
+// relaxed again only when one of its four neighbour blocks (the stencil is axis-aligned) published a change.  The
+// schedule is deterministic (every block reads the tile as of the last barrier); stage A's monotone field and stage B's
+// fixed dependency graph make the result independent of the schedule up to the update's own noise floor.
+constexpr int BLK = 8, PT = BLK + 2 * HALO, MAX_OUTER = 32, MAX_INNER = 48;      // private tile 12 x 12
+template <bool SECOND, bool LOCAL32>
+__global__ __launch_bounds__(1024) void fmm_round_blocked_kernel(double* __restrict__ dist, const double* __restrict__ ord,
+                                                                 const unsigned char* __restrict__ state, int H, int W, int tiles_x, int tiles_y,
+                                                                 const unsigned char* __restrict__ active_in, unsigned char* __restrict__ active_out,
+                                                                 unsigned char* __restrict__ active_clear, unsigned int* __restrict__ changed_tiles) {
+  const int tile = blockIdx.x;
+  if (threadIdx.x == 0) active_clear[tile] = 0;
+  if (!active_in[tile]) return;
+  __shared__ double d[LT][LT + 1];
+  __shared__ double o[SECOND ? LT : 1][LT + 1];
+  __shared__ unsigned char st[LT][LT + 4];
+  __shared__ double priv[16][PT * (PT + 1) + 2];      // per wave: 12 rows of 13 (one of padding) + a slot that holds +inf
+  __shared__ unsigned char blk[2][6][8];      // block (by, bx) at [by + 1][bx + 1]; the ring around the 4 x 4 blocks stays 0
+  __shared__ int anyflag[2];
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int r0 = ty * TILE - HALO, c0 = tx * TILE - HALO;
+  for (int i = threadIdx.x; i < LT * LT; i += 1024) {
+    const int ly = i / LT, lx = i - ly * LT;
+    const int r = r0 + ly, c = c0 + lx;
+    const bool in = r >= 0 && r < H && c >= 0 && c < W;
+    d[ly][lx] = in ? dist[(size_t)r * W + c] : INFINITY;
+    if (SECOND) o[ly][lx] = in ? ord[(size_t)r * W + c] : INFINITY;
+    st[ly][lx] = in ? state[(size_t)r * W + c] : ST_MASKED;
+  }
+  if (threadIdx.x < 2 * 6 * 8) (&blk[0][0][0])[threadIdx.x] = 0;
+  if (threadIdx.x < 2) anyflag[threadIdx.x] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int by = wave >> 2, bx = wave & 3;
+  const int ly = HALO + BLK * by + (lane >> 3), lx = HALO + BLK * bx + (lane & 7);
+  const int py = HALO + (lane >> 3), px = HALO + (lane & 7);
+  unsigned feed = st[ly][lx] == ST_FREE ? 0x100u : 0u;       // as in fmm_round_kernel
+  if (SECOND) {
+    const double oi = o[ly][lx];
+    const double oym = o[ly - 1][lx], oyp = o[ly + 1][lx], oxm = o[ly][lx - 1], oxp = o[ly][lx + 1];
+    feed |= (oym < oi ? 1u : 0u) | (oyp < oi ? 2u : 0u) | (oxm < oi ? 4u : 0u) | (oxp < oi ? 8u : 0u);
+    feed |= (o[ly - 2][lx] <= oym ? 16u : 0u) | (o[ly + 2][lx] <= oyp ? 32u : 0u) | (o[ly][lx - 2] <= oxm ? 64u : 0u) |
+            (o[ly][lx + 2] <= oxp ? 128u : 0u);
+  } else {
+    feed |= 0xfu;
+  }
+  double* pv = priv[wave];
+  constexpr int PS = PT + 1, INF_SLOT = PT * PS;
+  if (lane == 0) pv[INF_SLOT] = INFINITY;
+  // where the eight stencil values are read: the neighbour's cell of the private tile if it may feed this cell, the +inf slot if not
+  const int pc = py * PS + px;
+  const int a_ym1 = (feed & 1u) ? pc - PS : INF_SLOT, a_yp1 = (feed & 2u) ? pc + PS : INF_SLOT;
+  const int a_xm1 = (feed & 4u) ? pc - 1 : INF_SLOT, a_xp1 = (feed & 8u) ? pc + 1 : INF_SLOT;
+  const int a_ym2 = (feed & 16u) ? pc - 2 * PS : INF_SLOT, a_yp2 = (feed & 32u) ? pc + 2 * PS : INF_SLOT;
+  const int a_xm2 = (feed & 64u) ? pc - 2 : INF_SLOT, a_xp2 = (feed & 128u) ? pc + 2 : INF_SLOT;
+  const bool is_free = (feed & 0x100u) != 0;
+  bool ever = false, again = false;      // again: the block's own iterations hit their cap
+  int outer = 0;
+  for (; outer < MAX_OUTER; ++outer) {
+    const int cur = outer & 1, nxt = cur ^ 1;
+    // the tile wakes because a neighbour changed its halo: every block once; afterwards only next to a published change
+    const bool need = outer == 0 || again || blk[cur][by][bx + 1] || blk[cur][by + 2][bx + 1] || blk[cur][by + 1][bx] || blk[cur][by + 1][bx + 2];
+    if (need) {      // (wave-uniform) private copy of the block and its ring, as of the last barrier
+      for (int i = lane; i < PT * PT; i += 64) {
+        const int qy = i / PT, qx = i - qy * PT;
+        pv[qy * PS + qx] = d[BLK * by + qy][BLK * bx + qx];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) anyflag[cur] = 0;
+    if (lane == 0) blk[cur][by + 1][bx + 1] = 0;      // (read before the barrier above; written again in the next outer step)
+    if (need) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const double own0 = pv[pc];
+      double val = own0;
+      again = true;
+      for (int inner = 0; inner < MAX_INNER; ++inner) {
+        const double ym1 = pv[a_ym1], yp1 = pv[a_yp1], xm1 = pv[a_xm1], xp1 = pv[a_xp1];
+        double ym2 = INFINITY, yp2 = INFINITY, xm2 = INFINITY, xp2 = INFINITY;
+        if (SECOND) { ym2 = pv[a_ym2]; yp2 = pv[a_yp2]; xm2 = pv[a_xm2]; xp2 = pv[a_xp2]; }
+        double u;
+        if (LOCAL32) u = update_cell_local_fast(ym1, ym2, yp1, yp2, xm1, xm2, xp1, xp2);
+        else u = update_cell(axis_term(ym1, ym2, yp1, yp2), axis_term(xm1, xm2, xp1, xp2));
+        if (SECOND) {
+          if (val < INFINITY && fabs(u - val) <= (LOCAL32 ? 1e-6 : 1e-12 * fmax(1.0, val))) u = val;
+        } else {
+          u = fmin(u, val);
+        }
+        const double nv = is_free ? u : val;
+        const bool chd = nv != val;
+        if (!__any(chd)) { again = false; break; }
+        // every lane has read before any lane writes (one instruction stream, LDS operations of a wave execute in order);
+        // the next iteration reads after the write
+        val = nv;
+        asm volatile("" ::: "memory");
+        pv[pc] = nv;
+        asm volatile("" ::: "memory");
+      }
+      if (__any(val != own0)) {
+        d[ly][lx] = val;
+        if (lane == 0) { blk[nxt][by + 1][bx + 1] = 1; anyflag[nxt] = 1; }
+      } else if (again && lane == 0) {
+        anyflag[nxt] = 1;      // (cannot happen without a change; kept so that a capped block is never dropped)
+      }
+    }
+    __syncthreads();
+    if (!anyflag[nxt]) break;
+    ever = true;
+  }
+  if (!ever) return;
+  {
+    const int r = r0 + ly, c = c0 + lx;
+    if (r < H && c < W) dist[(size_t)r * W + c] = d[ly][lx];
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(changed_tiles, 1u);
+    if (outer == MAX_OUTER) active_out[tile] = 1;
     if (ty > 0) active_out[tile - tiles_x] = 1;
     if (ty + 1 < tiles_y) active_out[tile + tiles_x] = 1;
     if (tx > 0) active_out[tile - 1] = 1;
@@ -386,6 +546,16 @@ struct peanut_goal {
   int last_rounds = 0, last_passes = 0;
   bool last_converged = true;      // false: the ordering passes hit MAX_ORDER_PASSES with the last one still changing tiles
   int round_hint[1 + 64] = {0};    // rounds each stage needed in the previous solve (run_stage); stage 0 + up to 64 ordering passes (fmm_max_passes is clamped to 64)
+  // peanut_goal_mark_inputs: the field of the next select is solved on `side`, behind `ev_inputs` only, so that it runs next to
+  // whatever the caller enqueued on its stream after the mark (the map-prediction forward that produces target_pred)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_inputs = nullptr, ev_field = nullptr;
+  bool marked = false;
+  ~peanut_goal() {
+    if (ev_inputs) (void)hipEventDestroy(ev_inputs);
+    if (ev_field) (void)hipEventDestroy(ev_field);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 namespace {
@@ -412,13 +582,18 @@ int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned lo
       unsigned char* in = act + (size_t)(*cur) * nt;
       unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
       unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
-      const bool local32 = opt(OPT_FMM_LOCAL32) != 0;
-      if (local32)
-        hipLaunchKernelGGL((fmm_round_kernel<SECOND, true>), dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p,
-                           (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
-      else
-        hipLaunchKernelGGL((fmm_round_kernel<SECOND, false>), dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p,
-                           (const unsigned char*)g->state.p, H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k);
+      const bool local32 = opt(OPT_FMM_LOCAL32) != 0, blocked = opt(OPT_FMM_BLOCKED) != 0;
+#define PEANUT_FMM_LAUNCH(KERNEL)                                                                                                      \
+  hipLaunchKernelGGL(KERNEL, dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p, (const unsigned char*)g->state.p, \
+                     H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k)
+      if (blocked) {
+        if (local32) PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, true>));
+        else PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, false>));
+      } else {
+        if (local32) PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, true>));
+        else PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, false>));
+      }
+#undef PEANUT_FMM_LAUNCH
       *cur = (*cur + 1) % 3;
     }
     PEANUT_HIP_CHECK(hipMemcpyAsync(host, counters, batch * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
@@ -502,6 +677,22 @@ int peanut_goal_reset(peanut_goal_t* g) {
   return 0;
 }
 
+int peanut_goal_mark_inputs(peanut_goal_t* g, void* stream) {
+  if (!g) return fail(PEANUT_EINVAL, "peanut_goal_mark_inputs: null handle");
+  if (!g->side) {
+    // highest priority: the field is a chain of short launches (a ring of tiles per round) whose latency is the cost; its
+    // workgroups should take the next free CU slots ahead of the forward's large grids
+    int prio_least = 0, prio_greatest = 0;
+    PEANUT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    PEANUT_HIP_CHECK(hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, prio_greatest));
+    PEANUT_HIP_CHECK(hipEventCreateWithFlags(&g->ev_inputs, hipEventDisableTiming));
+    PEANUT_HIP_CHECK(hipEventCreateWithFlags(&g->ev_field, hipEventDisableTiming));
+  }
+  PEANUT_HIP_CHECK(hipEventRecord(g->ev_inputs, (hipStream_t)stream));
+  g->marked = true;
+  return 0;
+}
+
 int peanut_goal_rounds(peanut_goal_t* g) { return g ? g->last_rounds : PEANUT_EINVAL; }
 int peanut_goal_passes(peanut_goal_t* g) { return g ? g->last_passes : PEANUT_EINVAL; }
 int peanut_goal_converged(peanut_goal_t* g) { return g ? (g->last_converged ? 1 : 0) : PEANUT_EINVAL; }
@@ -547,12 +738,22 @@ int peanut_goal_select(peanut_goal_t* g, const float* full_obstacle, const uint8
   const int mode = dist_weight_temperature == -1 ? 1 : (dist_weight_temperature == 0 ? 2 : 0);
   if (mode != 2 && !target_pred) return fail(PEANUT_EINVAL, "peanut_goal_select: target_pred is needed unless dist_weight_temperature == 0");
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, stream)) return rc;
+  // the field needs the map inputs only: after peanut_goal_mark_inputs it is solved on the handle's own stream, behind the mark,
+  // next to what the caller enqueued on `s` since (the forward that produces target_pred); `s` joins before the weights
+  const bool aside = g->marked;
+  g->marked = false;
+  hipStream_t fs = aside ? g->side : s;
+  if (aside) PEANUT_HIP_CHECK(hipStreamWaitEvent(fs, g->ev_inputs, 0));
+  if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, fs)) return rc;
   // np.clip(loc + lmb, 0, full - 1)  (:389-390)
   int sr = loc_r + gx1, sc = loc_c + gy1;
   sr = sr < 0 ? 0 : (sr > g->H - 1 ? g->H - 1 : sr);
   sc = sc < 0 ? 0 : (sc > g->W - 1 ? g->W - 1 : sc);
-  if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, s)) return rc;
+  if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, fs)) return rc;
+  if (aside) {
+    PEANUT_HIP_CHECK(hipEventRecord(g->ev_field, fs));
+    PEANUT_HIP_CHECK(hipStreamWaitEvent(s, g->ev_field, 0));
+  }
   if (g->have_last && (g->last_lw != lw || g->last_lh != lh)) g->have_last = false;
   const int n = lw * lh;
   const double temperature = dist_weight_temperature / (double)map_resolution;      // (:395)

@@ -281,3 +281,69 @@ def test_ordering_pass_cap_is_reported_and_its_effect_is_bounded(shape, seed):
     print(f"{h}x{w}: cap of six {'hit' if hit_cap else 'not hit'} ({sol.passes} passes), default: fixed point after {free.passes} passes; "
           f"capped vs fixed point max {diff:.3e} cells")
     assert diff <= 0.1
+
+
+def test_field_solved_next_to_the_prediction_forward_is_the_same_field():
+    """peanut_goal_mark_inputs (round 5): the field of a marked select runs on the handle's own stream, next to the work the
+    caller enqueued after the mark (here a chain of large matrix products that ends in target_pred).  Same field, bit for bit, same
+    goal, as the unmarked call; an input converted after the mark falls back to the in-stream solve."""
+    from peanut_amd.goal import GeodesicSolver
+    H = W = 480
+    trav = _maze(H, W, 7)
+    obst = torch.from_numpy((~trav.astype(bool)).astype(np.float32)).cuda()
+    col = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    vis = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    lmb = (120, 360, 120, 360)
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand((240, 240), generator=g).cuda()
+    a = torch.rand((2048, 2048), generator=g).cuda()
+
+    def produce_target():            # a few milliseconds of device work on the caller's stream
+        x = a
+        for _ in range(6):
+            x = (x @ a) * (1.0 / 1024.0)
+        return base + x[:240, :240] * 1e-9
+
+    free = np.argwhere(trav[130:350, 130:350])[0] + 10
+    loc = (int(free[0]), int(free[1]))
+    sol = GeodesicSolver(H, W, 1)
+    ref = sol.select(obst, col, vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True, want_value=True)
+    sol2 = GeodesicSolver(H, W, 1)
+    for rep in range(3):             # (also with the round hints of a previous solve in place)
+        sol2.reset()
+        sol2.mark_inputs()
+        got = sol2.select(obst, col, vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True, want_value=True)
+        assert got["goal"] == ref["goal"] and abs(got["wt_sum"] - ref["wt_sum"]) <= 1e-9 * ref["wt_sum"] and got["rounds"] >= 1      # (the sum is an atomic accumulation: last digits vary)
+        assert torch.equal(got["dist"], ref["dist"]) and torch.equal(got["value"], ref["value"])
+    # an input that select has to convert (bool -> uint8) is younger than the mark: in-stream solve, same answer
+    sol2.reset()
+    sol2.mark_inputs()
+    got = sol2.select(obst, col.bool(), vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True)
+    assert got["goal"] == ref["goal"] and torch.equal(got["dist"], ref["dist"])
+
+
+def test_update_state_with_and_without_the_overlapped_field_agree():
+    """Agent_State.update_state marks the goal solver's inputs before the prediction forward (goal_overlap, default on): the
+    episode's goals, prediction schedule and final map equal those of the serial order."""
+    from oracle import mapping_scenes
+    from oracle.agent_ref import agent_args, fake_pattern
+    from peanut_amd.agent_state import Agent_State
+    runs = []
+    for overlap in (True, False):
+        args = agent_args(dist_weight_temperature=500, select_goal=True, goal_overlap=overlap)
+        st = Agent_State(args, prediction_model=FakePredictionGPU(fake_pattern(size=args.prediction_window)))
+        frames = mapping_scenes.make_sequence(seed=11, n_frames=24)
+        st.reset()
+        goals, steps = [], []
+        for i, fr in enumerate(frames):
+            obs = torch.from_numpy(mapping_scenes.frame_to_obs(fr))[None].cuda()
+            infos = {"sensor_pose": [float(v) for v in fr["pose"]], "goal_cat_id": 2}
+            if i == 0:
+                st.init_with_obs(obs, infos)
+            if st.update_state(obs, infos):
+                steps.append(i)
+                goals.append(tuple(st.global_goals[0]))
+        runs.append((steps, goals, st.full_map.clone(), st.value_max))
+    assert len(runs[0][0]) >= 2
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][3] == runs[1][3]
+    assert torch.equal(runs[0][2], runs[1][2])
