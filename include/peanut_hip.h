@@ -229,6 +229,16 @@ int peanut_map_dims(peanut_map_t* h, int dims[4]);
  * count, claim a segment, fill, rank inside the segment), no host sync. */
 int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs, const float* maps_last,
                        float* poses_inout, float* fp_map_pred, float* map_pred, void* stream);
+/* The bookkeeping Agent_State.update_local_map does on the local map after the projection
+ * (nav/agent/agent_state.py:281-296), in one launch instead of eight small tensor operations:
+ *   local_map[2, :, :] = 0;  local_map[2:4, r0:r1, c0:c1] = 1  (the trajectory square `loc - 2 : loc + 3`, passed as the
+ *   NORMALISED Python slice, 0 <= r0, r1 <= m; empty when r0 >= r1);  local_map[1][selem_rows + cr, selem_cols + cc] = 1 for
+ *   up to two centres (the agent's cell; the current goal when the agent is within goal_reached_dist of it), where the
+ *   footprint is the non-zero cells of selem (device uint8 [(2R+1), (2R+1)], `disk(col_rad + 1)`) offset by -R.  Negative
+ *   indices wrap like torch's; a footprint index outside [-m, m) is refused (PEANUT_EINVAL; torch raises IndexError).
+ * local_map: device fp32 [channels, m, m], channels >= 4.  No host sync. */
+int peanut_map_mark_agent(float* local_map, int channels, int m, int r0, int r1, int c0, int c1, const uint8_t* selem,
+                          int selem_radius, int n_centres, const int* centres_rc, void* stream);
 /* hipGraph replay of the step's launches, keyed on the seven pointer/stream arguments (an agent ping-pongs two map
  * buffers: two cached graphs). */
 int peanut_map_use_graph(peanut_map_t* h, int enable);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "peanut_pred_probe_enable": (C.c_int, [_P, C.c_int]),
     "peanut_pred_use_graph": (C.c_int, [_P, C.c_int]),
     "peanut_map_use_graph": (C.c_int, [_P, C.c_int]),
+    "peanut_map_mark_agent": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "peanut_pred_probe_collect": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_int)]),

@@ -15,12 +15,17 @@ differences, all on purpose:
 * ``update_goal_map`` (:418-446, scikit-image erosion of the goal category) is CPU planner glue and is not here.
 
 The 12-byte pose read-back per step (`local_pose.cpu()`, :276) is kept: the integer cell indices it
-yields drive Python-side slicing exactly as in the reference."""
+yields drive the host-side decisions exactly as in the reference.  The eight small tensor operations that follow it
+(:281-296: clear the location channel, trajectory square, explored-area footprints) are one launch
+(``peanut_map_mark_agent``), and the sensor pose goes up through a pinned staging buffer."""
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
 
+from . import _lib
 from .mapping import Semantic_Mapping
 from .prediction import PEANUT_Prediction_Model
 
@@ -79,6 +84,8 @@ class Agent_State:
         self.selem_idx = sel
         self._selem_r = torch.from_numpy(sel[0].astype(np.int64)).to(self.device)
         self._selem_c = torch.from_numpy(sel[1].astype(np.int64)).to(self.device)
+        self._selem_mask = torch.from_numpy(np.ascontiguousarray(disk(args.col_rad + 1))).to(self.device)     # uint8 [(2R+1)^2]
+        self._pose_host = torch.zeros(3, dtype=torch.float32).pin_memory()      # staging of the per-step sensor pose
         self.target_pred = None
         self.global_goals = [[0, 0]]
         self.dist_to_goal = float("inf")
@@ -182,21 +189,50 @@ class Agent_State:
         self._map_step(obs)
         locs = self.local_pose.cpu().numpy()
         self.planner_pose_inputs[:3] = locs + self.origins
-        self.local_map[2, :, :].fill_(0.)
         r, c = locs[1], locs[0]
         loc_r = int(r * 100.0 / args.map_resolution)
         loc_c = int(c * 100.0 / args.map_resolution)
         traj_rad = 2
-        self.local_map[2:4, loc_r - traj_rad:loc_r + traj_rad + 1, loc_c - traj_rad:loc_c + traj_rad + 1] = 1.
-        off = int(args.col_rad + 1)
-        self.local_map[1][self._selem_r - off + loc_r, self._selem_c - off + loc_c] = 1.
         self.dist_to_goal = np.sqrt((loc_r - (self.global_goals[0][0])) ** 2 +
                                     (loc_c - (self.global_goals[0][1])) ** 2) * args.map_resolution
+        centres = [(loc_r, loc_c)]
         if self.dist_to_goal < args.goal_reached_dist:
-            self.local_map[1][self._selem_r - off + self.global_goals[0][0],
-                              self._selem_c - off + self.global_goals[0][1]] = 1.
+            centres.append((self.global_goals[0][0], self.global_goals[0][1]))
+        self._mark_agent(loc_r, loc_c, traj_rad, centres)
         self.loc_r = loc_r
         self.loc_c = loc_c
+
+    def _upload_pose(self, sensor_pose):
+        """``torch.from_numpy(np.asarray(infos['sensor_pose'])).float().to(device)`` (:225) through one pinned buffer: the copy is
+        asynchronous, and the buffer is free again by the next step because update_local_map reads the pose back (a device
+        synchronisation) after the projection that consumes it."""
+        self._pose_host.copy_(torch.from_numpy(np.asarray(sensor_pose, dtype=np.float64)).float())
+        return self._pose_host.to(self.device, non_blocking=True)
+
+    def _mark_agent(self, loc_r, loc_c, traj_rad, centres):
+        """(:281-296) in one launch (``peanut_map_mark_agent``)::
+
+            self.local_map[2, :, :].fill_(0.)
+            self.local_map[2:4, loc_r - traj_rad:loc_r + traj_rad + 1, loc_c - traj_rad:loc_c + traj_rad + 1] = 1.
+            self.local_map[1][self.selem_idx[0] - int(args.col_rad + 1) + r, self.selem_idx[1] - int(args.col_rad + 1) + c] = 1.
+                                                                   # for (r, c) in centres: the agent, and the goal once reached
+
+        with Python's slice clamping and torch's index rules (negative wraps, out of range raises IndexError)."""
+        lm = self.local_map
+        if not lm.is_contiguous():            # (a view into full_map right after _rebind_local; _map_step replaces it)
+            raise RuntimeError("local_map must be contiguous here")
+        m = int(lm.shape[1])
+        rad = int(self.args.col_rad + 1)
+        r0, r1, _ = slice(loc_r - traj_rad, loc_r + traj_rad + 1).indices(m)
+        c0, c1, _ = slice(loc_c - traj_rad, loc_c + traj_rad + 1).indices(int(lm.shape[2]))
+        for cr, cc in centres:
+            if cr - rad < -m or cr + rad >= m or cc - rad < -m or cc + rad >= m:
+                raise IndexError(f"explored-area footprint around ({cr}, {cc}) leaves the {m} x {m} local map")
+        flat = (C.c_int * (2 * len(centres)))(*[int(v) for rc in centres for v in rc])
+        with torch.cuda.device(self.device):
+            rc = _lib.load().peanut_map_mark_agent(lm.data_ptr(), int(lm.shape[0]), m, r0, r1, c0, c1, self._selem_mask.data_ptr(), rad,
+                                                   len(centres), C.byref(flat), _lib.current_stream_ptr(self.device))
+        _lib.check(rc, "peanut_map_mark_agent")
 
     # ---- agent_state.py:303-338 ----
     def update_full_map(self):
@@ -270,7 +306,7 @@ class Agent_State:
         (:246-263) are CPU planner glue outside the hot path."""
         args = self.args
         self.goal_cat = infos['goal_cat_id']
-        self.poses = torch.from_numpy(np.asarray(infos['sensor_pose'])).float().to(self.device)
+        self.poses = self._upload_pose(infos['sensor_pose'])
         self.update_local_map(obs)
         if self.l_step == args.num_local_steps - 1:
             self.l_step = 0

@@ -460,6 +460,35 @@ __global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__
   }
 }
 
+
+// ---- Agent_State.update_local_map's bookkeeping after the projection (nav/agent/agent_state.py:281-296), one launch ----
+// channel 2 (current location) cleared, the trajectory square set in channels 2 and 3, the explored-area footprint stamped
+// into channel 1 around up to two centres.  One thread per map cell.
+struct MarkP {
+  int m, r0, r1, c0, c1, rad, n_centres, cr[2], cc[2];
+};
+__device__ __forceinline__ bool stamp_hits(int r, int c, int cr, int cc, int m, int rad, const unsigned char* __restrict__ selem) {
+  // a footprint cell (dr, dc) lands on row cr + dr, or on cr + dr + m when that is negative (torch's negative indices wrap)
+  int dr = r - cr, dc = c - cc;
+  if (dr > rad) dr -= m;
+  if (dc > rad) dc -= m;
+  if (dr < -rad || dr > rad || dc < -rad || dc > rad) return false;
+  if (cr + dr >= 0 ? (cr + dr != r) : (cr + dr + m != r)) return false;
+  if (cc + dc >= 0 ? (cc + dc != c) : (cc + dc + m != c)) return false;
+  return selem[(dr + rad) * (2 * rad + 1) + (dc + rad)] != 0;
+}
+__global__ __launch_bounds__(256) void map_mark_agent_kernel(float* __restrict__ local_map, const unsigned char* __restrict__ selem, MarkP p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.m * p.m) return;
+  const int r = i / p.m, c = i - r * p.m;
+  const size_t plane = (size_t)p.m * p.m;
+  const bool traj = r >= p.r0 && r < p.r1 && c >= p.c0 && c < p.c1;
+  local_map[2 * plane + i] = traj ? 1.0f : 0.0f;
+  if (traj) local_map[3 * plane + i] = 1.0f;
+  bool hit = false;
+  for (int k = 0; k < p.n_centres; ++k) hit = hit || stamp_hits(r, c, p.cr[k], p.cc[k], p.m, p.rad, selem);
+  if (hit) local_map[plane + i] = 1.0f;
+}
 }  // namespace
 }  // namespace peanut
 
@@ -616,6 +645,25 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
   if (!h->use_graph) return enqueue();
   return h->graphs.run({(uintptr_t)obs, (uintptr_t)pose_obs, (uintptr_t)maps_last, (uintptr_t)poses_inout,
                         (uintptr_t)fp_map_pred, (uintptr_t)map_pred, (uintptr_t)s}, s, enqueue);
+}
+
+int peanut_map_mark_agent(float* local_map, int channels, int m, int r0, int r1, int c0, int c1, const uint8_t* selem, int selem_radius,
+                          int n_centres, const int* centres_rc, void* stream) {
+  if (!local_map || !selem || (n_centres > 0 && !centres_rc)) return fail(PEANUT_EINVAL, "peanut_map_mark_agent: null argument");
+  if (channels < 4 || m < 1 || selem_radius < 0 || 2 * selem_radius + 1 > m || n_centres < 0 || n_centres > 2)
+    return fail(PEANUT_EINVAL, "peanut_map_mark_agent: bad dimensions");
+  if (r0 < 0 || c0 < 0 || r1 > m || c1 > m) return fail(PEANUT_EINVAL, "peanut_map_mark_agent: the trajectory square is not a normalised slice");
+  MarkP p{m, r0, r1, c0, c1, selem_radius, n_centres, {0, 0}, {0, 0}};
+  for (int k = 0; k < n_centres; ++k) {
+    const int cr = centres_rc[2 * k], cc = centres_rc[2 * k + 1];
+    // the footprint's index range must be one torch accepts: [-m, m)
+    if (cr - selem_radius < -m || cr + selem_radius >= m || cc - selem_radius < -m || cc + selem_radius >= m)
+      return fail(PEANUT_EINVAL, "peanut_map_mark_agent: footprint index out of range");
+    p.cr[k] = cr; p.cc[k] = cc;
+  }
+  hipLaunchKernelGGL(map_mark_agent_kernel, dim3((m * m + 255) / 256), dim3(256), 0, (hipStream_t)stream, local_map, selem, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_map_mark_agent: ") + hipGetErrorString(e));
 }
 
 int peanut_map_use_graph(peanut_map_t* h, int enable) {

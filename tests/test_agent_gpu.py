@@ -228,3 +228,37 @@ def test_recorded_episode_files_drive_the_replay(tmp_path):
     assert all(n == 2 for n in done.values())            # steps 0 and 9 of the 11 acted frames (the 12th is past the limit)
     assert agent.total_episodes == 2 and agent.timestep == 12
     assert float(agent.agent_states.local_map[4].sum()) > 0 and agent.agent_states.target_pred is not None
+
+
+def test_map_bookkeeping_in_one_launch_equals_the_tensor_operations():
+    """peanut_map_mark_agent (Agent_State._mark_agent) against the reference's statements (agent_state.py:281-296) run as
+    torch operations, bit for bit: in the middle of the map, at its borders (Python's slice clamping, torch's wrapping of
+    negative indices), with and without the second footprint (goal reached); indices torch refuses raise IndexError before anything is written."""
+    from oracle.agent_ref import agent_args
+    from peanut_amd.agent_state import Agent_State
+    args = agent_args()
+    st = Agent_State(args, prediction_model=None)
+    m, off = st.local_w, int(args.col_rad + 1)
+    g = torch.Generator().manual_seed(3)
+    base = torch.rand((st.nc, m, m), generator=g).cuda()
+
+    def reference(lm, loc_r, loc_c, centres):
+        lm[2, :, :].fill_(0.)
+        lm[2:4, loc_r - 2:loc_r + 3, loc_c - 2:loc_c + 3] = 1.
+        for r, c in centres:
+            lm[1][st._selem_r - off + r, st._selem_c - off + c] = 1.
+        return lm
+
+    cases = [((240, 240), None), ((100, 377), (300, 20)), ((off, off), None), ((m - 1 - off, m - 1 - off), (off, m - 1 - off)),
+             ((1, 2), None),            # the footprint wraps to the far rows / columns; the square's slice starts negative: empty
+             ((0, m - off - 1), None), ((3, 3), (2, 1)), ((m - 1 - off, 0), None)]
+    for (loc, goal) in cases:
+        centres = [loc] + ([goal] if goal else [])
+        want = reference(base.clone(), loc[0], loc[1], centres)
+        st.local_map = base.clone()
+        st._mark_agent(loc[0], loc[1], 2, centres)
+        assert torch.equal(st.local_map, want), (loc, goal)
+    st.local_map = base.clone()
+    with pytest.raises(IndexError):        # (a footprint row >= m: torch's device-side index check would abort the process here)
+        st._mark_agent(m - 2, 100, 2, [(m - 2, 100)])
+    assert torch.equal(st.local_map, base)
