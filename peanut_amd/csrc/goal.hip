@@ -175,33 +175,50 @@ __device__ __forceinline__ double update_cell_local(const AxisPick& y, const Axi
   return base + (double)r;
 }
 
-// update_cell_local(axis_pick(ym1, ym2, yp1, yp2), axis_pick(xm1, xm2, xp1, xp2)) with the SAME arithmetic, written for a short
-// dependent instruction chain (the blocked round kernel below is bound by the latency of one evaluation: one wave, one
-// front cell per iteration): the picks through min / compare-select instead of nested updates, the two axes ordered by
-// min / max, no structures passed by reference (the form above compiles to ~245 instructions per evaluation).  Values that must
-// not feed the cell arrive as INFINITY (the caller reads them from a slot that holds it).
+// update_cell_local(axis_pick(ym1, ym2, yp1, yp2), axis_pick(xm1, xm2, xp1, xp2)) written for a short dependent instruction
+// chain: the blocked round kernel below is bound by the latency of one evaluation (one wave advances the front one cell per
+// iteration, and the waves of a tile share four SIMDs), and the form above compiles to ~245 instructions.  Same formulas;
+// the picks through min / max / compare-select instead of nested updates, no structures passed by reference, the hardware's
+// 1-ulp square root and a reciprocal constant (a + a' is 2, 3.25 or 4.5) instead of the correctly rounded sequences: the
+// result differs from the form above by <= 2 ulp of a float around 1 (~2e-7 cell), below the 1e-6 cell at which stage B
+// already treats a change as noise.  Values that must not feed the cell arrive as INFINITY (the caller reads them from a
+// slot that holds it); SECOND = false: no second neighbours (stage A).
+template <bool SECOND>
 __device__ __forceinline__ double update_cell_local_fast(double ym1, double ym2, double yp1, double yp2, double xm1, double xm2,
                                                           double xp1, double xp2) {
-  // axis_pick: the j = -1 side unless the j = +1 side is strictly closer; the second neighbour of that side when it is not farther
-  const bool ty = yp1 < ym1, tx = xp1 < xm1;
-  const double v1y = ty ? yp1 : ym1, c2y = ty ? yp2 : ym2;
-  const double v1x = tx ? xp1 : xm1, c2x = tx ? xp2 : xm2;
-  const double v2y = (c2y <= v1y) ? c2y : INFINITY, v2x = (c2x <= v1x) ? c2x : INFINITY;
-  // the axis with the smaller neighbour first (y on a tie)
-  const bool y_first = v1y <= v1x;
-  const double s1 = y_first ? v1y : v1x, o1 = y_first ? v1x : v1y;
-  const double s2v = y_first ? v2y : v2x, o2v = y_first ? v2x : v2y;
-  const bool s2 = s2v < INFINITY, o2 = o2v < INFINITY;
-  const float as = s2 ? 2.25f : 1.0f;
-  const float ts = s2 ? (float)(s1 - s2v) * (1.0f / 3.0f) : 0.0f;
-  float r = ts + (s2 ? (2.0f / 3.0f) : 1.0f);
+  double v1y, v1x, v2y = INFINITY, v2x = INFINITY;
+  if (SECOND) {
+    // axis_pick: the j = -1 side unless the j = +1 side is strictly closer; the second neighbour of that side when it is not farther
+    const bool ty = yp1 < ym1, tx = xp1 < xm1;
+    v1y = ty ? yp1 : ym1;
+    v1x = tx ? xp1 : xm1;
+    const double c2y = ty ? yp2 : ym2, c2x = tx ? xp2 : xm2;
+    v2y = (c2y <= v1y) ? c2y : INFINITY;
+    v2x = (c2x <= v1x) ? c2x : INFINITY;
+  } else {
+    v1y = fmin(ym1, yp1);
+    v1x = fmin(xm1, xp1);
+  }
+  // the axis with the smaller neighbour first (equal values: either)
+  const double s1 = fmin(v1y, v1x), o1 = fmax(v1y, v1x);
+  float as = 1.0f, ao = 1.0f, ts = 0.0f, r = 1.0f, rA = 0.5f;
   const float ov = (float)(o1 - s1);                                       // +inf when the other axis has no upwind neighbour
-  const float ao = o2 ? 2.25f : 1.0f;
-  const float to = o2 ? ov + (float)(o1 - o2v) * (1.0f / 3.0f) : ov;
+  float to = ov;
+  if (SECOND) {
+    const bool y_first = v1y <= v1x;
+    const double s2v = y_first ? v2y : v2x, o2v = y_first ? v2x : v2y;
+    const bool s2 = s2v < INFINITY, o2 = o2v < INFINITY;
+    as = s2 ? 2.25f : 1.0f;
+    ts = s2 ? (float)(s1 - s2v) * (1.0f / 3.0f) : 0.0f;
+    r = ts + (s2 ? (2.0f / 3.0f) : 1.0f);
+    ao = o2 ? 2.25f : 1.0f;
+    to = o2 ? ov + (float)(o1 - o2v) * (1.0f / 3.0f) : ov;
+    rA = (s2 == o2) ? (s2 ? (1.0f / 4.5f) : 0.5f) : (1.0f / 3.25f);
+  }
   const float A = as + ao, B = as * ts + ao * to, C = as * ts * ts + ao * to * to - 1.0f;
   const float det = B * B - A * C;
-  const float u2 = (B + sqrtf(det)) / A;
-  if (o1 < INFINITY && ov < r && det >= 0.0f && u2 > ov) r = u2;
+  const float u2 = (B + __builtin_amdgcn_sqrtf(det)) * rA;
+  if (ov < r && det >= 0.0f && u2 > ov) r = u2;                            // (ov = +inf: no joint root)
   return s1 < INFINITY ? s1 + (double)r : INFINITY;
 }
 
@@ -322,12 +339,13 @@ __global__ __launch_bounds__(1024) void fmm_round_kernel(double* __restrict__ di
 // relaxed again only when one of its four neighbour blocks (the stencil is axis-aligned) published a change.  The
 // schedule is deterministic (every block reads the tile as of the last barrier); stage A's monotone field and stage B's
 // fixed dependency graph make the result independent of the schedule up to the update's own noise floor.
-constexpr int BLK = 8, PT = BLK + 2 * HALO, MAX_OUTER = 32, MAX_INNER = 48;      // private tile 12 x 12
+constexpr int BLK = 8, PT = BLK + 2 * HALO, MAX_OUTER = 64;      // private tile 12 x 12
 template <bool SECOND, bool LOCAL32>
 __global__ __launch_bounds__(1024) void fmm_round_blocked_kernel(double* __restrict__ dist, const double* __restrict__ ord,
                                                                  const unsigned char* __restrict__ state, int H, int W, int tiles_x, int tiles_y,
                                                                  const unsigned char* __restrict__ active_in, unsigned char* __restrict__ active_out,
-                                                                 unsigned char* __restrict__ active_clear, unsigned int* __restrict__ changed_tiles) {
+                                                                 unsigned char* __restrict__ active_clear, unsigned int* __restrict__ changed_tiles,
+                                                                 int max_inner) {
   const int tile = blockIdx.x;
   if (threadIdx.x == 0) active_clear[tile] = 0;
   if (!active_in[tile]) return;
@@ -351,7 +369,9 @@ __global__ __launch_bounds__(1024) void fmm_round_blocked_kernel(double* __restr
   if (threadIdx.x < 2) anyflag[threadIdx.x] = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int by = wave >> 2, bx = wave & 3;
+  // wave -> block through a Latin square (waves w, w + 4, w + 8, w + 12 share a SIMD): the blocks of a row AND of a column
+  // of the tile sit on four different SIMDs, so a front that runs along either axis does not queue its blocks on one of them
+  const int by = wave >> 2, bx = (wave & 3) ^ (by ^ (by >> 1));
   const int ly = HALO + BLK * by + (lane >> 3), lx = HALO + BLK * bx + (lane & 7);
   const int py = HALO + (lane >> 3), px = HALO + (lane & 7);
   unsigned feed = st[ly][lx] == ST_FREE ? 0x100u : 0u;       // as in fmm_round_kernel
@@ -394,12 +414,12 @@ __global__ __launch_bounds__(1024) void fmm_round_blocked_kernel(double* __restr
       const double own0 = pv[pc];
       double val = own0;
       again = true;
-      for (int inner = 0; inner < MAX_INNER; ++inner) {
+      for (int inner = 0; inner < max_inner; ++inner) {
         const double ym1 = pv[a_ym1], yp1 = pv[a_yp1], xm1 = pv[a_xm1], xp1 = pv[a_xp1];
         double ym2 = INFINITY, yp2 = INFINITY, xm2 = INFINITY, xp2 = INFINITY;
         if (SECOND) { ym2 = pv[a_ym2]; yp2 = pv[a_yp2]; xm2 = pv[a_xm2]; xp2 = pv[a_xp2]; }
         double u;
-        if (LOCAL32) u = update_cell_local_fast(ym1, ym2, yp1, yp2, xm1, xm2, xp1, xp2);
+        if (LOCAL32) u = update_cell_local_fast<SECOND>(ym1, ym2, yp1, yp2, xm1, xm2, xp1, xp2);
         else u = update_cell(axis_term(ym1, ym2, yp1, yp2), axis_term(xm1, xm2, xp1, xp2));
         if (SECOND) {
           if (val < INFINITY && fabs(u - val) <= (LOCAL32 ? 1e-6 : 1e-12 * fmax(1.0, val))) u = val;
@@ -583,12 +603,13 @@ int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned lo
       unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
       unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
       const bool local32 = opt(OPT_FMM_LOCAL32) != 0, blocked = opt(OPT_FMM_BLOCKED) != 0;
-#define PEANUT_FMM_LAUNCH(KERNEL)                                                                                                      \
+#define PEANUT_FMM_LAUNCH(KERNEL, ...)                                                                                                 \
   hipLaunchKernelGGL(KERNEL, dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p, (const unsigned char*)g->state.p, \
-                     H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k)
+                     H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k, ##__VA_ARGS__)
       if (blocked) {
-        if (local32) PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, true>));
-        else PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, false>));
+        const int max_inner = (int)std::min<long long>(std::max<long long>(opt(OPT_FMM_INNER), 1), 1024);
+        if (local32) PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, true>), max_inner);
+        else PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, false>), max_inner);
       } else {
         if (local32) PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, true>));
         else PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, false>));
