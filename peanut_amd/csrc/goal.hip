@@ -56,9 +56,51 @@ constexpr int MAX_ORDER_PASSES = 24;    // default of option fmm_max_passes: a c
 enum : unsigned char { ST_MASKED = 0, ST_FREE = 1, ST_SEED = 2 };
 
 // ---- traversible map: ~dilate(rint(obstacle), disk(rad)), collision -> 0, visited -> 1  (agent_state.py:382-386) ----
+// A workgroup covers 32 x 8 cells.  The obstacle bits of its rows (8 + 2 rad of them, 32 + 2 rad columns wide: one 64-bit word per
+// row while rad <= 16) are formed once with a ballot per row; a cell is blocked when any row of its disk has an obstacle bit under
+// that row's chord -- 2 rad + 1 AND-tests instead of (2 rad + 1)^2 loads (85 -> ~12 us on the 960 x 960 map).
+constexpr int TRAV_MAX_RAD = 16;
 __global__ __launch_bounds__(256) void goal_trav_kernel(const float* __restrict__ obst, const unsigned char* __restrict__ collision,
                                                         const unsigned char* __restrict__ visited, int H, int W, int rad,
                                                         unsigned char* __restrict__ trav) {
+  __shared__ unsigned long long rowbits[8 + 2 * TRAV_MAX_RAD];
+  __shared__ int chord[2 * TRAV_MAX_RAD + 1];      // half-width of the disk at row offset dy
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 8;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int span = 32 + 2 * rad;                    // <= 64
+  for (int rr = wave; rr < 8 + 2 * rad; rr += 4) {
+    const int r = r0 - rad + rr, c = c0 - rad + lane;
+    const bool ob = lane < span && r >= 0 && r < H && c >= 0 && c < W && rintf(obst[(size_t)r * W + c]) != 0.f;
+    const unsigned long long m = __ballot(ob);
+    if (lane == 0) rowbits[rr] = m;
+  }
+  if (threadIdx.x <= 2 * rad) {
+    const int dy = (int)threadIdx.x - rad;
+    int w = 0;
+    while ((w + 1) * (w + 1) + dy * dy <= rad * rad) ++w;
+    chord[threadIdx.x] = w;
+  }
+  __syncthreads();
+  const int lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
+  const int c = c0 + lc, r = r0 + lr;
+  if (r >= H || c >= W) return;
+  bool blocked = false;
+  for (int dy = -rad; dy <= rad; ++dy) {
+    const int w = chord[dy + rad];
+    // bits lc + rad - w .. lc + rad + w of the row (bit b = column c0 - rad + b)
+    const unsigned long long mask = ((w + w + 1 >= 64) ? ~0ull : ((1ull << (w + w + 1)) - 1ull)) << (lc + rad - w);
+    blocked = blocked || (rowbits[lr + rad + dy] & mask) != 0ull;
+  }
+  unsigned char t = blocked ? 0 : 1;
+  const size_t i = (size_t)r * W + c;
+  if (collision && collision[i] == 1) t = 0;
+  if (visited && visited[i] == 1) t = 1;
+  trav[i] = t;
+}
+// any radius (the footprint test cell by cell): used beyond TRAV_MAX_RAD
+__global__ __launch_bounds__(256) void goal_trav_wide_kernel(const float* __restrict__ obst, const unsigned char* __restrict__ collision,
+                                                             const unsigned char* __restrict__ visited, int H, int W, int rad,
+                                                             unsigned char* __restrict__ trav) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (r >= H || c >= W) return;
   bool blocked = false;
@@ -742,8 +784,12 @@ int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint
 int peanut_goal_traversible(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map, const uint8_t* visited_vis,
                             uint8_t* trav_out, void* stream) {
   if (!g || !full_obstacle) return fail(PEANUT_EINVAL, "peanut_goal_traversible: null argument");
-  hipLaunchKernelGGL(goal_trav_kernel, dim3((g->W + 31) / 32, (g->H + 7) / 8), dim3(256), 0, (hipStream_t)stream, full_obstacle,
-                     collision_map, visited_vis, g->H, g->W, g->rad, trav_out ? trav_out : (unsigned char*)g->trav.p);
+  if (g->rad <= TRAV_MAX_RAD)
+    hipLaunchKernelGGL(goal_trav_kernel, dim3((g->W + 31) / 32, (g->H + 7) / 8), dim3(256), 0, (hipStream_t)stream, full_obstacle,
+                       collision_map, visited_vis, g->H, g->W, g->rad, trav_out ? trav_out : (unsigned char*)g->trav.p);
+  else
+    hipLaunchKernelGGL(goal_trav_wide_kernel, dim3((g->W + 31) / 32, (g->H + 7) / 8), dim3(256), 0, (hipStream_t)stream, full_obstacle,
+                       collision_map, visited_vis, g->H, g->W, g->rad, trav_out ? trav_out : (unsigned char*)g->trav.p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_goal_traversible: ") + hipGetErrorString(e));
 }

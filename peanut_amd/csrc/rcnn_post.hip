@@ -117,14 +117,15 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int 
     const int nb = 1 << bits[pass];
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     __syncthreads();
-    // eight loads in flight per thread before the first LDS atomic: at batch 1 this kernel is five workgroups, and a
-    // load-use-load chain over the 163 200 logits of the finest level cost 155 us (profiles/r3h)
-    for (int i0 = tid; i0 < n; i0 += 1024 * 8) {
-      float v[8];
+    // sixteen loads in flight per thread before the first LDS atomic: at batch 1 this kernel is five workgroups, and a
+    // load-use-load chain over the 163 200 logits of the finest level cost 155 us (profiles/r3h; combining equal bins inside
+    // the wave before the atomic was measured at four times the cost: the lanes of a wave hit too many distinct bins, r8h)
+    for (int i0 = tid; i0 < n; i0 += 1024 * 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (i0 + u * 1024 < n) ? x[i0 + u * 1024] : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = (i0 + u * 1024 < n) ? x[i0 + u * 1024] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         if (i0 + u * 1024 >= n) break;
         const unsigned key = ord_key(v[u]);
         const bool match = pass == 0 || (key >> (shift[pass] + bits[pass])) == prefix;

@@ -148,7 +148,7 @@ def test_traversible_map_is_bit_exact():
     obst[0, 0] = obst[199, 259] = 1.0                    # borders: the footprint is cut off, zero outside
     col = (rng.rand(200, 260) > 0.995).astype(np.float64)
     vis = (rng.rand(200, 260) > 0.99).astype(np.float64)
-    for rad in (4, 1, 0):
+    for rad in (4, 1, 0, 7, 16, 17):          # (<= 16: row bit masks; beyond: the cell-by-cell footprint test)
         sol = GeodesicSolver(200, 260, rad)
         got = sol.traversible(torch.from_numpy(obst), col, vis).cpu().numpy()
         ref = goal_ref.traversible_map(obst, disk(rad), col, vis)
