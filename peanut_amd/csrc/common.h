@@ -64,6 +64,7 @@ struct ConvArgs {
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)48 << 20;   // 192 MiB: 768 partial 256x256 tiles (the stream-K tail of the persistent 256 x 256 kernel: up to 3 fragments for each of < 256 tail tiles)
+constexpr size_t kSplitKSideFloats = (size_t)8 << 20;       // 32 MiB: split-K scratch of the ops a plan runs on a side stream (small layers)
 
 inline int conv_out_dim(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 

@@ -305,7 +305,8 @@ void resized_hw(const peanut_rcnn_cfg& c, int h, int w, int* nh, int* nw) {
   *nw = (int)(neww + 0.5);
 }
 
-void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1) {
+void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const Act* res, const Act& out, int ext_slot = -1,
+                std::vector<Act>* keep = nullptr) {
   if (L->has_wino) L = wino_pick_form(L, in.B, in.H, in.W);
   ROp op;
   op.kind = R_CONV; op.name = L->name; op.conv = L; op.in = in; op.out = out;
@@ -320,8 +321,13 @@ void push_rconv(RPlan& pl, Arena& ar, const ConvLayer* L, const Act& in, const A
     op.wino_v.bytes = vf * sizeof(float); op.wino_v.off = ar.alloc(op.wino_v.bytes);
     op.wino_m.bytes = mf * sizeof(float); op.wino_m.off = ar.alloc(op.wino_m.bytes);
     op.has_wino = true;
-    ar.release(op.wino_v.off, op.wino_v.bytes);
-    ar.release(op.wino_m.off, op.wino_m.bytes);
+    if (keep) {                // (an op that runs next to later ones keeps its scratch until they have joined)
+      keep->push_back(op.wino_v);
+      keep->push_back(op.wino_m);
+    } else {
+      ar.release(op.wino_v.off, op.wino_v.bytes);
+      ar.release(op.wino_m.off, op.wino_m.bytes);
+    }
   }
   pl.ops.push_back(op);
 }
@@ -388,7 +394,15 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
     }
     feats[si] = cur;
   }
-  // FPN top-down (levels 5 -> 2)
+  // FPN top-down (levels 5 -> 2).  The 3x3 output convs of p5, p4, p3 depend on their own lateral sum only: with rcnn_fpn_overlap
+  // they are marked for the side stream and run next to the chain lateral -> top-down add -> ... -> p2's output conv (a frame at
+  // batch 1 leaves most CUs idle in every one of these launches).  What they read and their scratch stays allocated until the join.
+  const bool fpn_side = opt(OPT_RCNN_FPN_OVERLAP) != 0;
+  std::vector<Act> keep;
+  if (fpn_side) {
+    pl->splitk_side.bytes = kSplitKSideFloats * sizeof(float);
+    pl->splitk_side.off = ar.alloc(pl->splitk_side.bytes);
+  }
   Act prev{};
   Act p[5];
   for (int lvl = 3; lvl >= 0; --lvl) {
@@ -398,15 +412,19 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
     if (lvl < 3) {
       ROp op; op.kind = R_ADD_UP; op.name = "fpn_topdown" + std::to_string(lvl + 2); op.kernel = "add_upsampled2x";
       op.in = prev; op.out = lat; pl->ops.push_back(op);
-      rel(prev);
+      if (fpn_side) keep.push_back(prev); else rel(prev);
     }
     prev = lat;
     p[lvl] = conv_out_act(ar, h->output[lvl], prev);
-    push_rconv(*pl, ar, h->output[lvl], prev, nullptr, p[lvl], lvl);
+    const bool side = fpn_side && lvl > 0;
+    push_rconv(*pl, ar, h->output[lvl], prev, nullptr, p[lvl], lvl, side ? &keep : nullptr);
+    pl->ops.back().side = side;
   }
   rel(prev);
   p[4] = make_act(ar, B, (p[3].H - 1) / 2 + 1, (p[3].W - 1) / 2 + 1, p[3].C);
-  { ROp op; op.kind = R_SUBSAMPLE; op.name = "p6"; op.kernel = "subsample2"; op.in = p[3]; op.out = p[4]; op.ext_slot = 4; op.in_ext_slot = 3; pl->ops.push_back(op); }
+  { ROp op; op.kind = R_SUBSAMPLE; op.name = "p6"; op.kernel = "subsample2"; op.in = p[3]; op.out = p[4]; op.ext_slot = 4; op.in_ext_slot = 3;
+    op.join_side = fpn_side; pl->ops.push_back(op); }
+  for (const Act& t : keep) rel(t);
   // RPN head on p2..p6: the fused chain over all levels (RpnFused; taken at run time when the caller's objectness / delta buffers
   // are contiguous in level order or absent) ...
   if (h->rpn_conv->has_wino && opt(OPT_RCNN_RPN_FUSED) != 0) {
@@ -620,9 +638,22 @@ static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
     }
   }
   if (events) PEANUT_HIP_CHECK(hipEventRecord(events[0], s));
+  // side stream of the FPN output convs (not while probing: the per-op events time one stream)
+  const bool use_side = !events && pl->splitk_side.bytes != 0;
+  if (use_side && !h->side) {
+    PEANUT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    PEANUT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    PEANUT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  bool side_pending = false;
   size_t op_index = 0;
   for (const auto& op : pl->ops) {
     const bool skip = (op.kind == R_RPN_FUSED && !rpn_fused) || (op.rpn_level && rpn_fused);
+    if (op.join_side && side_pending) {
+      PEANUT_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+      PEANUT_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
+      side_pending = false;
+    }
     if (skip) {
       if (families) families[op_index] = "skipped";
       ++op_index;
@@ -683,7 +714,15 @@ static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
         a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.c1 = op.in.C; a.c2 = 0; a.Ho = op.out.H; a.Wo = op.out.W;
         if (op.has_in2) { a.x2 = P(op.in2); a.c2 = op.in2.C; }
         a.ws = P(pl->splitk); a.ws_floats = kSplitKScratchFloats;
-        if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, s))) return rc;
+        hipStream_t os = s;
+        if (op.side && use_side) {      // behind everything enqueued so far, next to what follows
+          PEANUT_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+          PEANUT_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+          os = h->side;
+          a.ws = P(pl->splitk_side); a.ws_floats = kSplitKSideFloats;
+          side_pending = true;
+        }
+        if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, os))) return rc;
         break;
       }
       case R_MAXPOOL:

@@ -19,6 +19,8 @@ struct ROp {
   int ext_slot = -1;          // 0..4 = p2..p6, 5..9 = objectness, 10..14 = deltas
   int in_ext_slot = -1;       // the input is the caller-owned output of that slot (read there when the caller gave a buffer)
   bool rpn_level = false;     // one of the fifteen per-level RPN-head launches: skipped when the fused form (R_RPN_FUSED) runs
+  bool side = false;          // FPN output conv of p3..p5: may run on the handle's side stream next to the top-down chain (round 5)
+  bool join_side = false;     // the first op that reads a side op's output: the main stream waits for the side stream before it
 };
 
 // The RPN head on all five pyramid levels as ONE chain (round 5): the shared 3x3 conv as Winograd with the levels' tiles side by
@@ -34,7 +36,7 @@ struct RpnFused {
 
 struct RPlan {
   int B = 0, H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
-  Act splitk;
+  Act splitk, splitk_side;    // split-K scratch of the main chain / of the ops on the side stream
   size_t bytes = 0;
   std::vector<ROp> ops;
   int lvl_h[5] = {0}, lvl_w[5] = {0};
@@ -67,6 +69,14 @@ struct peanut_rcnn {
   std::vector<peanut::ConvLayer*> mask_fcn;
   struct PostBufs;                       // scratch of peanut_rcnn_inference (rcnn_post.hip)
   std::shared_ptr<PostBufs> post;
+  // FPN side stream (rcnn_api.hip): the output convs of p5, p4, p3 next to the lateral / top-down chain that ends in p2's
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~peanut_rcnn() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 

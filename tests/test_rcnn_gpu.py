@@ -265,6 +265,35 @@ def test_rpn_head_fused_over_the_levels_equals_the_level_by_level_form(small_net
     del fused, plain
 
 
+def test_fpn_output_convs_on_the_side_stream_change_nothing(small_net):
+    """Round 5: the 3x3 output convs of p5, p4, p3 run on the handle's side stream next to the lateral / top-down chain that ends
+    in p2's output conv (option rcnn_fpn_overlap).  Same kernels on the same data, only the schedule differs: detections, the
+    pyramid and the semantic map are bit-identical to a handle with the option off, over repeated calls (a race would show as a
+    difference on some of them)."""
+    from peanut_amd import _lib
+    from peanut_amd.rcnn import MaskRCNN
+    s = small_net
+    img = s["img"].cuda()
+    with _lib.default_options(rcnn_fpn_overlap=1):
+        over = MaskRCNN(s["cfg"], s["sd"])
+    with _lib.default_options(rcnn_fpn_overlap=0):
+        plain = MaskRCNN(s["cfg"], s["sd"])
+    ref_front = plain.forward_front(img)
+    ref = plain.inference(img)
+    ref_sem = plain.semantic(img, s["cfg"].num_classes, 0.5, 0.5, None)
+    for rep in range(6):
+        fr = over.forward_front(img)
+        for k, (xs, ys) in enumerate(zip(fr, ref_front)):          # (pyramid, objectness, deltas)
+            for x, y in zip(xs, ys):
+                assert torch.equal(x, y), (rep, k)
+        got = over.inference(img)
+        for x, y in zip(got, ref):
+            assert torch.equal(x["scores"], y["scores"]) and torch.equal(x["pred_boxes"], y["pred_boxes"])
+            assert torch.equal(x["pred_masks"], y["pred_masks"])
+        assert torch.equal(over.semantic(img, s["cfg"].num_classes, 0.5, 0.5, None), ref_sem)
+    del over, plain
+
+
 def test_semantic_pred_maskrcnn_args_constructor(small_net, tmp_path):
     """segmentation.py:28-62 call surface: SemanticPredMaskRCNN(args).get_prediction(rgb) with a detectron2-format
     checkpoint on disk; the result equals the oracle detector + the reference's accumulation loop."""
