@@ -83,7 +83,7 @@ inline const OptionInfo* option_table() {
       {"rcnn_wino_m", 0, true, "detector front end: 4 / 5 / 6 pins one Winograd form (0: per shape)"},
       {"rcnn_stem_s2d", 1, true, "detector stem 7x7 stride 2 as a space-to-depth 4x4 conv"},
       {"rcnn_rpn_fused", 1, false, "detector: the RPN head on all five pyramid levels as one chain (five input transforms, ONE grouped Winograd GEMM, five output transforms, one objectness and one anchor-delta GEMM over all levels' rows: 12 launches instead of 25); read when a (B, H, W) plan is built"},
-      {"rcnn_fpn_overlap", 1, false, "detector: the FPN output convs of p5, p4, p3 on a side stream next to the lateral / top-down chain that ends in p2's (round 5); read when a (B, H, W) plan is built"},
+      {"rcnn_fpn_overlap", 0, false, "detector: the FPN output convs of p5, p4, p3 on a side stream next to the lateral / top-down chain that ends in p2's (round 5 experiment, bit-identical; measured SLOWER at batch 1, 5.70 against 5.61 ms per frame, profiles/r8: off); read when a (B, H, W) plan is built"},
       {"fmm_local32", 1, false, "goal solver: single-precision local solve inside a tile"},
       {"fmm_max_passes", 24, false, "goal solver: hard ceiling of the second-order ordering passes; they stop as soon as a pass changes nothing (6-10 passes on the agent's 960 x 960 map; peanut_goal_converged reports whether they reached their fixed point)"},
       {"fmm_blocked", 1, false, "goal solver: a wave relaxes its 8 x 8 block of the tile to convergence between workgroup barriers (round 5; 0: one Jacobi sweep of the whole tile per barrier pair)"},
