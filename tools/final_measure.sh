@@ -21,6 +21,8 @@ python tools/bench_rcnn.py 1 2>/dev/null | grep "^{" > $OUT/rcnn_b1.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --precision bf16x6 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
+python tools/bench_pipeline.py --episodes 2 --frames 40 --detector 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl          # the bench line's own shape
+python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --serial-goal 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl   # goal selection after the forward, timed on its own
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision bf16x6 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision fp16x3 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
 python tools/bench_pipeline.py --episodes 2 --frames 60 --detector --precision bf16x3 2>/dev/null | grep "^{" >> $OUT/pipeline_config4.jsonl
@@ -40,6 +42,8 @@ rocprofv3 --kernel-trace -d /tmp/fm_tl -- python $R/bench.py --batch 1 --size 72
 db=$(find /tmp/fm_tl -name '*.db' | head -1)
 cd $R
 python tools/gap_b1.py $OUT/gap_b1.json ${db:+--timeline-db $db --timeline-forwards 20} > $OUT/gap_b1_summary.txt 2>/dev/null
+python tools/step_profile.py 60 2>/dev/null | grep "^{" > $OUT/step_profile.json
+bash tools/exp_r8g.sh > /dev/null 2>&1; cp gpurun_out/r8g/detector_b1_timeline.txt $OUT/ 2>/dev/null
 tools/pmc_passes.sh $OUT/pmc_fp32 --precision fp32
 tools/pmc_passes.sh $OUT/pmc_bf16x6 --precision bf16x6
 tools/pmc_passes.sh $OUT/pmc_fp16x3 --precision fp16x3
