@@ -8,11 +8,15 @@
 // first-order fallback, masked cells excluded from every stencil; oracle/fmm_ref.c states the update rule that is
 // mirrored operation by operation, in double) is solved by relaxation, arranged so that every stage provably ends:
 //
-//   * tiles: the map is cut into 32x32 tiles; a workgroup stages a tile plus a 2-cell halo in LDS and sweeps it
-//     (Jacobi, two barriers per sweep, one cell per lane, re-evaluating only cells whose stencil saw a change in the
-//     previous sweep) until nothing in the tile changes; a tile that changed wakes
-//     its four neighbours for the next round (the stencil is axis-aligned: no diagonal dependency); rounds are plain
-//     launches over the tile grid in which sleeping tiles exit at once; the host reads one counter every few rounds;
+//   * tiles: the map is cut into 32x32 tiles; a workgroup stages a tile plus a 2-cell halo in LDS and relaxes it until nothing
+//     in the tile changes -- since round 5 block-wise (fmm_round_blocked_kernel): each of the 16 waves owns an 8 x 8 block, keeps
+//     a private copy of it with its two-cell ring and iterates it to convergence between two workgroup barriers (Jacobi inside
+//     the wave, which needs no barrier), then publishes it; the older form (fmm_round_kernel, option fmm_blocked = 0) sweeps
+//     the whole tile once per barrier pair.  A tile that changed wakes its four neighbours for the next round (the stencil is
+//     axis-aligned: no diagonal dependency); rounds are plain launches over the tile grid in which sleeping tiles exit at
+//     once; the host reads one counter every few rounds.  Only a ring of tiles is awake in a round, so a round costs the
+//     LATENCY of its slowest tile: the number of iterations the front needs to cross it times the dependent instruction
+//     chain of one update (profiles/r8/README.md), which is what the blocked form and update_cell_local_fast shorten;
 //   * stage A, first order: u <- min(u, update(u)) from +inf.  Monotone, hence convergent, to the unique first-order
 //     field u1 (the classic fast iterative method);
 //   * stage B, second order, on a FIXED dependency graph: a neighbour may feed a cell only if it precedes the cell in
@@ -35,6 +39,10 @@
 // The rest of update_global_goal is fused around it: obstacle dilation by the collision disk + collision / visited
 // overrides -> traversible map (:382-386), exp(-d / temperature) weights with the "stuck: keep the last weights"
 // rule (:395-399), value = target_pred * weights and its first-occurrence argmax (:401-413).
+//
+// The field needs the map, not the prediction: after peanut_goal_mark_inputs the traversible map and the field of the next
+// select run on a stream of the handle, next to the forward the caller enqueued in between (Agent_State.update_state:
+// update_prediction then update_global_goal); the caller's stream joins before the weights are formed.
 #include <math.h>
 #include <stdlib.h>
 

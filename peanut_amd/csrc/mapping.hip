@@ -253,8 +253,8 @@ __device__ __forceinline__ void map_rearm(int p, const unsigned* __restrict__ ke
 // ---- 5. per-voxel replay of the 8 corner passes ----
 __global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict__ wts6, const float* __restrict__ feat_s,
                                                          const unsigned* __restrict__ skey,
-                                                         const int* __restrict__ cell_head, float* __restrict__ proj,
-                                                         MapP P) {
+                                                         const int* __restrict__ cell_head, const int* __restrict__ cell_cnt,
+                                                         float* __restrict__ proj, MapP P) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)P.N * 8 * P.F;
   if (t >= total) return;
@@ -287,10 +287,24 @@ __global__ __launch_bounds__(256) void map_voxels_kernel(const float* __restrict
     const float* wa = wts6 + (size_t)c0 * P.N;
     const float* wb = wts6 + (size_t)(2 + c1) * P.N;
     const float* wc = wts6 + (size_t)(4 + c2) * P.N;
-    for (int j = hd; j < P.N && skey[j] == hk; ++j) {
-      const float wts = (wa[j] * wb[j]) * wc[j];      // ((1*w0)*w1)*w2
+    // the cell's points are the cell_cnt[hk] entries from hd on: the loads of four of them go out together (the loop used to end on
+    // `skey[j] != hk`, one dependent load per point: this kernel was 45 % of the step), the adds stay in point order
+    const int end = hd + cell_cnt[hk];
+    int j = hd;
+    for (; j + 4 <= end; j += 4) {
+      const float a0 = wa[j], a1 = wa[j + 1], a2 = wa[j + 2], a3 = wa[j + 3];
+      const float b0 = wb[j], b1 = wb[j + 1], b2 = wb[j + 2], b3 = wb[j + 3];
+      const float d0 = wc[j], d1 = wc[j + 1], d2 = wc[j + 2], d3 = wc[j + 3];
+      const float f0 = (f == 0) ? 1.0f : fs[j], f1 = (f == 0) ? 1.0f : fs[j + 1], f2 = (f == 0) ? 1.0f : fs[j + 2], f3 = (f == 0) ? 1.0f : fs[j + 3];
+      val = val + f0 * ((a0 * b0) * d0);              // ((1*w0)*w1)*w2; scatter_add_ in point order
+      val = val + f1 * ((a1 * b1) * d1);
+      val = val + f2 * ((a2 * b2) * d2);
+      val = val + f3 * ((a3 * b3) * d3);
+    }
+    for (; j < end; ++j) {
+      const float wts = (wa[j] * wb[j]) * wc[j];
       const float ft = (f == 0) ? 1.0f : fs[j];
-      val = val + ft * wts;                           // scatter_add_ in point order
+      val = val + ft * wts;
     }
     val = rintf(val);                                 // torch.round of the whole grid after this pass
   }
@@ -412,6 +426,7 @@ __device__ __forceinline__ float rotated_at(const float* __restrict__ view, int 
   return acc;
 }
 
+constexpr int kWarpChannels = 2;
 __global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__ view, const float* __restrict__ maps_last,
                                                        float* __restrict__ map_pred, const WarpT* __restrict__ wtp,
                                                        MapP P) {
@@ -443,7 +458,10 @@ __global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__
       touch |= hit;
     }
   }
-  for (int c = 0; c < P.C; ++c) {
+  // blockIdx.y: a group of kWarpChannels channels (one thread per pixel over all 14 channels left the launch at ~1 TB/s: too few
+  // loads in flight; the tap set-up above is a few dozen ALU operations and is simply repeated per group)
+  const int c_lo = blockIdx.y * kWarpChannels, c_hi = min(P.C, c_lo + kWarpChannels);
+  for (int c = c_lo; c < c_hi; ++c) {
     float tr = 0.0f;
     if (touch && c != 2 && c != 3) {
       const float v0 = rotated_at(view, c, tt.y0, tt.x0, rt[0], in_img[0], P);
@@ -632,12 +650,12 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
                        h->skeys, h->sidx, h->wts6, h->feat_s, P);
     const long long vt = (long long)P.N * 8 * P.F;
     hipLaunchKernelGGL(map_voxels_kernel, dim3((unsigned)((vt + 255) / 256)), dim3(256), 0, s, h->wts6, h->feat_s, h->skeys,
-                       h->cell_head, h->proj, P);
+                       h->cell_head, h->cell_cnt, h->proj, P);
     const int nfin = (std::max(P.vr * P.vr, P.N) + 255) / 256;
     hipLaunchKernelGGL(map_finish_kernel, dim3(nfin), dim3(256), 0, s, h->proj, h->view, fp_map_pred, h->stats, pose_obs, poses_inout,
                        h->wt, h->keys, h->cell_head, h->cell_cnt, h->cell_first, h->cell_fill, h->cursor, P);
-    hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
-                       h->wt, P);
+    hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256, (P.C + kWarpChannels - 1) / kWarpChannels), dim3(256), 0, s, h->view,
+                       maps_last, map_pred, h->wt, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_map_forward: ") + hipGetErrorString(e));
     return 0;
