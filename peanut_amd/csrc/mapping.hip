@@ -425,8 +425,20 @@ __device__ __forceinline__ float rotated_at(const float* __restrict__ view, int 
   acc = fmaf(sev, rt.se, acc);
   return acc;
 }
+// the same value with the four window reads unconditional (clamped address, the result replaced by 0 outside the window): the
+// sixteen reads of an output pixel and channel go out together instead of one wait per branch
+struct TapAddr { int o[4]; bool ok[4]; };
+__device__ __forceinline__ TapAddr tap_addr(const Tap& rt, bool in_img, const MapP& P) {
+  TapAddr a;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int wy = rt.y0 + (k >> 1) - P.y1, wx = rt.x0 + (k & 1) - P.x1;
+    a.ok[k] = in_img && (unsigned)wy < (unsigned)P.vr && (unsigned)wx < (unsigned)P.vr;
+    a.o[k] = a.ok[k] ? wy * P.vr + wx : 0;
+  }
+  return a;
+}
 
-constexpr int kWarpChannels = 2;
 __global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__ view, const float* __restrict__ maps_last,
                                                        float* __restrict__ map_pred, const WarpT* __restrict__ wtp,
                                                        MapP P) {
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__
   float gyt = bx * 0.0f; gyt = fmaf(by, 1.0f, gyt); gyt = fmaf(1.0f, wt.ty, gyt);
   const Tap tt = make_tap(gxt, gyt, M);
   // the four `rotated` pixels this output blends, each with its own rotation tap
-  Tap rt[4];
+  Tap rt[4] = {};
   bool in_img[4], touch = false;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -458,23 +470,51 @@ __global__ __launch_bounds__(256) void map_warp_kernel(const float* __restrict__
       touch |= hit;
     }
   }
-  // blockIdx.y: a group of kWarpChannels channels (one thread per pixel over all 14 channels left the launch at ~1 TB/s: too few
-  // loads in flight; the tap set-up above is a few dozen ALU operations and is simply repeated per group)
-  const int c_lo = blockIdx.y * kWarpChannels, c_hi = min(P.C, c_lo + kWarpChannels);
-  for (int c = c_lo; c < c_hi; ++c) {
-    float tr = 0.0f;
-    if (touch && c != 2 && c != 3) {
-      const float v0 = rotated_at(view, c, tt.y0, tt.x0, rt[0], in_img[0], P);
-      const float v1 = rotated_at(view, c, tt.y0, tt.x0 + 1, rt[1], in_img[1], P);
-      const float v2 = rotated_at(view, c, tt.y0 + 1, tt.x0, rt[2], in_img[2], P);
-      const float v3 = rotated_at(view, c, tt.y0 + 1, tt.x0 + 1, rt[3], in_img[3], P);
-      tr = v0 * tt.nw;
-      tr = fmaf(v1, tt.ne, tr);
-      tr = fmaf(v2, tt.sw, tr);
-      tr = fmaf(v3, tt.se, tr);
+  const size_t plane = (size_t)M * M;
+  if (!__any(touch)) {
+    // (most of the map: outside the warped window the output is max(maps_last, 0).)  All channels' loads first, then the stores:
+    // the loop `load, wait, store` per channel cost one memory latency per channel, 14 in a row -- most of this kernel's 22 us
+    for (int c0 = 0; c0 < P.C; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (c0 + u < P.C) ? maps_last[(size_t)(c0 + u) * plane + t] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + u < P.C) map_pred[(size_t)(c0 + u) * plane + t] = fmaxf(v[u], 0.0f);
     }
-    const size_t o = (size_t)c * M * M + t;
-    map_pred[o] = fmaxf(maps_last[o], tr);     // torch.max over the stacked pair (mapping.py:175-177)
+    return;
+  }
+  TapAddr ta[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ta[q] = tap_addr(rt[q], touch && in_img[q], P);
+  for (int c = 0; c < P.C; ++c) {
+    const float last = maps_last[(size_t)c * plane + t];
+    float tr = 0.0f;
+    if (c != 2 && c != 3) {           // (a pixel of this wave that touches nothing reads element 0 sixteen times and gets 0)
+      const float* vc = view + (size_t)c * P.vr * P.vr;
+      float w[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[q][k] = vc[ta[q].o[k]];
+      float vq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float nwv = ta[q].ok[0] ? w[q][0] : 0.0f, nev = ta[q].ok[1] ? w[q][1] : 0.0f;
+        const float swv = ta[q].ok[2] ? w[q][2] : 0.0f, sev = ta[q].ok[3] ? w[q][3] : 0.0f;
+        float acc = nwv * rt[q].nw;
+        acc = fmaf(nev, rt[q].ne, acc);
+        acc = fmaf(swv, rt[q].sw, acc);
+        acc = fmaf(sev, rt[q].se, acc);
+        vq[q] = (touch && in_img[q]) ? acc : 0.0f;
+      }
+      tr = vq[0] * tt.nw;
+      tr = fmaf(vq[1], tt.ne, tr);
+      tr = fmaf(vq[2], tt.sw, tr);
+      tr = fmaf(vq[3], tt.se, tr);
+      if (!touch) tr = 0.0f;
+    }
+    map_pred[(size_t)c * plane + t] = fmaxf(last, tr);     // torch.max over the stacked pair (mapping.py:175-177)
   }
 }
 
@@ -654,8 +694,8 @@ int peanut_map_forward(peanut_map_t* h, const float* obs, const float* pose_obs,
     const int nfin = (std::max(P.vr * P.vr, P.N) + 255) / 256;
     hipLaunchKernelGGL(map_finish_kernel, dim3(nfin), dim3(256), 0, s, h->proj, h->view, fp_map_pred, h->stats, pose_obs, poses_inout,
                        h->wt, h->keys, h->cell_head, h->cell_cnt, h->cell_first, h->cell_fill, h->cursor, P);
-    hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256, (P.C + kWarpChannels - 1) / kWarpChannels), dim3(256), 0, s, h->view,
-                       maps_last, map_pred, h->wt, P);
+    hipLaunchKernelGGL(map_warp_kernel, dim3((P.M * P.M + 255) / 256), dim3(256), 0, s, h->view, maps_last, map_pred,
+                       h->wt, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PEANUT_EHIP, std::string("peanut_map_forward: ") + hipGetErrorString(e));
     return 0;
