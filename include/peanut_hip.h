@@ -468,14 +468,17 @@ int peanut_goal_traversible(peanut_goal_t* g, const float* full_obstacle, const 
  * Synchronises the stream (the solver polls a convergence counter). */
 int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint8_t* goal_mask, int goal_r, int goal_c,
                         int fill_mode, double* dist_out, void* stream);
-/* Optional, before peanut_goal_select: "the map inputs of the next select (full_obstacle, collision_map, visited_vis) are
- * complete at this point of `stream`".  The next select then solves its traversible map and geodesic field on a stream of the
- * handle that waits for this mark only, i.e. next to whatever the caller enqueued on `stream` after the mark -- in the agent the
- * map-prediction forward that produces target_pred (Agent_State.update_state runs update_prediction then update_global_goal,
- * nav/agent/agent_state.py:240-245; the field needs the map, not the prediction).  The caller's stream joins before the weights
- * are formed: results are those of the unmarked call.  The caller must not write the three map inputs between the mark and the
- * select.  One mark serves one select. */
-int peanut_goal_mark_inputs(peanut_goal_t* g, void* stream);
+/* Optional first half of peanut_goal_select, for callers that produce target_pred AFTER the map is final -- in the agent
+ * Agent_State.update_state runs update_prediction and then update_global_goal (nav/agent/agent_state.py:240-245), and the geodesic
+ * field needs the map, not the prediction.  Call it when full_obstacle, collision_map and visited_vis are complete on `stream`
+ * (same arguments as the select that follows): the traversible map, the solver's initialisation and the first batch of relaxation
+ * rounds are enqueued on a stream of the handle behind that point of `stream`, without synchronising, so that they run beside
+ * whatever the caller enqueues on `stream` next (the prediction forward).  The peanut_goal_select that follows with the same
+ * inputs continues there and makes `stream` wait for the field before the weights are formed: results are those of a select
+ * alone.  The caller must not write the three map inputs in between.  A select with other inputs, peanut_fmm_distance or
+ * peanut_goal_reset lets the begun work run out and ignores it. */
+int peanut_goal_select_begin(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map,
+                             const uint8_t* visited_vis, const int lmb[4], int loc_r, int loc_c, void* stream);
 /* The whole of update_global_goal: traversible map, geodesic field from the agent's cell
  * (clip(loc + lmb[0/2], 0, full - 1)), weights exp(-dd / (dist_weight_temperature / map_resolution)) over the local
  * window lmb = {gx1, gx2, gy1, gy2} with the "sum < 10: keep the last weights" rule, value = target_pred * weights

@@ -125,7 +125,7 @@ SIGNATURES = {
     "peanut_goal_reset": (C.c_int, [_P]),
     "peanut_goal_rounds": (C.c_int, [_P]),
     "peanut_goal_passes": (C.c_int, [_P]),
-    "peanut_goal_mark_inputs": (C.c_int, [_P, _P]),
+    "peanut_goal_select_begin": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "peanut_goal_converged": (C.c_int, [_P]),
     "peanut_goal_traversible": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "peanut_fmm_distance": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -251,8 +251,8 @@ class Agent_State:
         self.full_map[:, self.lmb[0]:self.lmb[1], self.lmb[2]:self.lmb[3]] = self.local_map
         if goal_follows and getattr(args, "goal_overlap", True):
             # update_global_goal follows at once (update_state, :240-245): its geodesic field needs the map as it is NOW, not
-            # the prediction -- marked here, the solver runs it on its own stream next to the forward below (include/peanut_hip.h)
-            self._goal_solver().mark_inputs()
+            # the prediction -- begun here, the solver runs it on its own stream beside the forward below (include/peanut_hip.h)
+            self._goal_solver().select_begin(self.full_map[0], self.collision_map, self.visited_vis, self.lmb, (self.loc_r, self.loc_c))
         if self.full_w == args.prediction_window and self.full_h == args.prediction_window:
             object_preds = self.prediction_model.get_prediction_batch(self.full_map[None].contiguous())[0]
         else:

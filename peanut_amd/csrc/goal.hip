@@ -40,9 +40,10 @@
 // overrides -> traversible map (:382-386), exp(-d / temperature) weights with the "stuck: keep the last weights"
 // rule (:395-399), value = target_pred * weights and its first-occurrence argmax (:401-413).
 //
-// The field needs the map, not the prediction: after peanut_goal_mark_inputs the traversible map and the field of the next
-// select run on a stream of the handle, next to the forward the caller enqueued in between (Agent_State.update_state:
-// update_prediction then update_global_goal); the caller's stream joins before the weights are formed.
+// The field needs the map, not the prediction: peanut_goal_select_begin puts the traversible map, the initialisation and the first
+// batch of relaxation rounds on a stream of the handle at once; the forward the caller enqueues next (Agent_State.update_state:
+// update_prediction then update_global_goal) runs beside them, peanut_goal_select continues the solve on that stream, and the
+// caller's stream joins before the weights are formed.
 #include <math.h>
 #include <stdlib.h>
 
@@ -616,59 +617,78 @@ struct peanut_goal {
   int last_rounds = 0, last_passes = 0;
   bool last_converged = true;      // false: the ordering passes hit MAX_ORDER_PASSES with the last one still changing tiles
   int round_hint[1 + 64] = {0};    // rounds each stage needed in the previous solve (run_stage); stage 0 + up to 64 ordering passes (fmm_max_passes is clamped to 64)
-  // peanut_goal_mark_inputs: the field of the next select is solved on `side`, behind `ev_inputs` only, so that it runs next to
-  // whatever the caller enqueued on its stream after the mark (the map-prediction forward that produces target_pred)
+  // peanut_goal_select_begin: the field of the next select is solved on `side`, behind `ev_inputs` only, so that it runs next to
+  // whatever the caller enqueued on its stream after the call (the map-prediction forward that produces target_pred)
   hipStream_t side = nullptr;
   hipEvent_t ev_inputs = nullptr, ev_field = nullptr;
-  bool marked = false;
+  unsigned int* host_counters = nullptr;   // pinned: the per-round counters of a batch land here without blocking the enqueuing thread
+  // peanut_goal_select_begin: traversible map, initialisation and the first batch of stage-A rounds are already on `side`
+  struct Begun {
+    bool on = false;
+    const float* obst = nullptr;
+    const unsigned char *col = nullptr, *vis = nullptr;
+    int lmb[4] = {0, 0, 0, 0}, loc_r = 0, loc_c = 0, batch = 0, cur = 0;
+  } begun;
   ~peanut_goal() {
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
     if (ev_field) (void)hipEventDestroy(ev_field);
     if (side) (void)hipStreamDestroy(side);
+    if (host_counters) (void)hipHostFree(host_counters);
   }
 };
 
 namespace {
 
-// rounds of one stage until a round changes nothing; *total = tiles changed over the whole stage
+// `batch` relaxation rounds of a stage and the read-back of their "tiles changed" counters, enqueued (no synchronisation)
 template <bool SECOND>
-int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned long long* total, hipStream_t s) {
+int enqueue_rounds(peanut_goal* g, int* cur, int batch, hipStream_t s) {
   const int H = g->H, W = g->W, nt = g->tiles_x * g->tiles_y;
   unsigned char* act = (unsigned char*)g->active.p;
   unsigned int* counters = (unsigned int*)g->counters.p;
-  const int max_rounds = 32 * (g->tiles_x + g->tiles_y) + 64;    // generous bound on the front's path, in tiles
-  unsigned int host[MAX_ROUNDS_PER_CHECK];
-  *total = 0;
-  // The host reads the per-round "tiles changed" counters once per batch of rounds.  The first batch of a stage is as
-  // long as that stage needed in the previous solve on this handle (+2: consecutive solves of an episode see almost
-  // the same map), so that a stage normally costs ONE host synchronisation; rounds after the field has settled wake no
-  // tile and cost a few microseconds each.
-  int batch = std::min(std::max(g->round_hint[stage] + 2, 4), MAX_ROUNDS_PER_CHECK);
-  int needed = 0;
-  for (int round = 0; round < max_rounds; round += batch, batch = ROUNDS_PER_CHECK) {
-    PEANUT_HIP_CHECK(hipMemsetAsync(counters, 0, batch * sizeof(unsigned int), s));
-    for (int k = 0; k < batch; ++k) {
-      // three flag arrays in rotation: read, written (clean since the round before last), wiped for the next round
-      unsigned char* in = act + (size_t)(*cur) * nt;
-      unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
-      unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
-      const bool local32 = opt(OPT_FMM_LOCAL32) != 0, blocked = opt(OPT_FMM_BLOCKED) != 0;
+  if (!g->host_counters) PEANUT_HIP_CHECK(hipHostMalloc((void**)&g->host_counters, MAX_ROUNDS_PER_CHECK * sizeof(unsigned int), hipHostMallocDefault));
+  PEANUT_HIP_CHECK(hipMemsetAsync(counters, 0, batch * sizeof(unsigned int), s));
+  for (int k = 0; k < batch; ++k) {
+    // three flag arrays in rotation: read, written (clean since the round before last), wiped for the next round
+    unsigned char* in = act + (size_t)(*cur) * nt;
+    unsigned char* out = act + (size_t)((*cur + 1) % 3) * nt;
+    unsigned char* clr = act + (size_t)((*cur + 2) % 3) * nt;
+    const bool local32 = opt(OPT_FMM_LOCAL32) != 0, blocked = opt(OPT_FMM_BLOCKED) != 0;
 #define PEANUT_FMM_LAUNCH(KERNEL, ...)                                                                                                 \
   hipLaunchKernelGGL(KERNEL, dim3(nt), dim3(1024), 0, s, (double*)g->dist.p, (const double*)g->order.p, (const unsigned char*)g->state.p, \
                      H, W, g->tiles_x, g->tiles_y, in, out, clr, counters + k, ##__VA_ARGS__)
-      if (blocked) {
-        const int max_inner = (int)std::min<long long>(std::max<long long>(opt(OPT_FMM_INNER), 1), 1024);
-        if (local32) PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, true>), max_inner);
-        else PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, false>), max_inner);
-      } else {
-        if (local32) PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, true>));
-        else PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, false>));
-      }
-#undef PEANUT_FMM_LAUNCH
-      *cur = (*cur + 1) % 3;
+    if (blocked) {
+      const int max_inner = (int)std::min<long long>(std::max<long long>(opt(OPT_FMM_INNER), 1), 1024);
+      if (local32) PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, true>), max_inner);
+      else PEANUT_FMM_LAUNCH((fmm_round_blocked_kernel<SECOND, false>), max_inner);
+    } else {
+      if (local32) PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, true>));
+      else PEANUT_FMM_LAUNCH((fmm_round_kernel<SECOND, false>));
     }
-    PEANUT_HIP_CHECK(hipMemcpyAsync(host, counters, batch * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+#undef PEANUT_FMM_LAUNCH
+    *cur = (*cur + 1) % 3;
+  }
+  PEANUT_HIP_CHECK(hipMemcpyAsync(g->host_counters, counters, batch * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+// The host reads the per-round "tiles changed" counters once per batch of rounds.  The first batch of a stage is as long as that
+// stage needed in the previous solve on this handle (+2: consecutive solves of an episode see almost the same map), so that a
+// stage normally costs ONE host synchronisation; rounds after the field has settled wake no tile and cost a few microseconds each.
+inline int first_batch(const peanut_goal* g, int stage) { return std::min(std::max(g->round_hint[stage] + 2, 4), MAX_ROUNDS_PER_CHECK); }
+
+// rounds of one stage until a round changes nothing; *total = tiles changed over the whole stage.  enqueued > 0: the first batch
+// (that many rounds) is already on the stream (peanut_goal_select_begin)
+template <bool SECOND>
+int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned long long* total, hipStream_t s, int enqueued = 0) {
+  const int max_rounds = 32 * (g->tiles_x + g->tiles_y) + 64;    // generous bound on the front's path, in tiles
+  *total = 0;
+  int batch = enqueued > 0 ? enqueued : first_batch(g, stage);
+  int needed = 0;
+  for (int round = 0; round < max_rounds; round += batch, batch = ROUNDS_PER_CHECK) {
+    if (!(round == 0 && enqueued > 0))
+      if (int rc = enqueue_rounds<SECOND>(g, cur, batch, s)) return rc;
     PEANUT_HIP_CHECK(hipStreamSynchronize(s));
+    const unsigned int* host = g->host_counters;
     *rounds_used += batch;
     for (int k = 0; k < batch; ++k) {
       *total += host[k];
@@ -682,18 +702,33 @@ int run_stage(peanut_goal* g, int stage, int* cur, int* rounds_used, unsigned lo
   return fail(PEANUT_EHIP, "fmm: a relaxation stage did not settle within its round budget");
 }
 
-int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* seed_mask, int seed_r, int seed_c, hipStream_t s) {
+// state, distances and the seeds' tiles; leaves the seed tiles active in flag array 0
+int field_preamble(peanut_goal* g, const unsigned char* trav, const unsigned char* seed_mask, int seed_r, int seed_c, hipStream_t s) {
   const int H = g->H, W = g->W, n = H * W, nt = g->tiles_x * g->tiles_y;
   unsigned char* act = (unsigned char*)g->active.p;     // three flag arrays in rotation (run_stage)
   unsigned char* seed_tiles = act + 3 * (size_t)nt;     // fourth array: the tiles that hold seeds
   PEANUT_HIP_CHECK(hipMemsetAsync(act, 0, 4 * (size_t)nt, s));
   hipLaunchKernelGGL(fmm_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, trav, seed_mask, seed_r, seed_c, H, W,
                      (unsigned char*)g->state.p, (double*)g->dist.p, seed_tiles, g->tiles_x);
+  PEANUT_HIP_CHECK(hipMemcpyAsync(act, seed_tiles, nt, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// begun_batch > 0: the preamble and that many stage-A rounds are already on `s` (begun_cur = the flag rotation after them)
+int solve_field(peanut_goal* g, const unsigned char* trav, const unsigned char* seed_mask, int seed_r, int seed_c, hipStream_t s,
+                int begun_batch = 0, int begun_cur = 0) {
+  const int H = g->H, W = g->W, n = H * W, nt = g->tiles_x * g->tiles_y;
+  unsigned char* act = (unsigned char*)g->active.p;     // three flag arrays in rotation (run_stage)
+  unsigned char* seed_tiles = act + 3 * (size_t)nt;     // fourth array: the tiles that hold seeds
   int cur = 0, rounds = 0;
   unsigned long long changed = 0;
   // stage A: first-order field
-  PEANUT_HIP_CHECK(hipMemcpyAsync(act, seed_tiles, nt, hipMemcpyDeviceToDevice, s));
-  if (int rc = run_stage<false>(g, 0, &cur, &rounds, &changed, s)) return rc;
+  if (begun_batch > 0) {
+    cur = begun_cur;
+  } else if (int rc = field_preamble(g, trav, seed_mask, seed_r, seed_c, s)) {
+    return rc;
+  }
+  if (int rc = run_stage<false>(g, 0, &cur, &rounds, &changed, s, begun_batch)) return rc;
   // stage B: second order on the graph ordered by the previous field, until a pass changes nothing
   g->last_passes = 0;
   g->last_converged = false;
@@ -745,23 +780,53 @@ void peanut_goal_destroy(peanut_goal_t* g) { delete g; }
 int peanut_goal_reset(peanut_goal_t* g) {
   if (!g) return fail(PEANUT_EINVAL, "peanut_goal_reset: null handle");
   g->have_last = false;
+  if (g->begun.on) { (void)hipStreamSynchronize(g->side); g->begun.on = false; }
   return 0;
 }
 
-int peanut_goal_mark_inputs(peanut_goal_t* g, void* stream) {
-  if (!g) return fail(PEANUT_EINVAL, "peanut_goal_mark_inputs: null handle");
-  if (!g->side) {
-    // highest priority: the field is a chain of short launches (a ring of tiles per round) whose latency is the cost; its
-    // workgroups should take the next free CU slots ahead of the forward's large grids
-    int prio_least = 0, prio_greatest = 0;
-    PEANUT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    PEANUT_HIP_CHECK(hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, prio_greatest));
-    PEANUT_HIP_CHECK(hipEventCreateWithFlags(&g->ev_inputs, hipEventDisableTiming));
-    PEANUT_HIP_CHECK(hipEventCreateWithFlags(&g->ev_field, hipEventDisableTiming));
-  }
-  PEANUT_HIP_CHECK(hipEventRecord(g->ev_inputs, (hipStream_t)stream));
-  g->marked = true;
+namespace {
+int ensure_side(peanut_goal* g) {
+  if (g->side) return 0;
+  // highest priority: the field is a chain of short launches (a ring of tiles per round) whose latency is the cost; its
+  // workgroups should take the next free CU slots ahead of the forward's large grids
+  int prio_least = 0, prio_greatest = 0;
+  PEANUT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  PEANUT_HIP_CHECK(hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, prio_greatest));
+  PEANUT_HIP_CHECK(hipEventCreateWithFlags(&g->ev_inputs, hipEventDisableTiming));
+  PEANUT_HIP_CHECK(hipEventCreateWithFlags(&g->ev_field, hipEventDisableTiming));
   return 0;
+}
+// np.clip(loc + lmb, 0, full - 1)  (:389-390)
+void seed_cell(const peanut_goal* g, const int lmb[4], int loc_r, int loc_c, int* sr, int* sc) {
+  int r = loc_r + lmb[0], c = loc_c + lmb[2];
+  *sr = r < 0 ? 0 : (r > g->H - 1 ? g->H - 1 : r);
+  *sc = c < 0 ? 0 : (c > g->W - 1 ? g->W - 1 : c);
+}
+}  // namespace
+
+int peanut_goal_select_begin(peanut_goal_t* g, const float* full_obstacle, const uint8_t* collision_map, const uint8_t* visited_vis,
+                             const int lmb[4], int loc_r, int loc_c, void* stream) {
+  peanut::OptionScope option_scope(g ? &g->opts : nullptr);
+  if (!g || !full_obstacle || !lmb) return fail(PEANUT_EINVAL, "peanut_goal_select_begin: null argument");
+  if (lmb[0] < 0 || lmb[2] < 0 || lmb[1] > g->H || lmb[3] > g->W || lmb[1] - lmb[0] < 1 || lmb[3] - lmb[2] < 1)
+    return fail(PEANUT_EINVAL, "peanut_goal_select_begin: bad local map boundaries");
+  if (int rc = ensure_side(g)) return rc;
+  if (g->begun.on) PEANUT_HIP_CHECK(hipStreamSynchronize(g->side));      // a begin nobody finished: its rounds still own the scratch
+  PEANUT_HIP_CHECK(hipEventRecord(g->ev_inputs, (hipStream_t)stream));
+  PEANUT_HIP_CHECK(hipStreamWaitEvent(g->side, g->ev_inputs, 0));
+  if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, g->side)) return rc;
+  int sr, sc;
+  seed_cell(g, lmb, loc_r, loc_c, &sr, &sc);
+  if (int rc = field_preamble(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, g->side)) return rc;
+  int cur = 0;
+  const int batch = first_batch(g, 0);
+  if (int rc = enqueue_rounds<false>(g, &cur, batch, g->side)) return rc;
+  g->begun.on = true;
+  g->begun.obst = full_obstacle; g->begun.col = collision_map; g->begun.vis = visited_vis;
+  for (int i = 0; i < 4; ++i) g->begun.lmb[i] = lmb[i];
+  g->begun.loc_r = loc_r; g->begun.loc_c = loc_c; g->begun.batch = batch; g->begun.cur = cur;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_goal_select_begin: ") + hipGetErrorString(e));
 }
 
 int peanut_goal_rounds(peanut_goal_t* g) { return g ? g->last_rounds : PEANUT_EINVAL; }
@@ -775,6 +840,7 @@ int peanut_fmm_distance(peanut_goal_t* g, const uint8_t* traversible, const uint
   if (!goal_mask && (goal_r < 0 || goal_r >= g->H || goal_c < 0 || goal_c >= g->W))
     return fail(PEANUT_EINVAL, "peanut_fmm_distance: goal cell outside the map");
   hipStream_t s = (hipStream_t)stream;
+  if (g->begun.on) { PEANUT_HIP_CHECK(hipStreamSynchronize(g->side)); g->begun.on = false; }      // (an unfinished select_begin owns the scratch)
   if (int rc = solve_field(g, traversible, goal_mask, goal_mask && goal_r < 0 ? -1 : goal_r, goal_c, s)) return rc;
   const int n = g->H * g->W;
   if (fill_mode == 0) {
@@ -813,21 +879,26 @@ int peanut_goal_select(peanut_goal_t* g, const float* full_obstacle, const uint8
   const int mode = dist_weight_temperature == -1 ? 1 : (dist_weight_temperature == 0 ? 2 : 0);
   if (mode != 2 && !target_pred) return fail(PEANUT_EINVAL, "peanut_goal_select: target_pred is needed unless dist_weight_temperature == 0");
   hipStream_t s = (hipStream_t)stream;
-  // the field needs the map inputs only: after peanut_goal_mark_inputs it is solved on the handle's own stream, behind the mark,
-  // next to what the caller enqueued on `s` since (the forward that produces target_pred); `s` joins before the weights
-  const bool aside = g->marked;
-  g->marked = false;
-  hipStream_t fs = aside ? g->side : s;
-  if (aside) PEANUT_HIP_CHECK(hipStreamWaitEvent(fs, g->ev_inputs, 0));
-  if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, fs)) return rc;
-  // np.clip(loc + lmb, 0, full - 1)  (:389-390)
-  int sr = loc_r + gx1, sc = loc_c + gy1;
-  sr = sr < 0 ? 0 : (sr > g->H - 1 ? g->H - 1 : sr);
-  sc = sc < 0 ? 0 : (sc > g->W - 1 ? g->W - 1 : sc);
-  if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, fs)) return rc;
+  int sr, sc;
+  seed_cell(g, lmb, loc_r, loc_c, &sr, &sc);
+  // the field needs the map inputs only: after peanut_goal_select_begin with these very inputs its traversible map, its
+  // initialisation and the first batch of stage-A rounds are already running on the handle's own stream, next to what the caller
+  // enqueued on `s` since (the forward that produces target_pred); the rest follows there and `s` joins before the weights
+  bool aside = false;
+  if (g->begun.on) {
+    const peanut_goal::Begun& b = g->begun;
+    aside = b.obst == full_obstacle && b.col == collision_map && b.vis == visited_vis && b.lmb[0] == gx1 && b.lmb[1] == gx2 &&
+            b.lmb[2] == gy1 && b.lmb[3] == gy2 && b.loc_r == loc_r && b.loc_c == loc_c;
+    g->begun.on = false;
+    if (!aside) PEANUT_HIP_CHECK(hipStreamSynchronize(g->side));      // begun for other inputs: let it run out, solve these
+  }
   if (aside) {
-    PEANUT_HIP_CHECK(hipEventRecord(g->ev_field, fs));
+    if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, g->side, g->begun.batch, g->begun.cur)) return rc;
+    PEANUT_HIP_CHECK(hipEventRecord(g->ev_field, g->side));
     PEANUT_HIP_CHECK(hipStreamWaitEvent(s, g->ev_field, 0));
+  } else {
+    if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, stream)) return rc;
+    if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, s)) return rc;
   }
   if (g->have_last && (g->last_lw != lw || g->last_lh != lh)) g->have_last = false;
   const int n = lw * lh;

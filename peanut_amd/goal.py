@@ -64,14 +64,20 @@ class GeodesicSolver:
     def reset(self):
         _lib.check(self._lib.peanut_goal_reset(self._h), "peanut_goal_reset")
 
-    def mark_inputs(self):
-        """``peanut_goal_mark_inputs`` on the current stream: the map inputs of the next ``select`` are complete HERE, so its
-        geodesic field may run next to what is enqueued after this call (the prediction forward that produces ``target_pred``).
-        ``select`` falls back to the ordinary in-stream solve when it had to convert an input (the converted copy is younger
-        than the mark)."""
+    def select_begin(self, full_obstacle, collision_map, visited_vis, lmb, loc_rc):
+        """``peanut_goal_select_begin`` on the current stream: the map inputs of the ``select`` that follows are complete HERE; its
+        traversible map, initialisation and first relaxation rounds start now, on the solver's own stream, beside what is
+        enqueued after this call (the prediction forward that produces ``target_pred``).  The converted inputs are kept so that
+        ``select`` hands the library the same buffers."""
+        obst = full_obstacle.to(self.device, torch.float32).contiguous()
+        col, vis = _u8(collision_map, self.device), _u8(visited_vis, self.device)
+        bounds = (C.c_int * 4)(*[int(v) for v in lmb])
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.peanut_goal_mark_inputs(self._h, _lib.current_stream_ptr(self.device)), "peanut_goal_mark_inputs")
-        self._marked = True
+            rc = self._lib.peanut_goal_select_begin(self._h, obst.data_ptr(), None if col is None else col.data_ptr(),
+                                                    None if vis is None else vis.data_ptr(), C.byref(bounds), int(loc_rc[0]), int(loc_rc[1]),
+                                                    _lib.current_stream_ptr(self.device))
+        _lib.check(rc, "peanut_goal_select_begin")
+        self._begun = ((full_obstacle, collision_map, visited_vis), (obst, col, vis))
 
     def traversible(self, full_obstacle: torch.Tensor, collision_map=None, visited_vis=None) -> torch.Tensor:
         """agent_state.py:382-386 -> uint8 [H,W] (1 = traversible)."""
@@ -116,13 +122,9 @@ class GeodesicSolver:
         obst = full_obstacle.to(self.device, torch.float32).contiguous()
         col, vis = _u8(collision_map, self.device), _u8(visited_vis, self.device)
         tp = None if target_pred is None else target_pred.to(self.device, torch.float32).contiguous()
-        if getattr(self, "_marked", False):
-            self._marked = False
-            same = all(a is None or (isinstance(b, torch.Tensor) and a.data_ptr() == b.data_ptr())
-                       for a, b in ((obst, full_obstacle), (col, collision_map), (vis, visited_vis)))
-            if not same:        # an input was converted after the mark: mark again, here (no overlap, same result)
-                self.mark_inputs()
-                self._marked = False
+        begun, self._begun = getattr(self, "_begun", None), None
+        if begun is not None and all(a is b for a, b in zip(begun[0], (full_obstacle, collision_map, visited_vis))):
+            obst, col, vis = begun[1]          # the buffers select_begin handed over (a converted input is converted once)
         lw, lh = int(lmb[1] - lmb[0]), int(lmb[3] - lmb[2])
         if tp is not None and tuple(tp.shape) != (lw, lh):
             raise ValueError(f"target_pred must be [{lw},{lh}], got {tuple(tp.shape)}")

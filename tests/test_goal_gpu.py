@@ -284,9 +284,9 @@ def test_ordering_pass_cap_is_reported_and_its_effect_is_bounded(shape, seed):
 
 
 def test_field_solved_next_to_the_prediction_forward_is_the_same_field():
-    """peanut_goal_mark_inputs (round 5): the field of a marked select runs on the handle's own stream, next to the work the
-    caller enqueued after the mark (here a chain of large matrix products that ends in target_pred).  Same field, bit for bit, same
-    goal, as the unmarked call; an input converted after the mark falls back to the in-stream solve."""
+    """peanut_goal_select_begin (round 5): the field of a begun select runs on the handle's own stream, beside the work the
+    caller enqueued after the begin (here a chain of large matrix products that ends in target_pred).  Same field, bit for bit,
+    same goal, as the select alone; a select whose inputs differ from the begun ones ignores the begun work and solves its own."""
     from peanut_amd.goal import GeodesicSolver
     H = W = 480
     trav = _maze(H, W, 7)
@@ -311,15 +311,26 @@ def test_field_solved_next_to_the_prediction_forward_is_the_same_field():
     sol2 = GeodesicSolver(H, W, 1)
     for rep in range(3):             # (also with the round hints of a previous solve in place)
         sol2.reset()
-        sol2.mark_inputs()
+        sol2.select_begin(obst, col, vis, lmb, loc)
         got = sol2.select(obst, col, vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True, want_value=True)
         assert got["goal"] == ref["goal"] and abs(got["wt_sum"] - ref["wt_sum"]) <= 1e-9 * ref["wt_sum"] and got["rounds"] >= 1      # (the sum is an atomic accumulation: last digits vary)
         assert torch.equal(got["dist"], ref["dist"]) and torch.equal(got["value"], ref["value"])
-    # an input that select has to convert (bool -> uint8) is younger than the mark: in-stream solve, same answer
+    # an input that has to be converted (bool -> uint8) is converted once, at the begin, and the select reuses the buffer
     sol2.reset()
-    sol2.mark_inputs()
-    got = sol2.select(obst, col.bool(), vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True)
+    cb = col.bool()
+    sol2.select_begin(obst, cb, vis, lmb, loc)
+    got = sol2.select(obst, cb, vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True)
     assert got["goal"] == ref["goal"] and torch.equal(got["dist"], ref["dist"])
+    # a select for another agent cell than the one begun: the begun work is dropped, the answer is that of a select alone
+    other = (loc[0] + 7, loc[1] + 3)
+    alone = sol.select(obst, col, vis, lmb, other, produce_target(), 500.0, 5, want_dist=True)
+    sol2.select_begin(obst, col, vis, lmb, loc)
+    got = sol2.select(obst, col, vis, lmb, other, produce_target(), 500.0, 5, want_dist=True)
+    assert got["goal"] == alone["goal"] and torch.equal(got["dist"], alone["dist"])
+    # ... and a begin that no select follows does not disturb a distance transform on the same handle
+    sol2.select_begin(obst, col, vis, lmb, loc)
+    t_u8 = torch.from_numpy(trav).cuda()
+    assert torch.equal(sol2.distance(t_u8, goal=(130, 140)), sol.distance(t_u8, goal=(130, 140)))
 
 
 def test_update_state_with_and_without_the_overlapped_field_agree():

@@ -44,7 +44,7 @@ def synth_episode(seed, n_frames, dev):
 
 def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, dev=None, rank=0, world=1, goal_overlap=True):
     """The timed loop; returns the result dict on every rank (rank 0's is the one to print).  goal_overlap (the agent's default):
-    the geodesic field of the goal selection runs next to the prediction forward (peanut_goal_mark_inputs); False: one after the
+    the geodesic field of the goal selection runs next to the prediction forward (peanut_goal_select_begin); False: one after the
     other, and the goal selection is timed on its own (one extra device synchronisation per prediction step)."""
     dev = dev or torch.device("cuda", torch.cuda.current_device())
     from peanut_amd.agent_state import default_args   # nav/arguments.py defaults

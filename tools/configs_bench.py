@@ -372,7 +372,7 @@ def config4(dev, c3=None, mapping=None, cpu_legs=None):
                               "frac": round((front_ms * front_frac + back_ms * back_frac) / max(front_ms + back_ms, 1e-9), 4)}
     if mapping is not None:
         stages["mapping"] = {"ms": mapping["ms_per_step"], "frac": mapping["roofline"]["frac"]}
-    # goal selection: its geodesic field runs NEXT TO the prediction forward (peanut_goal_mark_inputs), so what it adds to a step is
+    # goal selection: its geodesic field runs NEXT TO the prediction forward (peanut_goal_select_begin), so what it adds to a step is
     # the pair's device time minus the forward alone; the serial cost per call comes from a second, short run with the overlap off
     serial = bp.run_pipeline(episodes=1, frames=40, precision="fp32", detector=False, goal=True, dev=dev, goal_overlap=False)
     pair = out.get("prediction_plus_goal_ms_per_call")
