@@ -53,6 +53,17 @@ struct RpnLevels {
   int A;
 };
 
+// The per-level top-k in slices (round 5): a level's objectness logits are cut into up to 8 ranges, every range selects its own
+// k largest (one workgroup each: the finest level of an 800 x 1067 frame is 160 000 logits, and ONE workgroup making its four
+// passes over them was 115 us, the longest kernel of the back half at batch 1), and rpn_rank_select_kernel takes the k largest of
+// a level's <= 8 k candidates by counting -- which also leaves them in score order.
+constexpr int kMaxSlices = 32, kMaxSlicesPerLevel = 8;
+struct RpnSlices {
+  int n_items, ctot;                                     // workgroups per image; candidates per image
+  int lvl[kMaxSlices], start[kMaxSlices], cnt[kMaxSlices], ks[kMaxSlices], coff[kMaxSlices];
+  int lvl_coff[kLevels], lvl_cnt[kLevels];               // a level's candidates: offset and number
+};
+
 // bitonic sort (descending) of n = power of two 64-bit keys in LDS, any thread count that divides n / 2 evenly
 __device__ __forceinline__ void bitonic_desc(unsigned long long* s, int n) {
   for (int size = 2; size <= n; size <<= 1)
@@ -96,11 +107,16 @@ __device__ __forceinline__ void find_bin(const int* hist, int nbins, int need, i
 }
 
 // ---- per (level, image): the k largest objectness logits, sorted descending (ties: lower index first) ----
-__global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int Ktot, int* __restrict__ sel_idx,
-                                                        float* __restrict__ sel_score) {
-  const int l = blockIdx.x, b = blockIdx.y;
-  const int n = lv.n[l], k = lv.k[l];
-  const float* x = lv.obj[l] + (size_t)b * n;
+// SLICED: workgroup blockIdx.x takes range sl.start/cnt of level sl.lvl and writes its sl.ks largest as 64-bit keys (score | index
+// within the level), unordered, to cand[b][sl.coff ...]; else: one workgroup per level, the k largest sorted into sel_idx / sel_score
+template <bool SLICED>
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, const RpnSlices sl, int Ktot, int* __restrict__ sel_idx,
+                                                        float* __restrict__ sel_score, unsigned long long* __restrict__ cand) {
+  const int b = blockIdx.y;
+  const int l = SLICED ? sl.lvl[blockIdx.x] : (int)blockIdx.x;
+  const int first = SLICED ? sl.start[blockIdx.x] : 0;
+  const int n = SLICED ? sl.cnt[blockIdx.x] : lv.n[l], k = SLICED ? sl.ks[blockIdx.x] : lv.k[l];
+  const float* x = lv.obj[l] + (size_t)b * lv.n[l] + first;
   __shared__ int hist[2048];
   __shared__ int part[64];
   __shared__ int res[2];
@@ -153,14 +169,14 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int 
         const int i = i0 + u * 1024;
         if (i >= n) break;
         const unsigned key = ord_key(v[u]);
-        if (key >= thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+        if (key >= thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)(first + i));
       }
     }
   } else {                          // ties across the cut: the first `need` of them by index (ordered chunks)
     for (int i0 = 0; i0 < n; i0 += 1024) {
       const int i = i0 + tid;
       const unsigned key = i < n ? ord_key(x[i]) : 0u;
-      if (i < n && key > thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+      if (i < n && key > thr) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)(first + i));
       const bool eq = i < n && key == thr;
       const unsigned long long bal = __ballot(eq);
       const int lane = tid & 63, wv = tid >> 6;
@@ -169,11 +185,16 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int 
       int before = taken_eq;
       for (int q = 0; q < wv; ++q) before += wave_cnt[q];
       before += __popcll(bal & ((1ull << lane) - 1ull));
-      if (eq && before < need) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
+      if (eq && before < need) sbuf[atomicAdd(&cnt, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)(first + i));
       __syncthreads();
       if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wave_cnt[q]; taken_eq += t; }
       __syncthreads();
     }
+  }
+  if (SLICED) {
+    __syncthreads();
+    if (tid < k) cand[(size_t)b * sl.ctot + sl.coff[blockIdx.x] + tid] = sbuf[tid];
+    return;
   }
   bitonic_desc(sbuf, 1024);
   if (tid < k) {
@@ -181,6 +202,47 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(const RpnLevels lv, int 
     const size_t o = (size_t)b * Ktot + lv.koff[l] + tid;
     sel_idx[o] = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
     sel_score[o] = ord_key_inv((unsigned)(e >> 32));
+  }
+}
+
+// the k largest of a level's candidates, in descending order, by counting (keys are distinct: the index is part of the key);
+// grid (ceil(max candidates / 64), levels, B), 512 threads as in rank_sort_keys_kernel below
+__global__ __launch_bounds__(512) void rpn_rank_select_kernel(const RpnLevels lv, const RpnSlices sl, int Ktot,
+                                                              const unsigned long long* __restrict__ cand, int* __restrict__ sel_idx,
+                                                              float* __restrict__ sel_score) {
+  constexpr int NW = 8;
+  __shared__ __attribute__((aligned(16))) unsigned long long sk[kMaxSlicesPerLevel * 1024];
+  __shared__ int part[NW][64];
+  const int l = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = sl.lvl_cnt[l];
+  if ((int)blockIdx.x * 64 >= C) return;
+  const unsigned long long* g = cand + (size_t)b * sl.ctot + sl.lvl_coff[l];
+  for (int i = tid; i < C; i += 64 * NW) sk[i] = g[i];
+  __syncthreads();
+  const int mine_i = blockIdx.x * 64 + lane;
+  const unsigned long long mine = mine_i < C ? sk[mine_i] : 0ull;
+  const int per = ((C + NW - 1) / NW + 1) & ~1, j0 = min(C, wave * per), j1 = min(C, j0 + per);
+  int larger = 0, j = j0;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  for (; j + 16 <= j1; j += 16) {
+    u64x2 kk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kk[u] = *reinterpret_cast<const u64x2*>(&sk[j + 2 * u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) larger += (kk[u][0] > mine) + (kk[u][1] > mine);
+  }
+  for (; j < j1; ++j) larger += sk[j] > mine;
+  part[wave][lane] = larger;
+  __syncthreads();
+  if (wave == 0 && mine_i < C) {
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r += part[w][lane];
+    if (r < lv.k[l]) {
+      const size_t o = (size_t)b * Ktot + lv.koff[l] + r;
+      sel_idx[o] = (int)(0xffffffffu - (unsigned)(mine & 0xffffffffull));
+      sel_score[o] = ord_key_inv((unsigned)(mine >> 32));
+    }
   }
 }
 
@@ -245,6 +307,57 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(unsigned long long* __r
   }
   if (threadIdx.x == 0 && sk[0] == 0ull) nvalid[blockIdx.x] = 0;
 }
+// The same ordering by counting (round 5): the keys are distinct (a candidate's position is part of its key) except for
+// 0 = invalid, so a key's place in the descending order is the number of larger keys.  A bitonic sort of 8 192 keys is 91
+// barrier-separated passes of ONE workgroup (65 us, whatever the batch); here every key counts the larger ones among the n_live
+// real entries on its own: a workgroup takes 64 keys, its eight waves an eighth of the comparisons each (a wave reads one LDS
+// word per step, the same for all lanes), n_live / 64 workgroups per image.  Out of place (every workgroup reads all keys).
+__global__ __launch_bounds__(512) void rank_sort_keys_kernel(const unsigned long long* __restrict__ keys, int Kpad, int n_live,
+                                                             unsigned long long* __restrict__ sorted, int* __restrict__ nvalid) {
+  constexpr int NW = 8;                      // waves = slices of the comparison range
+  __shared__ __attribute__((aligned(16))) unsigned long long sk[8192];
+  __shared__ int part[NW][64];
+  __shared__ int nz[NW];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long* g = keys + (size_t)b * Kpad;
+  int nonzero = 0;
+  for (int i = tid; i < n_live; i += 64 * NW) {
+    const unsigned long long v = g[i];
+    sk[i] = v;
+    nonzero += v != 0ull;
+  }
+  for (int o = 32; o > 0; o >>= 1) nonzero += __shfl_xor(nonzero, o);
+  if (lane == 0) nz[wave] = nonzero;
+  __syncthreads();
+  const int mine_i = blockIdx.x * 64 + lane;
+  const unsigned long long mine = mine_i < n_live ? sk[mine_i] : 0ull;
+  const int per = ((n_live + NW - 1) / NW + 1) & ~1, j0 = min(n_live, wave * per), j1 = min(n_live, j0 + per);     // even starts: 16-byte reads
+  int larger = 0;
+  int j = j0;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  for (; j + 16 <= j1; j += 16) {     // sixteen keys in flight (one read and its wait per step left the loop at ~120 cycles a key)
+    u64x2 k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) k[u] = *reinterpret_cast<const u64x2*>(&sk[j + 2 * u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) larger += (k[u][0] > mine) + (k[u][1] > mine);
+  }
+  for (; j < j1; ++j) larger += sk[j] > mine;
+  part[wave][lane] = larger;
+  __syncthreads();
+  if (wave == 0 && mine != 0ull) {
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r += part[w][lane];
+    sorted[(size_t)b * Kpad + r] = mine;
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    int t = 0;
+    for (int w = 0; w < NW; ++w) t += nz[w];
+    nvalid[b] = t;
+  }
+}
+
 // the same for the first count[b] keys of each segment (all non-zero): sorts the next power of two, at least 64
 template <int KMAX>
 __global__ __launch_bounds__(1024) void sort_keys_counted_kernel(unsigned long long* __restrict__ keys, const int* __restrict__ count,
@@ -377,9 +490,11 @@ __global__ __launch_bounds__(1024) void nms_scan_dev_kernel(const unsigned long 
     if (wave == 0) {
       unsigned long long alive = ~removed[b];
       if (b == nwords - 1 && (n & 63)) alive &= (1ull << (n & 63)) - 1;
-      for (int l = 0; l < 64; ++l) {
-        const unsigned long long d = readlane64(diag_cur, l);
-        if ((alive >> l) & 1ull) alive &= ~d;
+      // walk the boxes that are still alive (not all 64 lanes): the next one survives and strikes what it suppresses
+      for (unsigned long long todo = alive; todo != 0ull;) {
+        const int l = __builtin_ctzll(todo);
+        alive &= ~readlane64(diag_cur, l);
+        todo = alive & ~((2ull << l) - 1ull);
       }
       int done = 0;
       if (kept + __builtin_popcountll(alive) >= max_keep) {   // keep the first max_keep - kept of them
@@ -694,7 +809,7 @@ using namespace peanut;
 
 struct peanut_rcnn::PostBufs {
   DevBuf pyr[5], obj_all, dl_all;   // objectness / deltas of the five levels in ONE buffer each, level after level (the fused RPN chain needs that)
-  DevBuf sel_idx, sel_score, cbox, ckey, ccat, sbox, scat, sscore, keep, nms_ws, nvalid;
+  DevBuf sel_idx, sel_score, cand, cbox, ckey, ckey_sorted, ccat, sbox, scat, sscore, keep, nms_ws, nvalid;
   DevBuf rois, roi_level, roi_logit, prop_count;
   DevBuf x7, f1, f2, cls, bbox;
   DevBuf dbox, dkey, dcat, dsbox, dscat, dsscore, dkeep, dnvalid, dkeys;
@@ -883,7 +998,7 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   }
   const int words = (Ktot + 63) / 64, dwords = (Kc + 63) / 64;
   if ((rc = pb.sel_idx.ensure((size_t)B * Ktot * 4)) || (rc = pb.sel_score.ensure((size_t)B * Ktot * 4)) ||
-      (rc = pb.cbox.ensure((size_t)B * Ktot * 16)) || (rc = pb.ckey.ensure((size_t)B * Kpad * 8)) || (rc = pb.ccat.ensure((size_t)B * Ktot * 4)) ||
+      (rc = pb.cbox.ensure((size_t)B * Ktot * 16)) || (rc = pb.ckey.ensure((size_t)B * Kpad * 8)) || (rc = pb.ckey_sorted.ensure((size_t)B * Kpad * 8)) || (rc = pb.ccat.ensure((size_t)B * Ktot * 4)) ||
       (rc = pb.sbox.ensure((size_t)B * Ktot * 16)) || (rc = pb.scat.ensure((size_t)B * Ktot * 4)) || (rc = pb.sscore.ensure((size_t)B * Ktot * 4)) ||
       (rc = pb.keep.ensure((size_t)B * Ktot)) || (rc = pb.nvalid.ensure((size_t)B * 4)) ||
       (rc = pb.nms_ws.ensure(std::max((size_t)B * Ktot * words, (size_t)B * Kc * dwords) * 8)) ||
@@ -943,12 +1058,50 @@ static int rcnn_inference_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, 
   }
   mark();
   // ---- RPN: per-level top-k, decode, per-image sort, NMS (per level), post-NMS top-k ----
-  hipLaunchKernelGGL(rpn_topk_kernel, dim3(kLevels, B), dim3(1024), 0, s, lv, Ktot, (int*)pb.sel_idx.p, (float*)pb.sel_score.p);
+  {
+    RpnSlices sl{};
+    const int target = (int)std::max<long long>(opt(OPT_RCNN_TOPK_SLICE), 0);      // logits per workgroup; 0: one workgroup per level
+    int max_c = 0;
+    if (target > 0 && c.rpn_pre_nms_topk <= 1024) {
+      for (int l = 0; l < kLevels; ++l) {
+        const int room = kMaxSlices - sl.n_items - (kLevels - 1 - l);      // every later level needs at least one workgroup
+        const int ns = std::min(std::min(kMaxSlicesPerLevel, room), std::max(1, (lv.n[l] + target - 1) / target));
+        const int per = (lv.n[l] + ns - 1) / ns;
+        sl.lvl_coff[l] = sl.ctot;
+        for (int q = 0; q < ns; ++q) {
+          const int st = q * per, cn = std::min(per, lv.n[l] - st);
+          if (cn <= 0) break;
+          const int it = sl.n_items++;
+          sl.lvl[it] = l; sl.start[it] = st; sl.cnt[it] = cn; sl.ks[it] = std::min(cn, lv.k[l]); sl.coff[it] = sl.ctot;
+          sl.ctot += sl.ks[it];
+        }
+        sl.lvl_cnt[l] = sl.ctot - sl.lvl_coff[l];
+        max_c = std::max(max_c, sl.lvl_cnt[l]);
+      }
+    }
+    if (sl.n_items > 0) {
+      if ((rc = pb.cand.ensure((size_t)B * sl.ctot * 8))) return rc;
+      hipLaunchKernelGGL(rpn_topk_kernel<true>, dim3(sl.n_items, B), dim3(1024), 0, s, lv, sl, Ktot, (int*)pb.sel_idx.p, (float*)pb.sel_score.p,
+                         (unsigned long long*)pb.cand.p);
+      hipLaunchKernelGGL(rpn_rank_select_kernel, dim3((max_c + 63) / 64, kLevels, B), dim3(512), 0, s, lv, sl, Ktot,
+                         (const unsigned long long*)pb.cand.p, (int*)pb.sel_idx.p, (float*)pb.sel_score.p);
+    } else {
+      hipLaunchKernelGGL(rpn_topk_kernel<false>, dim3(kLevels, B), dim3(1024), 0, s, lv, sl, Ktot, (int*)pb.sel_idx.p, (float*)pb.sel_score.p,
+                         (unsigned long long*)nullptr);
+    }
+  }
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(blocks_for((long long)B * Kpad)), dim3(256), 0, s, lv, B, Ktot, Kpad, (const int*)pb.sel_idx.p,
                      (const float*)pb.sel_score.p, (float)nh, (float)nw, c.rpn_bbox_weights[0], c.rpn_bbox_weights[1], c.rpn_bbox_weights[2],
                      c.rpn_bbox_weights[3], (float*)pb.cbox.p, (unsigned long long*)pb.ckey.p, (int*)pb.ccat.p);
-  if ((rc = launch_sort_keys((unsigned long long*)pb.ckey.p, Kpad, B, (int*)pb.nvalid.p, s))) return rc;
-  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Ktot)), dim3(256), 0, s, (const unsigned long long*)pb.ckey.p,
+  const unsigned long long* sorted_keys = (const unsigned long long*)pb.ckey.p;
+  if (opt(OPT_RCNN_RANK_SORT) != 0 && Ktot <= 8192) {
+    hipLaunchKernelGGL(rank_sort_keys_kernel, dim3((Ktot + 63) / 64, B), dim3(512), 0, s, (const unsigned long long*)pb.ckey.p, Kpad, Ktot,
+                       (unsigned long long*)pb.ckey_sorted.p, (int*)pb.nvalid.p);
+    sorted_keys = (const unsigned long long*)pb.ckey_sorted.p;
+  } else if ((rc = launch_sort_keys((unsigned long long*)pb.ckey.p, Kpad, B, (int*)pb.nvalid.p, s))) {
+    return rc;
+  }
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for((long long)B * Ktot)), dim3(256), 0, s, sorted_keys,
                      (const int*)pb.nvalid.p, Kpad, Ktot, B, (const float*)pb.cbox.p, (const int*)pb.ccat.p, (float*)pb.sbox.p, (int*)pb.scat.p, (float*)pb.sscore.p);
   hipLaunchKernelGGL(nms_mask_dev_kernel, dim3(words, words, B), dim3(64), 0, s, (const float*)pb.sbox.p, (const int*)pb.scat.p, Ktot, words,
                      (const int*)pb.nvalid.p, c.rpn_nms_thresh, (unsigned long long*)pb.nms_ws.p);

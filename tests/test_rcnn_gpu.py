@@ -265,6 +265,53 @@ def test_rpn_head_fused_over_the_levels_equals_the_level_by_level_form(small_net
     del fused, plain
 
 
+def test_candidate_order_by_counting_equals_the_bitonic_sort(small_net):
+    """Round 5: the RPN candidates of an image are put in score order by counting the larger keys (option rcnn_rank_sort) instead of
+    one workgroup's bitonic sort.  The keys are distinct, so the order -- and with it every later stage -- is the same: bit-identical
+    detections and semantic map."""
+    from peanut_amd import _lib
+    from peanut_amd.rcnn import MaskRCNN
+    s = small_net
+    img = s["img"].cuda()
+    with _lib.default_options(rcnn_rank_sort=1):
+        a = MaskRCNN(s["cfg"], s["sd"])
+    with _lib.default_options(rcnn_rank_sort=0):
+        b = MaskRCNN(s["cfg"], s["sd"])
+    ra, rb = a.inference(img), b.inference(img)
+    assert len(ra) == len(rb) == 2 and all(len(x["scores"]) > 0 for x in ra)
+    for x, y in zip(ra, rb):
+        for k in ("scores", "pred_boxes", "pred_classes", "pred_masks"):
+            assert torch.equal(x[k], y[k]), k
+    assert torch.equal(a.semantic(img, s["cfg"].num_classes, 0.5, 0.5, None), b.semantic(img, s["cfg"].num_classes, 0.5, 0.5, None))
+    del a, b
+
+
+@pytest.mark.parametrize("slice_len", [300, 20480])
+def test_sliced_top_k_equals_the_one_workgroup_form(small_net, slice_len):
+    """Round 5: a pyramid level's objectness logits are cut into up to eight ranges, each range selects its k largest, and the k
+    largest of a level's candidates are picked (and ordered) by counting (option rcnn_topk_slice = logits per workgroup; 300 cuts
+    the small test net's levels into several ranges, with more logits than k in some and fewer in others).  The selected anchors,
+    their order and everything downstream are bit-identical to the one-workgroup-per-level form (rcnn_topk_slice = 0)."""
+    from peanut_amd import _lib
+    from peanut_amd.rcnn import MaskRCNN
+    s = small_net
+    img = s["img"].cuda()
+    with _lib.default_options(rcnn_topk_slice=slice_len):
+        a = MaskRCNN(s["cfg"], s["sd"])
+    with _lib.default_options(rcnn_topk_slice=0):
+        b = MaskRCNN(s["cfg"], s["sd"])
+    ra, rb = a.inference(img), b.inference(img)
+    assert len(ra) == len(rb) == 2 and all(len(x["scores"]) > 0 for x in ra)
+    for x, y in zip(ra, rb):
+        for k in ("scores", "pred_boxes", "pred_classes", "pred_masks"):
+            assert torch.equal(x[k], y[k]), k
+    cap, B = s["cfg"].rpn_post_nms_topk, img.shape[0]
+    assert torch.equal(a.debug_stage("prop_count", (B,), torch.int32), b.debug_stage("prop_count", (B,), torch.int32))
+    n0 = int(a.debug_stage("prop_count", (B,), torch.int32)[0])
+    assert n0 > 0 and torch.equal(a.debug_stage("rois", (B * cap, 5))[:n0], b.debug_stage("rois", (B * cap, 5))[:n0])      # the proposals, in order
+    del a, b
+
+
 def test_fpn_output_convs_on_the_side_stream_change_nothing(small_net):
     """Round 5: the 3x3 output convs of p5, p4, p3 run on the handle's side stream next to the lateral / top-down chain that ends
     in p2's output conv (option rcnn_fpn_overlap).  Same kernels on the same data, only the schedule differs: detections, the

@@ -5,12 +5,13 @@ from peanut_amd import _lib
 from peanut_amd.rcnn import MaskRCNN
 from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
 key = sys.argv[1]
+on_value = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
 rcfg = RcnnCfg(score_thresh_test=0.5)
 sd = make_seeded_rcnn_state_dict(rcfg, 0)
 nets = {}
 for v in (1, 0):
-    with _lib.default_options(**{key: v}):
+    with _lib.default_options(**{key: (on_value if v else 0)}):
         nets[v] = MaskRCNN(rcfg, sd, device=dev)
 g = torch.Generator().manual_seed(3)
 img = torch.randint(0, 256, (1, 480, 640, 3), generator=g, dtype=torch.uint8).to(dev)
