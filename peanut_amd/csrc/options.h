@@ -23,7 +23,7 @@ enum OptionId {
   OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_PW_BN64_MAXK, OPT_PW64_MAXTILES, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
-  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_PPM_GROUP_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_RCNN_RPN_FUSED, OPT_RCNN_FPN_OVERLAP, OPT_RCNN_RANK_SORT, OPT_RCNN_TOPK_SLICE, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES, OPT_FMM_BLOCKED, OPT_FMM_INNER,
+  OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_PPM_GROUP_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_RCNN_RPN_FUSED, OPT_RCNN_FPN_OVERLAP, OPT_RCNN_RANK_SORT, OPT_RCNN_TOPK_SLICE, OPT_RCNN_NMS_LEVELS, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES, OPT_FMM_BLOCKED, OPT_FMM_INNER,
   OPT_COUNT
 };
 
@@ -86,6 +86,7 @@ inline const OptionInfo* option_table() {
       {"rcnn_fpn_overlap", 0, false, "detector: the FPN output convs of p5, p4, p3 on a side stream next to the lateral / top-down chain that ends in p2's (round 5 experiment, bit-identical; measured SLOWER at batch 1, 5.70 against 5.61 ms per frame, profiles/r8: off); read when a (B, H, W) plan is built"},
       {"rcnn_rank_sort", 1, false, "detector: the RPN candidates of an image are ordered by counting the larger keys (n / 64 workgroups) instead of one workgroup's bitonic sort (round 5; same order: the keys are distinct)"},
       {"rcnn_topk_slice", 20480, false, "detector: objectness logits per workgroup of the per-level top-k (a level is cut into up to 8 ranges whose k largest are merged by counting; 0: one workgroup per level, round 4)"},
+      {"rcnn_nms_levels", 1, false, "detector: the proposal NMS level by level (five 16 x 16-word suppression blocks and five scans per image side by side, post-NMS top-k by counting) instead of one score-sorted list per image (round 5; same proposals)"},
       {"fmm_local32", 1, false, "goal solver: single-precision local solve inside a tile"},
       {"fmm_max_passes", 24, false, "goal solver: hard ceiling of the second-order ordering passes; they stop as soon as a pass changes nothing (6-10 passes on the agent's 960 x 960 map; peanut_goal_converged reports whether they reached their fixed point)"},
       {"fmm_blocked", 1, false, "goal solver: a wave relaxes its 8 x 8 block of the tile to convergence between workgroup barriers (round 5; 0: one Jacobi sweep of the whole tile per barrier pair)"},

@@ -312,6 +312,32 @@ def test_sliced_top_k_equals_the_one_workgroup_form(small_net, slice_len):
     del a, b
 
 
+def test_level_wise_nms_equals_the_score_sorted_list(small_net):
+    """Round 5: the proposal NMS runs level by level -- batched_nms never compares boxes of different pyramid levels, and the
+    per-level top-k leaves each level's candidates in score order -- with the post-NMS top-k taken by counting (option
+    rcnn_nms_levels).  Against the round-4 form (one score-sorted list per image, one suppression matrix, one scan): the same
+    proposals in the same order, bit for bit, and identical detections."""
+    from peanut_amd import _lib
+    from peanut_amd.rcnn import MaskRCNN
+    s = small_net
+    img = s["img"].cuda()
+    with _lib.default_options(rcnn_nms_levels=1):
+        a = MaskRCNN(s["cfg"], s["sd"])
+    with _lib.default_options(rcnn_nms_levels=0):
+        b = MaskRCNN(s["cfg"], s["sd"])
+    cap, B = s["cfg"].rpn_post_nms_topk, img.shape[0]
+    for rep in range(2):
+        ra, rb = a.inference(img), b.inference(img)
+        assert len(ra) == len(rb) == 2 and all(len(x["scores"]) > 0 for x in ra)
+        for x, y in zip(ra, rb):
+            for k in ("scores", "pred_boxes", "pred_classes", "pred_masks"):
+                assert torch.equal(x[k], y[k]), k
+        ca, cb = a.debug_stage("prop_count", (B,), torch.int32), b.debug_stage("prop_count", (B,), torch.int32)
+        assert torch.equal(ca, cb) and int(ca.min()) > 0
+        assert torch.equal(a.debug_stage("rois", (B * cap, 5)), b.debug_stage("rois", (B * cap, 5)))      # incl. the empty rows past the count
+    del a, b
+
+
 def test_fpn_output_convs_on_the_side_stream_change_nothing(small_net):
     """Round 5: the 3x3 output convs of p5, p4, p3 run on the handle's side stream next to the lateral / top-down chain that ends
     in p2's output conv (option rcnn_fpn_overlap).  Same kernels on the same data, only the schedule differs: detections, the
