@@ -256,12 +256,17 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
       sh1 = p_load_uncounted(prev_ss, ss_lane + shift_delta + 128);                                               \
     }                                                                                                             \
     const unsigned lane_off = (lane_row * prev_rs) + (prev_rs ? lane_col * 4 : 0);                                \
+    /* RAGGED: the clamped row offsets are worked out afresh in every group (the limit goes through an opaque copy): groups c  \
+       and c + 2 read the same rows, and hipcc otherwise keeps the eight products alive between them -- five of them in      \
+       scratch (the <RAGGED, !FLUSH> variant sits at 256 VGPRs) */                                                  \
+    int row_limit = prev_rows - 1;                                                                                \
+    if (RAGGED) asm volatile("" : "+s"(row_limit));                                                               \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
       const int r = ((c) & 1) * 8 + i, row = ((c) >> 2) * 32 + (r & 3) + 8 * (r >> 2);                            \
       unsigned roff = lane_off + (unsigned)row * prev_rs;                                                         \
       if (RAGGED) {                                                                                               \
         const int rr = (int)lane_row + row;                                                                       \
-        roff = (unsigned)(rr < prev_rows ? rr : prev_rows - 1) * prev_rs + (prev_rs ? lane_col * 4 : 0);          \
+        roff = (unsigned)(rr < row_limit ? rr : row_limit) * prev_rs + (prev_rs ? lane_col * 4 : 0);              \
       }                                                                                                           \
       resv[i] = p_load_uncounted(prev_res, roff + (prev_rs ? (((c) >> 1) & 1) * 128u : 0u));                      \
     }                                                                                                             \
