@@ -266,7 +266,10 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
       unsigned roff = lane_off + (unsigned)row * prev_rs;                                                         \
       if (RAGGED) {                                                                                               \
         const int rr = (int)lane_row + row;                                                                       \
-        roff = (unsigned)(rr < row_limit ? rr : row_limit) * prev_rs + (prev_rs ? lane_col * 4 : 0);              \
+        /* (24-bit multiply: rows and the row stride in bytes are far below 2^24; the 32-bit product + add otherwise becomes a     \
+           v_mad_u64_u32 whose unused upper addend half lands on a register with a load in flight -- harmless, but the audit     \
+           of uncounted loads, tests/test_abi.py, rightly has no notion of "unused half") */                                   \
+        roff = __umul24((unsigned)(rr < row_limit ? rr : row_limit), prev_rs) + (prev_rs ? lane_col * 4 : 0);     \
       }                                                                                                           \
       resv[i] = p_load_uncounted(prev_res, roff + (prev_rs ? (((c) >> 1) & 1) * 128u : 0u));                      \
     }                                                                                                             \
