@@ -6,7 +6,9 @@ batch 32 per GPU, data-parallel over N GPUs of one node (weak scaling, no data-p
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path (NCHW map batch resident in HBM -> NCHW probabilities in HBM)
-over one batch of synthetic maps.  Rank 0 prints ONE JSON line.
+over one batch of synthetic maps.  Rank 0 prints ONE JSON line -- the compact contract object
+(contract_line(): under 4 KB; the driver could not parse round 5's 23 KB line) -- and writes everything else it measured
+(per-family tables, extra precision modes, the other configurations with their stage tables) to bench_detail.json.
 `roofline` is measured live with HIP events recorded inside the timed region on the launch stream
 (peanut_pred_probe_*); `roofline.traffic` comes from a rocprofv3 PMC pass over this very command that
 bench.py runs on itself as a child (separate FETCH_SIZE / WRITE_SIZE passes, --kernel-trace only);
@@ -63,6 +65,110 @@ MODE_NOTES = {
               "fp32 CPU path (5.7e-6 / 7.7e-6); reported next to the headline, which stays on fp32 MFMA instructions",
 }
 METRIC = "maps/sec for 480x480x(4+N_cat) prediction fwd, batch 32"
+ALGORITHMS = ("direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 64 input channels as Winograd with fp32 "
+              "transforms, form chosen per shape -- at this size F(6x6,3x3) up to dilation 2 (PSP bottleneck included "
+              "in the fp32 mode, whose position GEMMs accumulate in two levels: partial sums of 64 channels), "
+              "F(5x5,3x3) for the dilation-4 layers (15x15 sub-grids), F(4x4,3x3) in the bottleneck of the emulated "
+              "modes; pyramid half of the PSP bottleneck folded through linearity "
+              "(nominal GFLOP/map counts the reference's 61 direct convs, so nominal TFLOP/s can exceed the MFMA peak)")
+
+# The driver parses the LAST stdout line; round 5's 23 KB line was not parsed.  The contract line is held under this many bytes,
+# everything else (op families, modes, the other configurations with their stage tables, notes) goes to bench_detail.json.
+CONTRACT_LINE_MAX_BYTES = 4096
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                 "traffic_measured_by_this_run", "launches_per_step", "avg_launch_ms", "mfma_busy", "flops_per_launch", "share_of_step_time",
+                 "gflop_per_map_executed", "whole_forward_tflops_executed", "effective_clock_ghz")
+CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "sample")
+
+
+def write_detail(detail: dict, path: str = "") -> str:
+    """Everything bench.py measured, as indented JSON next to the script (and under gpurun_out/ when that directory exists,
+    so that a gpurun call brings it back); returns the path written ('' when neither location is writable)."""
+    written = ""
+    targets = [path] if path else [os.path.join(ROOT, "bench_detail.json")]
+    if not path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    for t in targets:
+        try:
+            with open(t, "w") as fh:
+                json.dump(detail, fh, indent=1)
+            written = written or t
+        except OSError:
+            pass
+    return written
+
+
+def configs_summary(configs: dict) -> dict:
+    """Flat numbers of the other BASELINE.json configurations (tools/configs_bench.py) for the contract line."""
+    flat = {}
+    if not isinstance(configs, dict):
+        return flat
+    if "error" in configs:
+        flat["error"] = str(configs["error"])[:200]
+    for key, stem, unit in (("1", "config1", "maps_s"), ("3", "config3", "images_s"), ("4", "config4", "steps_s"),
+                            ("5", "config5", "maps_s"), ("mapping", "mapping", "steps_s")):
+        c = configs.get(key)
+        if isinstance(c, dict) and "value" in c:
+            flat[f"{stem}_{unit}"] = c["value"]
+            if (c.get("roofline") or {}).get("frac") is not None:
+                flat[f"{stem}_roofline_frac"] = c["roofline"]["frac"]
+            if (c.get("cpu_baseline") or {}).get("value") is not None:
+                flat[f"{stem}_cpu_{unit}"] = c["cpu_baseline"]["value"]
+    c3 = configs.get("3")
+    if isinstance(c3, dict) and isinstance(c3.get("batch1"), dict):
+        flat["detector_b1_ms_per_frame"] = c3["batch1"].get("ms_per_frame")
+    c4 = configs.get("4")
+    if isinstance(c4, dict):
+        st = c4.get("stages") or {}
+        if "prediction_720_per_step" in st:
+            flat["pred720_b1_ms_per_map"] = st["prediction_720_per_step"].get("ms_per_call")
+            flat["pred720_b1_frac"] = st["prediction_720_per_step"].get("frac")
+        if "mapping" in st:
+            flat["mapping_ms_per_step"] = st["mapping"].get("ms")
+        if "goal_selection_per_step" in st:
+            flat["goal_ms_added_per_call"] = st["goal_selection_per_step"].get("ms_added_per_call_next_to_the_forward")
+        flat["config4_ms_per_step"] = c4.get("ms_per_step")
+    if "seconds" in configs:
+        flat["seconds"] = configs["seconds"]
+    return flat
+
+
+def contract_line(detail: dict, detail_path: str = "") -> dict:
+    """The driver's contract object: the fields the bench contract names plus `roofline` and `cpu_baseline` reduced to their
+    numbers, flat summaries of the extra modes / configurations, and the name of the detail file -- never above
+    CONTRACT_LINE_MAX_BYTES as compact JSON (optional keys are dropped, least important first, if it ever would be)."""
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data", "config")}
+    roof, cpu = detail.get("roofline"), detail.get("cpu_baseline")
+    line["roofline"] = {k: roof[k] for k in ROOFLINE_KEYS if k in roof} if roof else None
+    line["cpu_baseline"] = {k: cpu[k] for k in CPU_KEYS if k in cpu} if cpu else None
+    optional = []                   # dropped from the end if the line would not fit
+    for k in ("speedup_vs_cpu_baseline", "gflop_per_map_nominal", "allgather_maps_ms", "allgather_maps_bytes_per_rank",
+              "allgather_maps_path", "rccl_ranks_seen"):
+        if k in detail:
+            line[k] = detail[k]
+    if detail.get("configs") is not None:
+        line["configs_summary"] = configs_summary(detail["configs"])
+        optional.append("configs_summary")
+    if detail.get("modes"):
+        line["modes_summary"] = {m: {"value": v["value"], "ms_per_step": v["ms_per_step"],
+                                     "frac": (v.get("roofline") or {}).get("frac")} for m, v in detail["modes"].items()}
+        optional.append("modes_summary")
+    if roof and roof.get("hbm_bound_kernels"):
+        line["hbm_bound_frac_of_8tbs"] = {k: v["frac_of_8tbs"] for k, v in roof["hbm_bound_kernels"].items()}
+        optional.append("hbm_bound_frac_of_8tbs")
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+
+    def size(o):
+        return len(json.dumps(o, separators=(",", ":")).encode())
+    while size(line) >= CONTRACT_LINE_MAX_BYTES and optional:
+        line.pop(optional.pop())
+    if size(line) >= CONTRACT_LINE_MAX_BYTES:      # free-text fields are the only thing left that can be long
+        for obj, k in ((line.get("cpu_baseline") or {}, "sample"), (line["config"], "workload"), (line, "allgather_maps_path")):
+            if isinstance(obj.get(k), str):
+                obj[k] = obj[k][:160]
+    assert size(line) < CONTRACT_LINE_MAX_BYTES
+    return line
 
 
 def synth_maps(b: int, c: int, s: int, device, seed0: int = 0) -> torch.Tensor:
@@ -330,17 +436,20 @@ def main(argv=None, backend_factory=HipBackend):
                     choices=sorted(PEAK_TFLOPS), help="conv arithmetic (include/peanut_hip.h PEANUT_PREC_*)")
     ap.add_argument("--also", default=os.environ.get("PEANUT_BENCH_ALSO"),
                     help="comma list of extra precision modes measured after the main run and reported under "
-                         "'modes' (empty string to skip); default: bf16x6,fp16x3,bf16x3 at N = 1, none at N > 1 (every rank "
-                         "would build three more models and run their steps: the scaling runs measure the headline only)")
+                         "'modes' of bench_detail.json ('all' = bf16x6,fp16x3,bf16x3); default: none -- the driver form measures "
+                         "the fp32 headline only (tools/final_measure.sh asks for all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-op HIP-event probe")
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
                     help="roofline.traffic: 'measure' profiles a short child run of this command with rocprofv3 PMC "
                          "counters; 'auto' = measure at N=1 when rocprofv3 is installed, else the committed file")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) here")
-    ap.add_argument("--configs", default=os.environ.get("PEANUT_BENCH_CONFIGS", "1,3,4,5,mapping"),
+    ap.add_argument("--detail", default="", help="where the full measurement record goes (default: bench_detail.json next to this script)")
+    ap.add_argument("--configs", default=os.environ.get("PEANUT_BENCH_CONFIGS", "4"),
                     help="the other BASELINE.json configurations measured after the headline (N = 1 only) and reported under "
-                         "'configs', each with its own roofline and cpu_baseline (tools/configs_bench.py); empty string to skip")
+                         "'configs' of bench_detail.json, each with its own roofline and cpu_baseline, flat numbers in the contract "
+                         "line's configs_summary (tools/configs_bench.py); default 4 (the per-step pipeline, which also measures the "
+                         "detector and the mapping stage), 'all' = 1,3,4,5,mapping, empty string to skip")
     args = ap.parse_args(argv)
     preset = PRESETS[args.config]
     for k, v in preset.items():
@@ -356,7 +465,11 @@ def main(argv=None, backend_factory=HipBackend):
     backend = backend_factory()
     dev = backend.device
     if args.also is None:
-        args.also = "bf16x6,fp16x3,bf16x3" if world == 1 else ""
+        args.also = ""
+    if args.also == "all":
+        args.also = "bf16x6,fp16x3,bf16x3"
+    if args.configs == "all":
+        args.configs = "1,3,4,5,mapping"
 
     cfg = PredCfg(in_channels=args.channels)
     sd = backend.state_dict(cfg)
@@ -409,7 +522,7 @@ def main(argv=None, backend_factory=HipBackend):
                     "algorithmic_bytes_per_launch": round(f["bytes"] / max(f["launches"], 1)),
                     "launches_per_step": f["launches"] // max(nf, 1),
                     "avg_launch_ms": round(f["ms"] / max(f["launches"], 1), 4),
-                    "flops_per_launch": f["flops"] / max(f["launches"], 1),
+                    "flops_per_launch": round(f["flops"] / max(f["launches"], 1)),
                     "share_of_step_time": round(f["ms"] / max(sum(v["ms"] for v in fam.values()), 1e-9), 4),
                     "note": "achieved = FLOPs this kernel family EXECUTES per launch (Winograd GEMMs at their transformed "
                             "size incl. tile padding, folded pyramid excluded) / its mean launch time from HIP events on the "
@@ -510,7 +623,8 @@ def main(argv=None, backend_factory=HipBackend):
                      "--config", str(args.config), "--batch", str(B), "--size", str(S), "--channels", str(cfg.in_channels),
                      "--precision", args.precision] + (["--maps", os.path.abspath(args.maps)] if args.maps else [])
             measured = measure_hbm_traffic(roof["kernel"], child)
-        if measured is not None and measured.get("traffic") is not None:
+        roof["traffic_measured_by_this_run"] = bool(measured is not None and measured.get("traffic") is not None)
+        if roof["traffic_measured_by_this_run"]:
             roof.update(measured)
         else:
             fb = hbm_traffic_from_file(args.precision, roof["kernel"]) if (args.config == 2 and not args.maps) else {"traffic": None}
@@ -523,7 +637,7 @@ def main(argv=None, backend_factory=HipBackend):
     if rank == 0:
         total_maps = world * B * args.steps
         value = total_maps / elapsed
-        line = {
+        detail = {
             "metric": METRIC if args.config == 2 else f"maps/sec for {S}x{S}x(4+N_cat) prediction fwd, batch {B} per GPU "
                                                         f"(SURVEY.md sec. 8d config {args.config})",
             "value": round(value, 3), "unit": "maps/s", "n_gpus": world,
@@ -538,28 +652,24 @@ def main(argv=None, backend_factory=HipBackend):
                        "parallelism": f"dp{world} (map shards, no data-path collective)"},
             "gflop_per_map_nominal": round(conv_flops_per_map(cfg, S, S) / 1e9, 3),
             "whole_forward_tflops_nominal": round(value * conv_flops_per_map(cfg, S, S) / 1e12, 2),
-            "algorithms": "direct implicit GEMM on fp32 MFMA; stride-1 3x3 convs with >= 64 input channels as Winograd with fp32 "
-                          "transforms, form chosen per shape -- at this size F(6x6,3x3) up to dilation 2 (PSP bottleneck included "
-                          "in the fp32 mode, whose position GEMMs accumulate in two levels: partial sums of 64 channels), "
-                          "F(5x5,3x3) for the dilation-4 layers (15x15 sub-grids), F(4x4,3x3) in the bottleneck of the emulated "
-                          "modes; pyramid half of the PSP bottleneck folded through linearity "
-                          "(nominal GFLOP/map counts the reference's 61 direct convs, so nominal TFLOP/s can exceed the MFMA peak)",
+            "algorithms": ALGORITHMS,
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu is not None:
-            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+            detail["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
             for mname, m in modes.items():
                 m["speedup_vs_cpu_baseline"] = round(m["value"] / cpu["value"], 1)
         if modes:
-            line["modes"] = modes
+            detail["modes"] = modes
         if configs is not None:
-            line["configs"] = configs
+            detail["configs"] = configs
         if gather_ms is not None:
-            line["allgather_maps_ms"] = round(gather_ms, 3)
-            line["allgather_maps_bytes_per_rank"] = int(out.numel() * 4)
-            line["allgather_maps_path"] = gather_path
-            line["rccl_ranks_seen"] = pdist.rccl_ranks_seen()       # ranks of the library's own communicator (peanut_comm_info); 0: none was built
-        print(json.dumps(line), flush=True)
+            detail["allgather_maps_ms"] = round(gather_ms, 3)
+            detail["allgather_maps_bytes_per_rank"] = int(out.numel() * 4)
+            detail["allgather_maps_path"] = gather_path
+            detail["rccl_ranks_seen"] = pdist.rccl_ranks_seen()       # ranks of the library's own communicator (peanut_comm_info); 0: none was built
+        detail_path = write_detail(detail, args.detail)
+        print(json.dumps(contract_line(detail, detail_path), separators=(",", ":")), flush=True)
     pdist.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -209,14 +209,25 @@ def _bench_worker(rank, world, port, q, break_gather):
         buf, code = io.StringIO(), 0
         with contextlib.redirect_stdout(buf):
             try:
-                bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "32"], backend_factory=StubBackend)
+                import tempfile
+                detail = os.path.join(tempfile.gettempdir(), f"peanut_bench_detail_{port}.json")
+                bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "32", "--detail", detail],
+                           backend_factory=StubBackend)
             except SystemExit as e:
                 code = e.code if isinstance(e.code, int) else 1
-        lines = [l for l in buf.getvalue().splitlines() if l.startswith("{")]
-        q.put((rank, code, [json.loads(l) for l in lines]))
+        out_lines = buf.getvalue().splitlines()
+        lines = [l for l in out_lines if l.startswith("{")]
+        # the driver reads the LAST stdout line: it must be the (only) JSON line, strict JSON, under the contract's size bound
+        assert not lines or (out_lines[-1] == lines[-1] and len(lines[-1].encode()) < bench.CONTRACT_LINE_MAX_BYTES), out_lines[-1][:200]
+        full = []
+        if lines and os.path.exists(detail):
+            with open(detail) as fh:
+                full = [json.load(fh)]
+            os.remove(detail)
+        q.put((rank, code, [json.loads(l) for l in lines], full))
     except Exception as ex:  # pragma: no cover
         import traceback
-        q.put((rank, -1, traceback.format_exc() + repr(ex)))
+        q.put((rank, -1, traceback.format_exc() + repr(ex), []))
 
 
 @pytest.mark.parametrize("break_gather", [False, True], ids=["gather_ok", "gather_falls_back"])
@@ -235,14 +246,16 @@ def test_bench_main_runs_its_multi_rank_control_flow_under_gloo(break_gather):
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    for rank, code, lines in res:
+    for rank, code, lines, _full in res:
         assert code == (4 if break_gather else 0), (rank, code, lines)
     assert len(res[0][2]) == 1 and res[1][2] == [], res
-    line = res[0][2][0]
+    line, detail = res[0][2][0], res[0][3][0]
+    assert line["detail"] and detail["value"] == line["value"] and detail["roofline"]["kernel"] == line["roofline"]["kernel"]
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["higher_is_better"] is True
     assert line["config"]["global_batch"] == 4 and line["steps"] == 3 and line["warmup"] == 1
     assert abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"] + 1e-3
-    assert "modes" not in line and "configs" not in line and line["cpu_baseline"] is None
+    assert "modes_summary" not in line and "configs_summary" not in line and line["cpu_baseline"] is None
+    assert "modes" not in detail and "configs" not in detail
     assert line["allgather_maps_ms"] >= 0 and line["allgather_maps_bytes_per_rank"] == 2 * 6 * 32 * 32 * 4
     assert line["rccl_ranks_seen"] == 0                      # host tensors: the library's RCCL communicator was not built
     assert ("failed" in line["allgather_maps_path"]) == break_gather
@@ -251,4 +264,5 @@ def test_bench_main_runs_its_multi_rank_control_flow_under_gloo(break_gather):
     # the headline's CURRENT dominant family (bench.DOMINANT_FAMILY_FP32; tests/test_pred_gpu.py checks on the GPU that it still is)
     # must be in profiles/hbm_traffic.json: at N > 1 no PMC child pass runs and the line's traffic comes from that file
     assert roof["kernel"] == bench.DOMINANT_FAMILY_FP32 and roof["bound"] == "mfma"
-    assert roof["traffic"] is not None and roof["traffic"] > 0 and "NOT measured by this run" in roof["traffic_source"]
+    assert roof["traffic"] is not None and roof["traffic"] > 0 and roof["traffic_measured_by_this_run"] is False
+    assert "NOT measured by this run" in detail["roofline"]["traffic_source"]

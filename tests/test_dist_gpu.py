@@ -87,32 +87,75 @@ def test_bench_spawns_its_own_ranks_or_refuses():
     assert "allgather_maps_ms" in line
 
 
-@pytest.mark.slow
-def test_bench_line_carries_the_contract_fields():
-    """The ONE JSON line of bench.py (small shape, short run): the driver's fields, the roofline object with the HBM-bound
-    families reported against bandwidth, a cpu_baseline object (bounded sample), and every requested mode with its own
-    roofline."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "96",
-           "--also", "bf16x6,fp16x3", "--traffic", "none"]
-    r = subprocess.run(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+def _run_bench(args, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    out_lines = r.stdout.splitlines()
+    lines = [ln for ln in out_lines if ln.startswith("{")]
+    # the driver parses the LAST stdout line: exactly one JSON line, last, strict JSON, under 4 KB
+    assert len(lines) == 1 and out_lines[-1] == lines[0]
+    assert len(lines[0].encode()) < 4096, len(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_contract(line, steps, warmup, batch):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "modes"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "detail"):
         assert k in line, k
-    assert line["unit"] == "maps/s" and line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["unit"] == "maps/s" and line["n_gpus"] == 1 and line["steps"] == steps and line["warmup"] == warmup
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
-    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]
+    assert abs(line["value"] - batch * steps / (line["ms_per_step"] * steps * 1e-3)) <= 0.01 * line["value"]
     roof = line["roofline"]
-    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3 and "traffic" in roof
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "launches_per_step",
+              "avg_launch_ms"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    hbm = roof["hbm_bound_kernels"]
-    assert {"nchw_to_nhwc", "maxpool", "ppm_pool", "upsample_logits"} <= set(hbm) and all(v["gb_s"] > 0 for v in hbm.values())
     cpu = line["cpu_baseline"]
+    assert set(cpu) == {"value", "unit", "cores", "kind", "cpu_model", "sample"}
     assert cpu["kind"] == "port" and cpu["unit"] == "maps/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
-    assert set(line["modes"]) == {"bf16x6", "fp16x3"}
-    for m in line["modes"].values():
+
+
+@pytest.mark.slow
+def test_bench_line_carries_the_contract_fields(tmp_path):
+    """The ONE JSON line of bench.py (small shape, short run): the driver's fields, the roofline and cpu_baseline objects reduced
+    to their numbers, flat summaries of the requested modes; the per-family tables and the modes' own rooflines are in the detail
+    file the line names."""
+    detail_path = str(tmp_path / "detail.json")
+    line = _run_bench(["--steps", "3", "--warmup", "1", "--batch", "2", "--size", "96", "--also", "bf16x6,fp16x3", "--traffic", "none",
+                       "--detail", detail_path])
+    _check_contract(line, 3, 1, 2)
+    assert set(line["modes_summary"]) == {"bf16x6", "fp16x3"} and all(m["value"] > 0 for m in line["modes_summary"].values())
+    assert {"nchw_to_nhwc", "maxpool", "ppm_pool", "upsample_logits"} <= set(line["hbm_bound_frac_of_8tbs"])
+    with open(detail_path) as fh:
+        detail = json.load(fh)
+    assert detail["value"] == line["value"] and detail["roofline"]["frac"] == line["roofline"]["frac"]
+    hbm = detail["roofline"]["hbm_bound_kernels"]
+    assert {"nchw_to_nhwc", "maxpool", "ppm_pool", "upsample_logits"} <= set(hbm) and all(v["gb_s"] > 0 for v in hbm.values())
+    assert set(detail["modes"]) == {"bf16x6", "fp16x3"}
+    for m in detail["modes"].values():
         assert m["value"] > 0 and m["roofline"]["peak"] in (416.7, 833.3) and "speedup_vs_cpu_baseline" in m
+
+
+@pytest.mark.slow
+def test_bench_default_command_form_prints_a_parseable_contract_line():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- the driver's own command form, every default in force (headline at
+    480 x 480 x 14, batch 32, PMC traffic passes, CPU baseline, config 4 with the detector and the mapping stage): the last
+    stdout line is the contract object, strict JSON under 4 KB, with a measured roofline, a cpu_baseline and the flat
+    configs_summary (round 5's line was 23 KB and the driver recorded parsed = null)."""
+    t0 = __import__("time").perf_counter()
+    line = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], timeout=1500)
+    wall = __import__("time").perf_counter() - t0
+    _check_contract(line, 20, 5, 32)
+    assert line["config"]["survey_config"] == 2 and line["config"]["global_batch"] == 32
+    import bench
+    assert line["roofline"]["kernel"] == bench.DOMINANT_FAMILY_FP32 and line["roofline"]["frac"] > 0.5
+    cs = line["configs_summary"]
+    assert "error" not in cs, cs
+    for k in ("config4_steps_s", "detector_b1_ms_per_frame", "pred720_b1_ms_per_map", "mapping_steps_s", "config3_images_s"):
+        assert cs.get(k) and cs[k] > 0, (k, cs)
+    assert os.path.exists(os.path.join(ROOT, line["detail"]))
+    print(f"default bench form: {wall:.0f} s wall, line {len(json.dumps(line, separators=(',', ':')))} bytes, "
+          f"{line['value']} maps/s, frac {line['roofline']['frac']}, traffic {line['roofline']['traffic']}")

@@ -8,7 +8,9 @@ cd $R
 if [ "${SKIP_PYTEST:-0}" != "1" ]; then
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|max-abs|max \|GPU|final map|vs oracle|fp64|worst" > $OUT/pytest_gpu.txt
 fi
-python bench.py --steps 20 --warmup 5 --op-table $OUT/op_table_fp32.json > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+# the driver's own command form first (compact contract line, config 4 only), then the full record (all modes, all configurations)
+python bench.py --gpus 1 --steps 20 --warmup 5 --detail $OUT/bench_detail_driver_form.json > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+python bench.py --steps 20 --warmup 5 --also all --configs all --op-table $OUT/op_table_fp32.json --detail $OUT/bench_detail.json > $OUT/bench_line_full.json 2>> $OUT/bench_stderr.txt
 for m in bf16x6 fp16x3 bf16x3; do python bench.py --precision $m --steps 10 --warmup 3 --no-cpu-baseline --also "" --traffic measure --op-table $OUT/op_table_$m.json 2>/dev/null | grep "^{" ; done > $OUT/bench_modes.json
 python bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline --also "bf16x6,fp16x3" --traffic none 2>/dev/null | grep "^{" > $OUT/bench_config5.json
 for m in fp32 bf16x6 fp16x3; do
