@@ -332,6 +332,45 @@ def test_b4_480_forward_matches_reference_golden(golden_dir):
         del m
 
 
+@pytest.mark.slow
+def test_b32_480_headline_batch_matches_reference_golden(golden_dir):
+    """The headline's own step -- the 32 maps bench.py times at N = 1 (bench.synth_maps, seed0 = 0, 480 x 480 x 14) -- against
+    logits from the reference's OWN model files (tests/golden/pspnet_b32_480_golden.npz, rows 3::8 / cols 5::8;
+    oracle/gen_golden.py --round6), in the fp32 mode and the two fp32-class emulated modes, at 5e-5.  In the fp32 mode the
+    kernel assignment is the one the benchmark times, asserted by op name: layer4's conv1 / conv3 and both conv3 + downsample
+    GEMMs on the persistent 256 x 256 kernel (bench.DOMINANT_FAMILY_FP32) -- layer4 conv1 reaches it only at this batch."""
+    import bench
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    z = np.load(os.path.join(golden_dir, "pspnet_b32_480_golden.npz"))
+    x = bench.synth_maps(32, 14, 480, "cpu", seed0=int(z["b32_480/input_seed"]))
+    assert float(x.double().sum()) == float(z["b32_480/input_sum"]), "bench.synth_maps changed: regenerate the fixture"
+    assert np.array_equal(x.double().sum(dim=(1, 2, 3)).numpy(), z["b32_480/input_sum_per_map"])
+    ref = z["b32_480/logits32_sub"]
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    xd = x.cuda()
+    out = torch.empty((32, cfg.num_classes, 480, 480), device="cuda")
+    for precision in ("fp32", "bf16x6", "fp16x3"):
+        m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, precision=precision)
+        m.get_prediction_batch(xd, apply_sigmoid=False, out=out)            # the call bench.py times (sigmoid aside)
+        got = out[:, :, 3::8, 5::8].cpu().numpy()
+        err = float(np.abs(got - ref).max())
+        print(f"{precision}: the headline's 32 maps vs the reference golden max-abs {err:.3e}")
+        assert err <= TOL, precision
+        if precision == "fp32":
+            ops = {name: kern for name, kern, *_ in m.model.profile(xd)}
+            for layer in ("layer4.0.conv1", "layer4.1.conv1", "layer4.2.conv1", "layer4.1.conv3", "layer4.2.conv3",
+                          "layer4.0.conv3+downsample", "layer3.0.conv3+downsample"):
+                hit = [n for n in ops if n.endswith(layer)]
+                assert hit and all(ops[n] == bench.DOMINANT_FAMILY_FP32 for n in hit), (layer, [(n, ops[n]) for n in hit])
+            # with the sigmoid, as timed: probabilities of the same logits
+            m.get_prediction_batch(xd, apply_sigmoid=True, out=out)
+            perr = float(np.abs(out[:, :, 3::8, 5::8].cpu().numpy() - 1.0 / (1.0 + np.exp(-ref.astype(np.float64)))).max())
+            assert perr <= 2e-5, perr
+        del m
+
+
 def test_pyramid_term_row_kernel_is_bit_identical(golden_dir):
     """The folded pyramid term (csrc/pspnet_aux.hip) evaluated with one wave per output row (round 4, option ppm_term_rows = 1:
     no workgroup barrier in the row loop) against the workgroup-wide two-phase kernel: the same operations in the same order,
