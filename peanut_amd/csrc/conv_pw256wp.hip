@@ -541,12 +541,13 @@ int launch_conv_pw256wp(const ConvKParams& p0, float* ws, size_t ws_floats, hipS
   p.stagger = (int)opt(OPT_PW256WP_STAGGER);
   note_kernel("conv_pw_glds_256x256p");
   // blocks per epilogue group: with a residual two (32 residual registers; four would need 64 and the kernel then sits at the 256-register
-  // limit with spills), without one four (fewer repeated fragment reads in an item's first iteration); pw256wp_npre = 2 / 4 forces
+  // limit with spills), without one four (fewer repeated fragment reads in an item's first iteration); pw256wp_npre = 2 forces two
+  // the residual variant exists with two blocks per group only: <true, 4> compiled to 255 VGPRs + 4 spilled (20 B of scratch) and was
+  // removed in round 6 -- pw256wp_npre = 4 applies to the layers without a residual
   const long long npre_opt = opt(OPT_PW256WP_NPRE);
-  const bool npre2 = npre_opt == 2 || (npre_opt != 4 && p.res != nullptr);
+  const bool npre2 = npre_opt == 2 || p.res != nullptr;
   if (p.res) {
-    if (npre2) hipLaunchKernelGGL((conv_pw_glds256wp_kernel<true, 2>), dim3((unsigned)G), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_pw_glds256wp_kernel<true, 4>), dim3((unsigned)G), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((conv_pw_glds256wp_kernel<true, 2>), dim3((unsigned)G), dim3(512), 0, stream, p);
   } else {
     if (npre2) hipLaunchKernelGGL((conv_pw_glds256wp_kernel<false, 2>), dim3((unsigned)G), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((conv_pw_glds256wp_kernel<false, 4>), dim3((unsigned)G), dim3(512), 0, stream, p);

@@ -289,3 +289,33 @@ def test_uncounted_asm_loads_are_not_touched_before_their_wait():
     for src in audit.DEFAULT:                     # conv_pw_ares.hip AND conv_pw256p.hip (both use uncounted asm loads)
         n, findings = audit.audit(audit.assembly(src))
         assert n >= 100 and findings == [], (src, findings[:5])
+
+
+def test_hot_kernels_have_no_spilled_vgprs_and_no_scratch():
+    """Register budget of the built library, from the code objects' own metadata (tools/kernel_resources.py; the numbers
+    `-Rpass-analysis=kernel-resource-usage` prints): no kernel spills a VGPR, none of the convolution / GEMM / Winograd /
+    mapping / goal kernels uses scratch memory, and the MFMA kernels keep the occupancy their LDS plan assumes (two
+    workgroups' worth of waves per SIMD).  Spilled SGPRs (v_writelane into a spare VGPR: no memory traffic) are bounded per
+    kernel so that growth is noticed.  Round 5's conv_pw_glds256wp_kernel<true, 4> (255 VGPRs + 4 spilled, 20 B scratch) is
+    gone: the residual variant exists with two blocks per epilogue group only."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build.build()
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.library_kernels()
+    assert len(ks) >= 100
+    names = [k["name"] for k in ks]
+    assert not any("conv_pw_glds256wp_kernel<true, 4>" in n for n in names)
+    assert any("conv_pw_glds256wp_kernel<true, 2>" in n for n in names) and any("conv_pw_glds256wp_kernel<false, 4>" in n for n in names)
+    spilled = [(k["file"], k["name"], k["vgpr_spill_count"]) for k in ks if k["vgpr_spill_count"]]
+    assert spilled == [], spilled
+    # scratch: only the detector's per-box post-processing kernel keeps a small per-thread array (rcnn_post.hip: box_post_kernel)
+    scratch = [(k["file"], k["name"], k["private_segment_fixed_size"]) for k in ks if k["private_segment_fixed_size"]]
+    assert all(f == "rcnn_post.hip" and "box_post_kernel" in n for f, n, _ in scratch), scratch
+    for k in ks:
+        assert k["sgpr_spill_count"] <= 90, (k["name"], k["sgpr_spill_count"])
+        hot = k["file"] in ("conv_pw256p.hip", "conv_pw256wp.hip", "conv_pw_ares.hip", "conv_pw.hip", "gemm_rs.hip") and "reduce" not in k["name"]
+        if hot:
+            assert k["waves_per_simd"] >= 2, (k["name"], k["vgpr_count"], k.get("agpr_count"))

@@ -45,7 +45,7 @@ db=$(find /tmp/fm_tl -name '*.db' | head -1)
 cd $R
 python tools/gap_b1.py $OUT/gap_b1.json ${db:+--timeline-db $db --timeline-forwards 20} > $OUT/gap_b1_summary.txt 2>/dev/null
 python tools/step_profile.py 60 2>/dev/null | grep "^{" > $OUT/step_profile.json
-bash tools/exp_r8g.sh > /dev/null 2>&1; cp gpurun_out/r8g/detector_b1_timeline.txt $OUT/ 2>/dev/null
+bash tools/detector_timeline.sh > /dev/null 2>&1; cp gpurun_out/r8g/detector_b1_timeline.txt $OUT/ 2>/dev/null
 tools/pmc_passes.sh $OUT/pmc_fp32 --precision fp32
 tools/pmc_passes.sh $OUT/pmc_bf16x6 --precision bf16x6
 tools/pmc_passes.sh $OUT/pmc_fp16x3 --precision fp16x3
