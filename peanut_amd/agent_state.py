@@ -221,6 +221,10 @@ class Agent_State:
         lm = self.local_map
         if not lm.is_contiguous():            # (a view into full_map right after _rebind_local; _map_step replaces it)
             raise RuntimeError("local_map must be contiguous here")
+        if lm.dtype != torch.float32 or lm.shape[1] != lm.shape[2]:
+            # peanut_map_mark_agent takes ONE side length (row / column decomposition, plane stride, index checks) and fp32 planes:
+            # the reference's local map is square (agent_state.py:56-60: local_w = local_h); anything else is refused, not mis-indexed
+            raise ValueError(f"_mark_agent: the local map must be a square fp32 [C, M, M] tensor, got {tuple(lm.shape)} {lm.dtype}")
         m = int(lm.shape[1])
         rad = int(self.args.col_rad + 1)
         r0, r1, _ = slice(loc_r - traj_rad, loc_r + traj_rad + 1).indices(m)

@@ -533,8 +533,10 @@ int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_float
     return launch_with_tail_split<decltype(&conv_pw_glds256w_kernel), 256, 256, 512>(&conv_pw_glds256w_kernel, q, ws, ws_floats, stream,
                                                                                       &slots256w);
   }
-  if (conv_pw_uses_256p(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, p.flush, (long long)(p.M / p.HoWo) * p.H * p.W) && !(p.flush && p.res))
-    return launch_conv_pw256p(p, ws, ws_floats, stream);
+  if (conv_pw_uses_256p(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2, p.flush, (long long)(p.M / p.HoWo) * p.H * p.W) && !(p.flush && p.res)) {
+    const int rc = launch_conv_pw256p(p, ws, ws_floats, stream);
+    if (rc != 1) return rc;            // 1: more items per workgroup than its plan table holds -> the kernels below
+  }
   if (conv_pw_uses_256(p.cout, p.M, p.mt_per_group, bn_tile, p.c1 + p.c2)) {
     static SlotCache slots256;
     ConvKParams q = p;

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256p_kernel(const ConvKParams
   const int n_frag = u1 > u0 ? (u1 - 1) / upt - u0 / upt + 1 : 0;
   const int n_items = nf + (skU > 0 ? n_frag : sp1 - sp0);
   if (n_items == 0) return;
+  if (n_items > kMaxItems) __builtin_trap();      // the launcher bounds the plan; never write past the LDS table
   // The items are worked out ONCE, one per thread, into the LDS plan table (round 5, as in conv_pw256wp.hip): the 64-bit divisions of
   // the stream-K bookkeeping were inlined at every use of item_at -- four places -- and cost the kernel 100-170 spilled SGPRs.
   if (tid < n_items) {
@@ -525,7 +526,9 @@ int launch_conv_pw256p(const ConvKParams& p0, float* ws, size_t ws_floats, hipSt
     }
   }
   if (p.n_sp > 0 && (!ws || (size_t)p.n_sp * 256 * 128 > ws_floats)) return fail(-2, "conv_pw256p: split-K scratch too small");
-  if (p.n_full / G + (p.n_sp + G - 1) / G + 4 > 120) return fail(-2, "conv_pw256p: more items per workgroup than the plan table holds");
+  // more items per workgroup than the LDS plan table holds (a layer near the 4 GiB output bound, or a part with few CUs): nothing is
+  // launched and the caller takes the tile-per-workgroup kernel, as launch_conv_pw256wp's callers do
+  if (p.n_full / G + (p.n_sp + G - 1) / G + 4 > 120) return 1;
   p.partial = ws;
   p.mtiles = mtiles;
   p.nchunk = (int)opt(OPT_NCHUNK);

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512) void conv_pw_glds256wp_kernel(const ConvKParam
     const int n_frag = u1 > u0 ? (u1 - 1) / upt - u0 / upt + 1 : 0;
     n_items = nf + (skU > 0 ? n_frag : sp1 - sp0);
     if (n_items == 0) return;
+    if (n_items > kMaxItems) __builtin_trap();      // the launcher bounds the plan; never write past the LDS table
     if (tid < n_items) {
       const int i = tid;
       int tile, kt0, kt1, part;

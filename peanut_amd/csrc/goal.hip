@@ -814,19 +814,27 @@ int peanut_goal_select_begin(peanut_goal_t* g, const float* full_obstacle, const
   if (g->begun.on) PEANUT_HIP_CHECK(hipStreamSynchronize(g->side));      // a begin nobody finished: its rounds still own the scratch
   PEANUT_HIP_CHECK(hipEventRecord(g->ev_inputs, (hipStream_t)stream));
   PEANUT_HIP_CHECK(hipStreamWaitEvent(g->side, g->ev_inputs, 0));
-  if (int rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, g->side)) return rc;
+  // from here on work may be in flight on g->side that writes the handle's scratch: the handle is marked busy BEFORE the first
+  // enqueue (for no inputs yet: obst = nullptr matches no select, so whoever comes next synchronises the side stream first), and an
+  // enqueue that fails part-way lets the side stream run out before the error is returned
+  g->begun.on = true;
+  g->begun.obst = nullptr; g->begun.col = nullptr; g->begun.vis = nullptr;
+  int cur = 0, batch = 0, rc = 0;
   int sr, sc;
   seed_cell(g, lmb, loc_r, loc_c, &sr, &sc);
-  if (int rc = field_preamble(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, g->side)) return rc;
-  int cur = 0;
-  const int batch = first_batch(g, 0);
-  if (int rc = enqueue_rounds<false>(g, &cur, batch, g->side)) return rc;
-  g->begun.on = true;
+  rc = peanut_goal_traversible(g, full_obstacle, collision_map, visited_vis, nullptr, g->side);
+  if (!rc) rc = field_preamble(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, g->side);
+  if (!rc) { batch = first_batch(g, 0); rc = enqueue_rounds<false>(g, &cur, batch, g->side); }
+  if (!rc && hipGetLastError() != hipSuccess) rc = fail(PEANUT_EHIP, "peanut_goal_select_begin: launch failed");
+  if (rc) {
+    (void)hipStreamSynchronize(g->side);
+    g->begun.on = false;
+    return rc;
+  }
   g->begun.obst = full_obstacle; g->begun.col = collision_map; g->begun.vis = visited_vis;
   for (int i = 0; i < 4; ++i) g->begun.lmb[i] = lmb[i];
   g->begun.loc_r = loc_r; g->begun.loc_c = loc_c; g->begun.batch = batch; g->begun.cur = cur;
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : fail(PEANUT_EHIP, std::string("peanut_goal_select_begin: ") + hipGetErrorString(e));
+  return 0;
 }
 
 int peanut_goal_rounds(peanut_goal_t* g) { return g ? g->last_rounds : PEANUT_EINVAL; }
@@ -893,7 +901,10 @@ int peanut_goal_select(peanut_goal_t* g, const float* full_obstacle, const uint8
     if (!aside) PEANUT_HIP_CHECK(hipStreamSynchronize(g->side));      // begun for other inputs: let it run out, solve these
   }
   if (aside) {
-    if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, g->side, g->begun.batch, g->begun.cur)) return rc;
+    if (int rc = solve_field(g, (const unsigned char*)g->trav.p, nullptr, sr, sc, g->side, g->begun.batch, g->begun.cur)) {
+      (void)hipStreamSynchronize(g->side);      // `s` never joined the side stream: let it run out before the scratch is reused
+      return rc;
+    }
     PEANUT_HIP_CHECK(hipEventRecord(g->ev_field, g->side));
     PEANUT_HIP_CHECK(hipStreamWaitEvent(s, g->ev_field, 0));
   } else {

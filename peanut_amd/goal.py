@@ -24,6 +24,17 @@ def _u8(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     return (t != 0).to(device=device, dtype=torch.uint8).contiguous() if t.dtype != torch.uint8 else t.to(device).contiguous()
 
 
+def _ident(t):
+    """What makes two map arguments 'the same input': the storage they view (data pointer, shape, strides, dtype, device) --
+    not the Python object (full_map[0] is a new view object on every call)."""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return ("t", t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device))
+    a = np.asarray(t)
+    return ("n", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
+
+
 class GeodesicSolver:
     """peanut_goal_t: scratch for one full-map size + the collision-disk radius."""
 
@@ -33,6 +44,8 @@ class GeodesicSolver:
         self._lib = _lib.load()
         self.device = torch.device(device)
         self.H, self.W, self.col_rad = int(full_h), int(full_w), int(col_rad)
+        self.begun_matches = 0            # selects that took over the field a select_begin had started (same storage)
+        self._begun = None
         self._h = C.c_void_p()
         # (an empty default_options block = the option lock: a handle snapshots the process defaults while it is created, and must
         # not do so in the middle of another thread's `with default_options(...)`)
@@ -77,7 +90,7 @@ class GeodesicSolver:
                                                     None if vis is None else vis.data_ptr(), C.byref(bounds), int(loc_rc[0]), int(loc_rc[1]),
                                                     _lib.current_stream_ptr(self.device))
         _lib.check(rc, "peanut_goal_select_begin")
-        self._begun = ((full_obstacle, collision_map, visited_vis), (obst, col, vis))
+        self._begun = (tuple(_ident(t) for t in (full_obstacle, collision_map, visited_vis)), (obst, col, vis))
 
     def traversible(self, full_obstacle: torch.Tensor, collision_map=None, visited_vis=None) -> torch.Tensor:
         """agent_state.py:382-386 -> uint8 [H,W] (1 = traversible)."""
@@ -119,12 +132,17 @@ class GeodesicSolver:
     def select(self, full_obstacle, collision_map, visited_vis, lmb, loc_rc, target_pred, dist_weight_temperature: float,
                map_resolution: int, want_dist: bool = False, want_value: bool = False):
         """One ``update_global_goal`` evaluation -> dict(goal=(r, c), value_max, wt_sum, kept_last, rounds[, dist, value])."""
-        obst = full_obstacle.to(self.device, torch.float32).contiguous()
-        col, vis = _u8(collision_map, self.device), _u8(visited_vis, self.device)
         tp = None if target_pred is None else target_pred.to(self.device, torch.float32).contiguous()
+        # `begun` stays referenced until the C call has returned: the side stream may still be reading its buffers.  The inputs of
+        # select_begin are recognised by storage (data pointer, shape, strides, dtype, device), not by object identity: Agent_State
+        # passes full_map[0], a fresh view object on every call
         begun, self._begun = getattr(self, "_begun", None), None
-        if begun is not None and all(a is b for a, b in zip(begun[0], (full_obstacle, collision_map, visited_vis))):
+        if begun is not None and begun[0] == tuple(_ident(t) for t in (full_obstacle, collision_map, visited_vis)):
             obst, col, vis = begun[1]          # the buffers select_begin handed over (a converted input is converted once)
+            self.begun_matches += 1
+        else:
+            obst = full_obstacle.to(self.device, torch.float32).contiguous()
+            col, vis = _u8(collision_map, self.device), _u8(visited_vis, self.device)
         lw, lh = int(lmb[1] - lmb[0]), int(lmb[3] - lmb[2])
         if tp is not None and tuple(tp.shape) != (lw, lh):
             raise ValueError(f"target_pred must be [{lw},{lh}], got {tuple(tp.shape)}")

@@ -321,6 +321,21 @@ def test_field_solved_next_to_the_prediction_forward_is_the_same_field():
     sol2.select_begin(obst, cb, vis, lmb, loc)
     got = sol2.select(obst, cb, vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True)
     assert got["goal"] == ref["goal"] and torch.equal(got["dist"], ref["dist"])
+    # the agent's own call shape (agent_state.py: full_map[0] is a FRESH VIEW OBJECT on every call) with a bool collision map: the
+    # begun inputs are recognised by their storage, so the select takes the begun field (begun_matches counts it) -- round 5 compared
+    # object identities and silently re-solved serially here
+    full_map = torch.stack([obst, obst * 0])
+    sol2.reset()
+    n0 = sol2.begun_matches
+    sol2.select_begin(full_map[0], cb, vis, lmb, loc)
+    got = sol2.select(full_map[0], col.bool(), vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True)
+    assert sol2.begun_matches == n0                       # a different (equal-valued) bool tensor is different storage: not matched
+    assert got["goal"] == ref["goal"] and torch.equal(got["dist"], ref["dist"])
+    sol2.reset()
+    sol2.select_begin(full_map[0], cb, vis, lmb, loc)
+    got = sol2.select(full_map[0], cb, vis, lmb, loc, produce_target(), 500.0, 5, want_dist=True)
+    assert sol2.begun_matches == n0 + 1
+    assert got["goal"] == ref["goal"] and torch.equal(got["dist"], ref["dist"])
     # a select for another agent cell than the one begun: the begun work is dropped, the answer is that of a select alone
     other = (loc[0] + 7, loc[1] + 3)
     alone = sol.select(obst, col, vis, lmb, other, produce_target(), 500.0, 5, want_dist=True)
