@@ -48,6 +48,11 @@ int peanut_debug_weight_pieces(const float* values, int n, int precision, unsign
  * tiles of tile x tile (4, 5 or 6; csrc/winograd.hip), as the uploader computes it (double arithmetic, rounded once):
  * out [(tile + 2)^2][cout][cin].  tests/test_abi.py holds it against the Toom-Cook construction in exact rationals. */
 int peanut_debug_wino_weights(const float* w_oihw, int cout, int cin, int tile, float* out);
+/* Test hook (ABI 14): how many Winograd input transforms of this process have summed their producer's split-K partial tiles
+ * themselves (csrc/common.h DeferredSplit; option defer_splitk): a Bottleneck conv1 at batch 1 then runs no reduce launch.  Replaces
+ * nothing in the reference (resnet.py:267-307 conv1 -> bn1 -> relu -> conv2 are four module calls there); lets a test assert
+ * that the fused path really ran while the results stay bit-identical. */
+long long peanut_debug_deferred_splitk_count(void);
 
 /* ------------------------------------------------------------------------------------------
  * Tuning options (csrc/options.h): kernel gates, Winograd form policy, launch-plan switches -- named by key, e.g.

@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 13    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 14    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "peanut_source_hash": (C.c_char_p, []),
     "peanut_debug_weight_pieces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "peanut_debug_wino_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "peanut_debug_deferred_splitk_count": (C.c_longlong, []),
     "peanut_pred_create": (C.c_int, [C.POINTER(_P), C.POINTER(PredCfgC), C.POINTER(TensorC), C.c_int]),
     "peanut_pred_destroy": (None, [_P]),
     "peanut_pred_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -46,6 +46,21 @@ struct ConvDesc {
                            // PEANUT_FLUSH_*), 0 = one running sum over all of K
 };
 
+// A pointwise conv whose tail split-K partial tiles are summed by its CONSUMER (round 6): when every 128 x 128 tile of a launch is cut
+// into k-ranges (a batch-1 layer: fewer tiles than CUs), the launcher may leave the partial tiles unsummed -- no reduce launch -- and
+// describe them here; the small-problem Winograd input transform of the next layer then reads a pixel as
+// relu(scale * alpha * (p0 + p1 + ...) + shift), the reduce kernel's own expression in its own order (bit-identical), and the conv's
+// output tensor is never written.  Saves one launch (~5.2 us: the floor of a small dependent kernel) per Bottleneck at batch 1.
+// The caller offers the struct (ConvArgs::defer) only when the consumer has said it can read it (wino_input_accepts_deferred).
+struct DeferredSplit {
+  bool valid;
+  const float* partial;      // [tile = mt * ntiles + nt][split_p][128 * 128] raw accumulator tiles
+  int split_p, ntiles, M, cout, relu;
+  const float* scale;
+  const float* shift;
+  float alpha;
+};
+
 struct ConvArgs {
   const float* x;     // [B,H,W,c1]
   const float* x2;    // optional second source, channels [c1, c1+c2) of the logical input
@@ -61,6 +76,7 @@ struct ConvArgs {
   int ss_group_stride;     // floats between the scale (and shift) blocks of the weight groups (0: one block for all)
   int group_valid_rows;    // grouped GEMM: rows of each group that hold data, the rest up to the group's whole tiles being zero padding
                            // (Winograd positions: tiles before padding); 0 = unknown / all.  A kernel may skip work on the padding.
+  DeferredSplit* defer;    // optional: the launcher may skip its split-K reduce and describe the partial tiles here (see DeferredSplit)
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)48 << 20;   // 192 MiB: 768 partial 256x256 tiles (the stream-K tail of the persistent 256 x 256 kernel: up to 3 fragments for each of < 256 tail tiles)
@@ -108,7 +124,12 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, 
 // x [B,H,W,C] -> V [36][m_pad][C] fp32
 // m_pad_total > 0: the rows of a position are shared by several tensors (the five RPN levels as one grouped GEMM): V / Mb point at this
 // tensor's first tile, positions are m_pad_total rows apart
-int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran = 128, int m = 4, long long m_pad_total = 0);
+// df (optional, valid): x was not written -- the transform sums the producer's split-K partial tiles itself (DeferredSplit)
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran = 128, int m = 4, long long m_pad_total = 0,
+                      const DeferredSplit* df = nullptr);
+// whether that transform of an input [B,H,W,C] can read deferred split-K partials (the small-problem variants only)
+bool wino_input_accepts_deferred(int B, int H, int W, int C, int dil, int gran, int m);
+long long wino_deferred_count();      // transforms launched with deferred input so far (process-wide; test hook)
 // Mb [36][m_pad][C] -> y [B,H,W,C] = relu(scale * (A^T M A) + shift + res)
 int launch_wino_output(const float* Mb, const float* scale, const float* shift, const float* res, float* y,
                        int B, int H, int W, int C, int dil, int relu, hipStream_t s, int gran = 128, int m = 4, long long m_pad_total = 0);

@@ -56,6 +56,7 @@ struct ConvKParams {
   float* dump;                // conv_pw_glds256wp_kernel: one 256 x 256 tile of scratch behind the partial tiles (target of a workgroup's first, empty epilogue)
   int stagger;                // conv_pw_glds256wp_kernel: spread of the workgroups' start times, in sleeps of ~3.4 us (option pw256wp_stagger)
   int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*
+  DeferredSplit* defer;       // HOST pointer, never read on the device: launch_with_tail_split may skip its reduce and fill it (common.h)
 };
 
 template <int I>
@@ -375,7 +376,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKPara
     const int ss_off = (p.mt_per_group && p.ss_group_stride) ? (mt / p.mt_per_group) * p.ss_group_stride : 0;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + ss_off + n) * p.alpha;
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + ss_off + n);
-    v = v * sc + sh;
+    // one fused multiply-add per channel, spelled out (what `v * sc + sh` compiled to anyway): the Winograd input transforms that sum
+    // a producer's partial tiles themselves (winograd.hip: deferred_pixel) must reproduce this value bit for bit, whatever hipcc's
+    // contraction decides in either instantiation (round 6: the f32x4 instantiation there had decided differently)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
     const size_t o = (size_t)m * p.cout + n;
     if (vec_ok) {
       if (n < p.cout) {
@@ -432,8 +437,22 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
   p.mtiles = mtiles;
   p.nchunk = (int)opt(OPT_NCHUNK);
   p.res_prefetch = opt(OPT_RES_PREFETCH) != 0;
+  // every tile split, 128 x 128 tiles in the plain order, no residual, one weight group: the consumer may sum the partial tiles itself
+  bool deferred = false;
+  if (p.defer) {
+    DeferredSplit* df = p.defer;
+    if (BM == 128 && BN == 128 && t > 0 && t == T && !p.res && p.mt_per_group == 0 && p.cout % 128 == 0 &&
+        !(p.nchunk > 0 && p.ntiles > p.nchunk)) {
+      df->valid = true;
+      df->partial = ws; df->split_p = sp; df->ntiles = p.ntiles; df->M = p.M; df->cout = p.cout; df->relu = p.relu;
+      df->scale = p.scale; df->shift = p.shift; df->alpha = p.alpha;
+      deferred = true;
+    }
+    p.defer = nullptr;
+  }
   hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(NT), 0, stream, p);
-  if (t > 0) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
+  static const bool keep_reduce = getenv("PEANUT_DEFER_KEEP_REDUCE") != nullptr;      // debugging aid: write the output tensor as well
+  if (t > 0 && (!deferred || keep_reduce)) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));
   return 0;

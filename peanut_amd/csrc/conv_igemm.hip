@@ -350,6 +350,8 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.flush = (d.rs && !rs_fallback) ? 0 : d.flush_ch / d.bk;   // k-tiles per partial sum (conv_pw.hip; every other kernel keeps one running sum)
   p.mt_per_group = a.mt_per_group; p.w_group_stride = (long long)a.w_group_stride; p.ss_group_stride = a.ss_group_stride;
   p.group_valid = a.mt_per_group ? a.group_valid_rows : 0;
+  if (a.defer) a.defer->valid = false;      // set by launch_with_tail_split alone, when it left its partial tiles unsummed
+  p.defer = a.defer;
   if (d.rs && !rs_fallback) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
     if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");
     p.w = static_cast<const float*>(d.w_s);

@@ -390,17 +390,30 @@ inline void wino_scratch_floats(const ConvLayer& L, int B, int H, int W, size_t*
   *m = (size_t)L.wino_np() * m_pad * L.d.cout;
 }
 
+// whether this layer, run by launch_conv_layer on an input [B,H,W,*], can sum a producer's deferred split-K partial tiles
+inline bool conv_layer_accepts_deferred(const ConvLayer& L, int B, int H, int W) {
+  if (!L.has_wino || L.d.rs || L.wino.rs) return false;
+  return wino_input_accepts_deferred(B, H, W, L.d.cin, L.d.dil, wino_gran_for(L, B, H, W), L.wino_m);
+}
+
 // One conv layer, as Winograd (input transform -> grouped GEMM -> output transform) when the layer carries
 // that form and scratch is supplied, else as the direct kernel.
-inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_v, float* wino_m, hipStream_t s) {
-  if (!(L.has_wino && !a.x2 && wino_v && wino_m)) return launch_conv(L.d, a, s);
+// `produced`: what the layer that wrote a.x left behind when it skipped its split-K reduce (common.h: DeferredSplit); consumed here.
+inline int launch_conv_layer(const ConvLayer& L, const ConvArgs& a, float* wino_v, float* wino_m, hipStream_t s, DeferredSplit* produced = nullptr) {
+  const bool deferred_in = produced && produced->valid;
+  if (!(L.has_wino && !a.x2 && wino_v && wino_m)) {
+    if (deferred_in) return fail(PEANUT_EINVAL, L.name + ": the producer deferred its split-K reduce to a layer that cannot sum it");
+    return launch_conv(L.d, a, s);
+  }
   int th, tw, rc;
   long long n_tiles, m_pad;
   const int gran = wino_gran_for(L, a.B, a.H, a.W);
   wino_geometry(a.B, a.H, a.W, L.d.dil, &th, &tw, &n_tiles, &m_pad, gran, L.wino_m);
   const long long np = L.wino_np();
   if (np * m_pad > 0x7fffffffLL) return fail(PEANUT_EINVAL, L.name + ": Winograd problem too large");
-  if ((rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran, L.wino_m))) return rc;
+  rc = launch_wino_input(a.x, wino_v, a.B, a.H, a.W, L.d.cin, L.d.dil, s, gran, L.wino_m, 0, deferred_in ? produced : nullptr);
+  if (produced) produced->valid = false;
+  if (rc) return rc;
   ConvArgs g{};
   g.x = wino_v; g.y = wino_m;
   g.B = 1; g.H = 1; g.W = (int)(np * m_pad); g.c1 = L.d.cin; g.c2 = 0; g.Ho = 1; g.Wo = g.W;

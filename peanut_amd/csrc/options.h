@@ -22,7 +22,7 @@ enum OptionId {
   OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW256P_STREAMK, OPT_PW256WP_MINK, OPT_PW256WP_MINTILES, OPT_PW256WP_NPRE, OPT_PW256WP_STAGGER, OPT_PW_ARES,
   OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_PW_BN64_MAXK, OPT_PW64_MAXTILES, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
-  OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX,
+  OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX, OPT_WINO_SMALL_MAXWG, OPT_DEFER_SPLITK,
   OPT_PPM_OVERLAP, OPT_PPM_GROUPED, OPT_PPM_TERM_ROWS, OPT_PPM_GROUP_ROWS, OPT_RCNN_WINO_M, OPT_RCNN_STEM_S2D, OPT_RCNN_RPN_FUSED, OPT_RCNN_FPN_OVERLAP, OPT_RCNN_RANK_SORT, OPT_RCNN_TOPK_SLICE, OPT_RCNN_NMS_LEVELS, OPT_FMM_LOCAL32, OPT_FMM_MAX_PASSES, OPT_FMM_BLOCKED, OPT_FMM_INNER,
   OPT_COUNT
 };
@@ -76,6 +76,8 @@ inline const OptionInfo* option_table() {
       {"wino_flush_ch", 64, true, "channels per partial sum of the position GEMMs' two-level accumulation (0: off)"},
       {"wino_min_cin", 0, true, "fewest input channels of a Winograd layer (0: the planner's policy)"},
       {"wino_narrow_minpix", 100000, false, "layers under 128 channels take their Winograd form from this many input pixels on"},
+      {"wino_small_maxwg", 1024, false, "Winograd transforms: launches with fewer workgroups than this of the one-thread-per-tile kernels take the small-problem variants (a workgroup per tile and 64-channel slice, a thread per line, through LDS; bit-identical; 0: never)"},
+      {"defer_splitk", 1, false, "a Bottleneck conv1 whose every tile is split along k leaves its partial tiles unsummed and conv2's (small-problem) Winograd input transform sums them: one launch fewer per block at batch 1, bit-identical (0: every conv runs its own reduce); read when a (B, H, W) plan is built"},
       {"ppm_overlap", -1, false, "pyramid branch of the PSP head on a side stream: 0 / 1, -1 = by size"},
       {"ppm_grouped", -1, false, "per-scale PSP GEMMs as one grouped launch: 0 / 1, -1 = by size"},
       {"ppm_term_rows", 1, false, "folded pyramid term: one wave per output row, no barrier in the row loop (0: the workgroup-wide two-phase kernel)"},

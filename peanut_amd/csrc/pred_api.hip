@@ -54,6 +54,8 @@ struct Op {
   // address scale s at row s * ppm_scale_rows
   int group_mt = 0;
   int ppm_scale_rows = 0;
+  bool defer_ok = false;       // OP_CONV: the next op is the Winograd input transform that alone reads this output and can sum split-K partial
+                               // tiles itself (common.h: DeferredSplit): this conv may skip its split-K reduce (round 6, option defer_splitk)
 };
 
 struct Plan {
@@ -80,6 +82,7 @@ struct peanut_conv {
 
 struct peanut_pred {
   Options opts = default_options();   // this handle's tuning options (options.h): snapshot of the process defaults at creation
+  DeferredSplit deferred{};           // run time: handed from a conv1 that skipped its split-K reduce to the Winograd input transform behind it
   peanut_pred_cfg cfg{};
   int cin_pad = 0;
   std::vector<std::unique_ptr<ConvLayer>> convs;
@@ -355,7 +358,14 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
       push_conv(*pl, blk.c1, x, nullptr, nullptr, t1);
       const int h2 = conv_out_dim(x.H, 3, d2.stride, d2.pad, d2.dil), w2 = conv_out_dim(x.W, 3, d2.stride, d2.pad, d2.dil);
       Act t2 = make_act(ar, B, h2, w2, d2.cout);
+      const size_t c1_idx = pl->ops.size() - 1;
       push_conv(*pl, blk.c2, t1, nullptr, nullptr, t2, &ar);
+      {   // conv1's output is read by conv2 alone: its Winograd input transform may sum conv1's split-K partial tiles (common.h: DeferredSplit)
+        const Op& win = pl->ops[c1_idx + 1];
+        if (opt(OPT_DEFER_SPLITK) != 0 && !h->keep_all && win.kind == OP_WINO_IN && pl->ops[c1_idx].kind == OP_CONV && !win.conv->d.rs &&
+            wino_input_accepts_deferred(t1.B, t1.H, t1.W, t1.C, win.conv->d.dil, win.wino_gran, win.conv->wino_m))
+          pl->ops[c1_idx].defer_ok = true;
+      }
       rel(t1);
       Act idn = x;
       bool own_idn = false;
@@ -568,10 +578,15 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
         a.w_group_stride = op.conv->w.bytes / sizeof(float) / (size_t)h->cfg.n_pool_scales;
         a.ss_group_stride = op.conv->d.cout_pad;
       }
+      if (op.defer_ok) a.defer = &h->deferred;
       return launch_conv(op.conv->d, a, s);
     }
-    case OP_WINO_IN:
-      return launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran, op.conv->wino_m);
+    case OP_WINO_IN: {
+      const int rc = launch_wino_input(P(op.in), P(op.out), op.in.B, op.in.H, op.in.W, op.in.C, op.conv->d.dil, s, op.wino_gran, op.conv->wino_m, 0,
+                                       h->deferred.valid ? &h->deferred : nullptr);
+      h->deferred.valid = false;
+      return rc;
+    }
     case OP_WINO_GEMM: {
       ConvArgs a{};
       a.x = P(op.in); a.y = P(op.out);
@@ -607,7 +622,7 @@ extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
-int peanut_abi_version(void) { return 13; }
+int peanut_abi_version(void) { return 14; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 #ifndef PEANUT_SOURCE_HASH
 #define PEANUT_SOURCE_HASH ""
@@ -996,6 +1011,8 @@ int peanut_debug_weight_pieces(const float* values, int n, int precision, unsign
       pieces[(size_t)q * n + c] = q < np ? o[((size_t)(c / 16) * np + q) * bn * 16 + (c % 16)] : (unsigned short)0;
   return 0;
 }
+
+long long peanut_debug_deferred_splitk_count(void) { return wino_deferred_count(); }
 
 int peanut_debug_wino_weights(const float* w_oihw, int cout, int cin, int tile, float* out) {
   if (!w_oihw || !out || cout < 1 || cin < 1 || tile < 4 || tile > 6) return fail(PEANUT_EINVAL, "peanut_debug_wino_weights: bad arguments");

@@ -375,6 +375,13 @@ std::unique_ptr<RPlan> build_rplan(const peanut_rcnn* h, int B, int H, int W) {
       push_rconv(*pl, ar, blk.c1, cur, nullptr, t1);
       Act t2 = conv_out_act(ar, blk.c2, t1);
       push_rconv(*pl, ar, blk.c2, t1, nullptr, t2);
+      {   // conv1's output is read by conv2 alone: conv2's input transform may sum conv1's split-K partial tiles (common.h: DeferredSplit)
+        ROp& o2 = pl->ops[pl->ops.size() - 1];
+        ROp& o1 = pl->ops[pl->ops.size() - 2];
+        if (opt(OPT_DEFER_SPLITK) != 0 && o2.has_wino && o1.conv == blk.c1 && !o1.has_res && o1.ext_slot < 0 &&
+            conv_layer_accepts_deferred(*o2.conv, t1.B, t1.H, t1.W))
+          o1.defer_ok = true;
+      }
       rel(t1);
       Act y = conv_out_act(ar, blk.c3, t2);
       if (blk.c3s) {                                    // [t2 | x] x [W3'; Ws'] + shifts, ReLU: conv3 and the shortcut in one GEMM
@@ -647,6 +654,7 @@ static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
   }
   bool side_pending = false;
   size_t op_index = 0;
+  DeferredSplit deferred{};        // handed from a conv1 that skipped its split-K reduce to the conv2 right behind it
   for (const auto& op : pl->ops) {
     const bool skip = (op.kind == R_RPN_FUSED && !rpn_fused) || (op.rpn_level && rpn_fused);
     if (op.join_side && side_pending) {
@@ -722,7 +730,9 @@ static int rcnn_front_impl(peanut_rcnn_t* h, const uint8_t* img_bgr, int B, int 
           a.ws = P(pl->splitk_side); a.ws_floats = kSplitKSideFloats;
           side_pending = true;
         }
-        if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, os))) return rc;
+        DeferredSplit* produced = deferred.valid ? &deferred : nullptr;     // (the previous op's, consumed by this one)
+        if (op.defer_ok && !produced) a.defer = &deferred;
+        if ((rc = launch_conv_layer(*op.conv, a, op.has_wino ? P(op.wino_v) : nullptr, op.has_wino ? P(op.wino_m) : nullptr, os, produced))) return rc;
         break;
       }
       case R_MAXPOOL:

@@ -21,6 +21,8 @@ struct ROp {
   bool rpn_level = false;     // one of the fifteen per-level RPN-head launches: skipped when the fused form (R_RPN_FUSED) runs
   bool side = false;          // FPN output conv of p3..p5: may run on the handle's side stream next to the top-down chain (round 5)
   bool join_side = false;     // the first op that reads a side op's output: the main stream waits for the side stream before it
+  bool defer_ok = false;      // R_CONV: the next op is the Winograd layer that alone reads this output and can sum split-K partial tiles itself
+                              // (common.h: DeferredSplit): this op may skip its split-K reduce (round 6, option defer_splitk)
 };
 
 // The RPN head on all five pyramid levels as ONE chain (round 5): the shared 3x3 conv as Winograd with the levels' tiles side by

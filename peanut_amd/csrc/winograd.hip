@@ -20,6 +20,8 @@
 // convolutions (5e-6, |logit| <= 6.4); contract 1e-3.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "conv_common.h"
 
@@ -479,6 +481,267 @@ __global__ __launch_bounds__(256) void wino5_output_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small-problem variants (round 6).  The kernels above give one thread a whole tile of a channel group: 64 (36) loads, the
+// whole two-sided transform, 64 (36) stores -- a serial chain of ~8-10 us whatever the size, and a batch-1 layer has few such
+// threads (one detector frame's res4 conv2: 108 tiles x 128 channel pairs = 54 workgroups on 256 CUs).  One detector frame
+// runs 86 transforms, one 720 x 720 map 36: 0.84 ms of a 5.47 ms frame, 0.45 ms of a 3.4 ms map (profiles/r8z).
+// Here a WORKGROUP takes one tile of 64 (128) channels and a thread one LINE of it: stage 1 the first-side transform of one
+// column (input) / one row of positions (output), through LDS, stage 2 the second-side transform of one row / one output
+// column.  8 (6) times the threads, an eighth (sixth) of the chain each.  The same bt8 / at8 / bt6 / at6 on the same
+// operands in the same order: bit-identical to the kernels above (tests/test_conv_gpu.py holds the two to torch.equal).
+// ---------------------------------------------------------------------------------------------------------------
+// What a deferred producer left behind (common.h: DeferredSplit), as a kernel argument.  pixel_value() is the reduce kernel's
+// expression (conv_common.h: conv_splitk_reduce_kernel) for the VEC channels starting at channel n of pixel row m: partial tiles
+// summed in part order, times scale * alpha, plus shift, ReLU.
+struct DeferredSrc {
+  const float* partial;
+  const float* scale;
+  const float* shift;
+  float alpha;
+  int split_p, ntiles, relu;
+};
+// SP: the number of parts when it is 2 or 4 (all loads of a pixel then leave together), 0 = any (a loop)
+template <typename VT, int SP>
+__device__ __forceinline__ VT deferred_pixel(const DeferredSrc& df, long long m, int n) {
+  const int mt = (int)(m >> 7), row = (int)(m & 127), nt = n >> 7, col = n & 127;
+  const int parts = SP ? SP : df.split_p;
+  const float* base = df.partial + ((size_t)(mt * df.ntiles + nt) * parts) * (128 * 128) + row * 128 + col;
+  VT v;
+  if constexpr (SP != 0) {
+    VT part[SP];
+#pragma unroll
+    for (int s = 0; s < SP; ++s) part[s] = *reinterpret_cast<const VT*>(base + (size_t)s * (128 * 128));
+    v = part[0];
+#pragma unroll
+    for (int s = 1; s < SP; ++s) v += part[s];
+  } else {
+    v = *reinterpret_cast<const VT*>(base);
+    for (int s = 1; s < parts; ++s) v += *reinterpret_cast<const VT*>(base + (size_t)s * (128 * 128));
+  }
+  const VT sc = *reinterpret_cast<const VT*>(df.scale + n) * df.alpha;
+  const VT sh = *reinterpret_cast<const VT*>(df.shift + n);
+  // one fused multiply-add per channel, spelled out: what conv_splitk_reduce_kernel's `v * sc + sh` compiles to (v_pk_fma_f32)
+  constexpr int NV = (int)(sizeof(VT) / sizeof(float));
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    float t = __builtin_fmaf(v[e], sc[e], sh[e]);
+    if (df.relu) t = relu_keep_nan(t);
+    v[e] = t;
+  }
+  return v;
+}
+
+// DEFER: -1 = the input tensor is read; 0 / 2 / 4 = the producer's split-K partial tiles are summed (any number of parts / exactly 2 / 4)
+template <int LANES, int DEFER>
+__global__ __launch_bounds__(8 * LANES) void wino6_input_small_kernel(const float* __restrict__ x, float* __restrict__ V, const WinoGeom g, const DeferredSrc df) {
+  __shared__ f32x2 u[8][8][LANES];
+  const int l = threadIdx.x % LANES, a = threadIdx.x / LANES;      // a: the column (stage 1), then the row (stage 2)
+  const int slices = g.C / (2 * LANES);
+  const long long tile = blockIdx.x / slices;
+  const int cg = (int)(blockIdx.x % slices) * LANES + l;
+  int b, oy, ox, ty, tx;
+  decode_tile(g, tile, b, oy, ox, ty, tx);
+  const int r0 = oy + g.d * (6 * ty - 1), c0 = ox + g.d * (6 * tx - 1);
+  const float* xb = x + (size_t)b * g.H * g.W * g.C + cg * 2;
+  {
+    const int c = c0 + a * g.d;
+    const bool cok = (unsigned)c < (unsigned)g.W;
+    f32x2 p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + i * g.d;
+      f32x2 v = {0.f, 0.f};
+      if (cok && (unsigned)r < (unsigned)g.H) {
+        if constexpr (DEFER >= 0) v = deferred_pixel<f32x2, DEFER>(df, ((long long)b * g.H + r) * g.W + c, cg * 2);
+        else v = *reinterpret_cast<const f32x2*>(xb + ((size_t)r * g.W + c) * g.C);
+      }
+      p[i] = v;
+    }
+    bt8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);      // column a: p <- B^T p
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i][a][l] = p[i];
+  }
+  __syncthreads();
+  f32x2 q[8], t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = u[a][j][l];
+  bt8(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);          // row a: (p B)[a][:]
+  const size_t pos_stride = (size_t)g.m_pad * g.C;
+  float* o = V + (size_t)tile * g.C + cg * 2 + (size_t)(a * 8) * pos_stride;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x2*>(o + j * pos_stride) = t[j];
+}
+
+template <bool RES, int LANES>
+__global__ __launch_bounds__(8 * LANES) void wino6_output_small_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, const float* __restrict__ res,
+                                                                      float* __restrict__ y, const WinoGeom g, int relu) {
+  __shared__ f32x2 qs[8][6][LANES];
+  const int l = threadIdx.x % LANES, a = threadIdx.x / LANES;      // a: the row of positions (stage 1), then the output column (stage 2)
+  const int slices = g.C / (2 * LANES);
+  const long long tile = blockIdx.x / slices;
+  const int ng = (int)(blockIdx.x % slices) * LANES + l;
+  int b, oy, ox, ty, tx;
+  decode_tile(g, tile, b, oy, ox, ty, tx);
+  const int r0 = oy + g.d * 6 * ty, c0 = ox + g.d * 6 * tx;
+  if (r0 >= g.H || c0 >= g.W) return;                               // tile entirely outside its sub-grid (the whole workgroup leaves)
+  const size_t pos_stride = (size_t)g.m_pad * g.C;
+  {
+    const float* sp = Mb + (size_t)tile * g.C + ng * 2 + (size_t)(a * 8) * pos_stride;
+    f32x2 m[8], q[6];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(sp + j * pos_stride));
+    at8(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], q[0], q[1], q[2], q[3], q[4], q[5]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) qs[a][j][l] = q[j];
+  }
+  __syncthreads();
+  if (a >= 6) return;
+  const int c = c0 + a * g.d;
+  const size_t img = (size_t)b * g.H * g.W;
+  f32x2 rc[6];
+  if constexpr (RES) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int r = r0 + k * g.d;
+      const bool ok = c < g.W && r < g.H;
+      const size_t off = ok ? (img + (size_t)r * g.W + c) * g.C + ng * 2 : 0;
+      rc[k] = *reinterpret_cast<const f32x2*>(res + off);
+    }
+  }
+  const f32x2 sc = *reinterpret_cast<const f32x2*>(scale + ng * 2);
+  const f32x2 sh = *reinterpret_cast<const f32x2*>(shift + ng * 2);
+  f32x2 o[6];
+  at8(qs[0][a][l], qs[1][a][l], qs[2][a][l], qs[3][a][l], qs[4][a][l], qs[5][a][l], qs[6][a][l], qs[7][a][l], o[0], o[1], o[2], o[3], o[4], o[5]);
+  if (c >= g.W) return;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int r = r0 + k * g.d;
+    if (r >= g.H) continue;
+    const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 2;
+    f32x2 v = o[k] * sc + sh;
+    if constexpr (RES) v += rc[k];
+    if (relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); }
+    *reinterpret_cast<f32x2*>(y + off) = v;
+  }
+}
+
+// F(4x4): a workgroup = one tile x LANES 4-channel groups, 6 lines
+template <int LANES, int DEFER>
+__global__ __launch_bounds__(6 * LANES) void wino4_input_small_kernel(const float* __restrict__ x, float* __restrict__ V, const WinoGeom g, const DeferredSrc df) {
+  __shared__ f32x4 u[6][6][LANES];
+  const int l = threadIdx.x % LANES, a = threadIdx.x / LANES;
+  const int slices = g.C / (4 * LANES);
+  const long long tile = blockIdx.x / slices;
+  const int cg = (int)(blockIdx.x % slices) * LANES + l;
+  int b, oy, ox, ty, tx;
+  decode_tile(g, tile, b, oy, ox, ty, tx);
+  const int r0 = oy + g.d * (4 * ty - 1), c0 = ox + g.d * (4 * tx - 1);
+  const float* xb = x + (size_t)b * g.H * g.W * g.C + cg * 4;
+  {
+    const int c = c0 + a * g.d;
+    const bool cok = (unsigned)c < (unsigned)g.W;
+    f32x4 p[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int r = r0 + i * g.d;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cok && (unsigned)r < (unsigned)g.H) {
+        if constexpr (DEFER >= 0) v = deferred_pixel<f32x4, DEFER>(df, ((long long)b * g.H + r) * g.W + c, cg * 4);
+        else v = *reinterpret_cast<const f32x4*>(xb + ((size_t)r * g.W + c) * g.C);
+      }
+      p[i] = v;
+    }
+    bt6(p[0], p[1], p[2], p[3], p[4], p[5], p[0], p[1], p[2], p[3], p[4], p[5]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) u[i][a][l] = p[i];
+  }
+  __syncthreads();
+  f32x4 t0, t1, t2, t3, t4, t5;
+  bt6(u[a][0][l], u[a][1][l], u[a][2][l], u[a][3][l], u[a][4][l], u[a][5][l], t0, t1, t2, t3, t4, t5);
+  const size_t pos_stride = (size_t)g.m_pad * g.C;
+  float* o = V + (size_t)tile * g.C + cg * 4 + (size_t)(a * 6) * pos_stride;
+  *reinterpret_cast<f32x4*>(o) = t0;
+  *reinterpret_cast<f32x4*>(o + pos_stride) = t1;
+  *reinterpret_cast<f32x4*>(o + 2 * pos_stride) = t2;
+  *reinterpret_cast<f32x4*>(o + 3 * pos_stride) = t3;
+  *reinterpret_cast<f32x4*>(o + 4 * pos_stride) = t4;
+  *reinterpret_cast<f32x4*>(o + 5 * pos_stride) = t5;
+}
+
+template <bool RES, int LANES>
+__global__ __launch_bounds__(6 * LANES) void wino4_output_small_kernel(const float* __restrict__ Mb, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, const float* __restrict__ res,
+                                                                      float* __restrict__ y, const WinoGeom g, int relu) {
+  __shared__ f32x4 qs[6][4][LANES];
+  const int l = threadIdx.x % LANES, a = threadIdx.x / LANES;
+  const int slices = g.C / (4 * LANES);
+  const long long tile = blockIdx.x / slices;
+  const int ng = (int)(blockIdx.x % slices) * LANES + l;
+  int b, oy, ox, ty, tx;
+  decode_tile(g, tile, b, oy, ox, ty, tx);
+  const int r0 = oy + g.d * 4 * ty, c0 = ox + g.d * 4 * tx;
+  if (r0 >= g.H || c0 >= g.W) return;
+  const size_t pos_stride = (size_t)g.m_pad * g.C;
+  {
+    const float* sp = Mb + (size_t)tile * g.C + ng * 4 + (size_t)(a * 6) * pos_stride;
+    const f32x4 m0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp));
+    const f32x4 m1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + pos_stride));
+    const f32x4 m2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + 2 * pos_stride));
+    const f32x4 m3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + 3 * pos_stride));
+    const f32x4 m4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + 4 * pos_stride));
+    const f32x4 m5 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + 5 * pos_stride));
+    f32x4 q0, q1, q2, q3;
+    at6(m0, m1, m2, m3, m4, m5, q0, q1, q2, q3);
+    qs[a][0][l] = q0; qs[a][1][l] = q1; qs[a][2][l] = q2; qs[a][3][l] = q3;
+  }
+  __syncthreads();
+  if (a >= 4) return;
+  const int c = c0 + a * g.d;
+  const size_t img = (size_t)b * g.H * g.W;
+  f32x4 rc[4];
+  if constexpr (RES) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + k * g.d;
+      const bool ok = c < g.W && r < g.H;
+      const size_t off = ok ? (img + (size_t)r * g.W + c) * g.C + ng * 4 : 0;
+      rc[k] = *reinterpret_cast<const f32x4*>(res + off);
+    }
+  }
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ng * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ng * 4);
+  f32x4 o0, o1, o2, o3;
+  at6(qs[0][a][l], qs[1][a][l], qs[2][a][l], qs[3][a][l], qs[4][a][l], qs[5][a][l], o0, o1, o2, o3);
+  if (c >= g.W) return;
+  const f32x4 o[4] = {o0, o1, o2, o3};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + k * g.d;
+    if (r >= g.H) continue;
+    const size_t off = (img + (size_t)r * g.W + c) * g.C + ng * 4;
+    f32x4 v = o[k] * sc + sh;
+    if constexpr (RES) v += rc[k];
+    if (relu) v = relu_keep_nan(v);
+    *reinterpret_cast<f32x4*>(y + off) = v;
+  }
+}
+
+// Which launches take the small-problem variants: fewer workgroups of the one-thread-per-tile kernels than wino_small_maxwg
+// (options.h; default 1024 = four per CU -- above that those kernels stream at 5-6 TB/s and are the better form), whole 64-channel
+// slices, and a grid that fits.  F(5x5) has no small variant (dilation-4 layers of 480 x 480 maps only).
+int wino_small_lanes(long long n_tiles, int C, int m) {
+  const long long maxwg = opt(OPT_WINO_SMALL_MAXWG);
+  if (maxwg <= 0 || (m != 4 && m != 6)) return 0;
+  const long long big_wgs = (n_tiles * (m == 4 ? C / 4 : C / 2) + 255) / 256;
+  if (big_wgs >= maxwg) return 0;
+  const int per32 = m == 4 ? 128 : 64, per16 = per32 / 2;
+  const int lanes = C % per32 == 0 ? 32 : (C % per16 == 0 ? 16 : 0);
+  if (!lanes || n_tiles * (C / (lanes * (m == 4 ? 4 : 2))) > 0x7fffffffLL) return 0;
+  return lanes;
+}
+
 int grid_for(long long total) {
   long long blocks = (total + 255) / 256;
   if (blocks > 256LL * 64) blocks = 256LL * 64;
@@ -535,13 +798,47 @@ void wino_transform_weights(const float* w_oihw, int cout, int cin, float* out, 
     }
 }
 
-int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran, int m, long long m_pad_total) {
+static std::atomic<long long> g_deferred_count{0};
+long long wino_deferred_count() { return g_deferred_count.load(std::memory_order_relaxed); }
+
+bool wino_input_accepts_deferred(int B, int H, int W, int C, int dil, int gran, int m) {
+  if (C % 4 || m < 4 || m > 6 || C % 128 != 0) return false;      // (the producer's 128-wide n-tiles are whole)
+  int th, tw;
+  long long n_tiles, m_pad;
+  wino_geometry(B, H, W, dil, &th, &tw, &n_tiles, &m_pad, gran, m);
+  return wino_small_lanes(n_tiles, C, m) != 0;
+}
+
+int launch_wino_input(const float* x, float* V, int B, int H, int W, int C, int dil, hipStream_t s, int gran, int m, long long m_pad_total,
+                      const DeferredSplit* df) {
   if (C % 4 || m < 4 || m > 6) return fail(-2, "wino_input: channels must be a multiple of 4, tiles 4x4, 5x5 or 6x6");
   WinoGeom g{B, H, W, C, dil, 0, 0, 0, 0};
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
   if (m_pad_total > 0) g.m_pad = m_pad_total;     // this tensor's tiles are a sub-range of a position's rows (V already points at its first tile)
   const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
-  if (m == 6) hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
+  const bool defer = df && df->valid;
+  DeferredSrc src{};
+  if (defer) {
+    if (df->cout != C || (long long)df->M != (long long)B * H * W || !wino_small_lanes(g.n_tiles, C, m))
+      return fail(-2, "wino_input: deferred split-K partials do not match this transform");
+    src = DeferredSrc{df->partial, df->scale, df->shift, df->alpha, df->split_p, df->ntiles, df->relu};
+    g_deferred_count.fetch_add(1, std::memory_order_relaxed);
+  }
+  if (const int lanes = wino_small_lanes(g.n_tiles, C, m)) {
+    const unsigned grid = (unsigned)(g.n_tiles * (C / (lanes * (m == 4 ? 4 : 2))));
+#define PEANUT_WINO_SMALL_IN(K, L, T)                                                                          \
+    do {                                                                                                       \
+      if (defer && src.split_p == 4) hipLaunchKernelGGL((K<L, 4>), dim3(grid), dim3(T), 0, s, x, V, g, src);   \
+      else if (defer && src.split_p == 2) hipLaunchKernelGGL((K<L, 2>), dim3(grid), dim3(T), 0, s, x, V, g, src); \
+      else if (defer) hipLaunchKernelGGL((K<L, 0>), dim3(grid), dim3(T), 0, s, x, V, g, src);                  \
+      else hipLaunchKernelGGL((K<L, -1>), dim3(grid), dim3(T), 0, s, x, V, g, src);                            \
+    } while (0)
+    if (m == 6 && lanes == 32) PEANUT_WINO_SMALL_IN(wino6_input_small_kernel, 32, 256);
+    else if (m == 6) PEANUT_WINO_SMALL_IN(wino6_input_small_kernel, 16, 128);
+    else if (lanes == 32) PEANUT_WINO_SMALL_IN(wino4_input_small_kernel, 32, 192);
+    else PEANUT_WINO_SMALL_IN(wino4_input_small_kernel, 16, 96);
+#undef PEANUT_WINO_SMALL_IN
+  } else if (m == 6) hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   else if (m == 5) hipLaunchKernelGGL(wino5_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   else hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, V, g);
   hipError_t e = hipGetLastError();
@@ -556,7 +853,15 @@ int launch_wino_output(const float* Mb, const float* scale, const float* shift, 
   wino_geometry(B, H, W, dil, &g.th, &g.tw, &g.n_tiles, &g.m_pad, gran, m);
   if (m_pad_total > 0) g.m_pad = m_pad_total;
   const long long total = g.n_tiles * (m == 4 ? C / 4 : C / 2);
-  if (m == 6 && res) hipLaunchKernelGGL(wino6_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
+  if (const int lanes = wino_small_lanes(g.n_tiles, C, m)) {
+    const unsigned grid = (unsigned)(g.n_tiles * (C / (lanes * (m == 4 ? 4 : 2))));
+#define PEANUT_WINO_SMALL_OUT(K, R, L, T) hipLaunchKernelGGL((K<R, L>), dim3(grid), dim3(T), 0, s, Mb, scale, shift, res, y, g, relu)
+    if (m == 6 && lanes == 32) { if (res) PEANUT_WINO_SMALL_OUT(wino6_output_small_kernel, true, 32, 256); else PEANUT_WINO_SMALL_OUT(wino6_output_small_kernel, false, 32, 256); }
+    else if (m == 6) { if (res) PEANUT_WINO_SMALL_OUT(wino6_output_small_kernel, true, 16, 128); else PEANUT_WINO_SMALL_OUT(wino6_output_small_kernel, false, 16, 128); }
+    else if (lanes == 32) { if (res) PEANUT_WINO_SMALL_OUT(wino4_output_small_kernel, true, 32, 192); else PEANUT_WINO_SMALL_OUT(wino4_output_small_kernel, false, 32, 192); }
+    else { if (res) PEANUT_WINO_SMALL_OUT(wino4_output_small_kernel, true, 16, 96); else PEANUT_WINO_SMALL_OUT(wino4_output_small_kernel, false, 16, 96); }
+#undef PEANUT_WINO_SMALL_OUT
+  } else if (m == 6 && res) hipLaunchKernelGGL(wino6_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   else if (m == 6) hipLaunchKernelGGL(wino6_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   else if (m == 5) hipLaunchKernelGGL(wino5_output_kernel, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);
   else if (res) hipLaunchKernelGGL(wino_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, Mb, scale, shift, res, y, g, relu);

@@ -890,6 +890,49 @@ def test_winograd_6x6_tiles_match_torch(precision, tile):
     print(f"F({tile}x{tile},3x3) {precision}: worst relative error over {len(cases)} layers {worst:.3e}")
 
 
+@pytest.mark.parametrize("tile", [6, 4])
+def test_small_problem_winograd_transforms_are_bit_identical(tile):
+    """Round 6: the Winograd transforms of small launches (a batch-1 detector frame, one 720 x 720 map) run as a workgroup per
+    tile and 64-channel slice with a thread per line, through LDS (csrc/winograd.hip: wino{6,4}_*_small_kernel) instead of one
+    thread per tile and channel group.  Same bt / at helpers on the same operands in the same order: the layer must come out
+    bit for bit the same with the variants forced on (wino_small_maxwg = 2^30) and off (0) -- dilation 1 / 2 / 4, maps that do
+    not divide into whole tiles, both lane widths (64- / 128-channel slices and their halves), with and without a residual
+    and ReLU -- and agree with F.conv2d."""
+    from peanut_amd.ops import FusedConv
+    cases = [  # B, H, W, cin, cout, dilation, relu, residual
+        (1, 50, 67, 256, 256, 1, True, False),       # detector res4 conv2 at batch 1
+        (1, 25, 34, 512, 512, 1, True, False),       # res5
+        (1, 90, 90, 128, 128, 1, True, False),       # one 720 x 720 map, layer2
+        (1, 45, 45, 256, 256, 2, True, False),       # dilation 2, odd sub-grids
+        (2, 23, 31, 64, 192, 1, False, True),        # 64-channel input (the narrow lane width), residual
+        (1, 37, 29, 192, 320, 4, True, True),        # dilation 4, channels that are multiples of 64 but not of 128
+        (3, 7, 5, 128, 64, 1, False, False),         # maps smaller than two tiles
+    ]
+    for case in cases:
+        B, H, W, cin, cout, d, relu, residual = case
+        g = torch.Generator().manual_seed(H * 1009 + W * 31 + cin + cout + d + tile)
+        x = _rand((B, cin, H, W), g)
+        w = _rand((cout, cin, 3, 3), g, (2.0 / (cin * 9)) ** 0.5)
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = _rand((cout,), g, 0.1)
+        ref = F.conv2d(x, w, None, padding=d, dilation=d) * scale[None, :, None, None] + shift[None, :, None, None]
+        res = _rand(tuple(ref.shape), g) if residual else None
+        if residual:
+            ref = ref + res
+        if relu:
+            ref = F.relu(ref)
+        rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda()
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        ys = []
+        for maxwg in (1 << 30, 0):
+            conv = FusedConv(w, scale, shift, padding=d, dilation=d, relu=relu, options={"wino_m": tile, "wino_small_maxwg": maxwg})
+            ys.append(conv(xd, residual=rd))
+            del conv
+        assert torch.equal(ys[0], ys[1]), case
+        err = ((ys[0].permute(0, 3, 1, 2).cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        assert err <= 4e-4, f"{case}: {err:.3e}"
+
+
 def test_two_level_accumulation_lowers_the_winograd_error():
     """The position GEMMs of the fp32 Winograd forms move their running sums into a second accumulator set every 64
     channels (csrc/conv_common.h: PEANUT_FLUSH_*; csrc/net_common.h: wino_flush_channels) -- the partial sums stay small,

@@ -865,6 +865,35 @@ def test_deployed_720_window_matches_reference_golden(golden_dir, precision):
     assert err <= TOL
 
 
+@pytest.mark.parametrize("size", [720, 240, 250])
+def test_conv1_split_k_summed_by_the_winograd_input_transform_is_bit_identical(size):
+    """Round 6 (option defer_splitk, csrc/common.h DeferredSplit): at batch 1 a Bottleneck's conv1 has fewer 128 x 128 tiles than
+    the chip has CUs, every tile is cut along k, and the partial tiles used to be summed by a reduce launch of their own; now the
+    small-problem Winograd input transform of conv2 sums them while it loads (the reduce kernel's expression in its order) and
+    conv1's output tensor is never written.  One 720 x 720 map (the agent's window), one 240 x 240 map (config 1) and an odd
+    size: logits bit-identical to a handle with the option off, and the library's counter shows the fused transforms ran."""
+    from bench import synth_maps
+    from peanut_amd import _lib
+    from peanut_amd.prediction import PEANUT_Prediction_Model
+    from peanut_amd.weights import PredCfg, make_seeded_state_dict
+    cfg = PredCfg()
+    sd = make_seeded_state_dict(cfg, 0)
+    x = synth_maps(1, cfg.in_channels, size, "cpu", seed0=31 + size).cuda()
+    lib = _lib.load()
+    on = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg)
+    off = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=sd, cfg=cfg, options={"defer_splitk": 0})
+    n0 = lib.peanut_debug_deferred_splitk_count()
+    y_off = off.get_prediction_batch(x, apply_sigmoid=False)
+    assert lib.peanut_debug_deferred_splitk_count() == n0
+    y_on = on.get_prediction_batch(x, apply_sigmoid=False)
+    fused = lib.peanut_debug_deferred_splitk_count() - n0
+    print(f"{size} x {size}, batch 1: {fused} Winograd input transforms summed their producer's split-K partial tiles")
+    assert fused >= 3, fused                      # (720: layer2.1-3 and layer3.0-5 conv1; 240: layer2 / layer3 / layer4)
+    assert torch.equal(y_on, y_off)
+    assert torch.equal(on.get_prediction_batch(x, apply_sigmoid=False), y_on)      # and again (scratch reuse across calls)
+    del on, off
+
+
 def test_distance_to_the_fp64_reference_at_480(golden_dir):
     """The benchmark's own input recipe at the headline size: one 480x480 map (bench.synth_maps, seed 4242) against
     the reference's model files run in float64 (sub-grid rows 1::4, cols 2::4 of the logits,

@@ -367,6 +367,42 @@ def test_fpn_output_convs_on_the_side_stream_change_nothing(small_net):
     del over, plain
 
 
+def test_conv1_split_k_summed_by_conv2s_input_transform_changes_nothing(small_net):
+    """Round 6 (option defer_splitk): in a batch-1 frame every Bottleneck conv1 of res3-res5 is cut along k in all of its tiles; its
+    partial tiles are now summed by conv2's (small-problem) Winograd input transform instead of a reduce launch of their own.
+    The pyramid, the RPN outputs, the detections and the semantic map are bit-identical to a handle with the option off -- on the
+    small test net (two 96 x 128 images) and on ONE 480 x 640 agent frame through R-101 -- and the library's counter shows the
+    fused transforms ran."""
+    from peanut_amd import _lib
+    from peanut_amd.rcnn import MaskRCNN
+    from peanut_amd.rcnn_weights import RcnnCfg, make_seeded_rcnn_state_dict
+    lib = _lib.load()
+    s = small_net
+    g = torch.Generator().manual_seed(5)
+    cases = [(s["cfg"], s["sd"], s["img"].cuda())]
+    big = RcnnCfg(score_thresh_test=0.5)
+    cases.append((big, make_seeded_rcnn_state_dict(big, 0), torch.randint(0, 256, (1, 480, 640, 3), generator=g, dtype=torch.uint8).cuda()))
+    for cfg, sd, img in cases:
+        with _lib.default_options(defer_splitk=1):
+            on = MaskRCNN(cfg, sd)
+        with _lib.default_options(defer_splitk=0):
+            off = MaskRCNN(cfg, sd)
+        n0 = lib.peanut_debug_deferred_splitk_count()
+        ref_front = off.forward_front(img)
+        ref_sem = off.semantic(img, cfg.num_classes, 0.5, 0.5, None)
+        assert lib.peanut_debug_deferred_splitk_count() == n0
+        fr = on.forward_front(img)
+        fused = lib.peanut_debug_deferred_splitk_count() - n0
+        print(f"{tuple(img.shape)}: {fused} input transforms summed their producer's split-K partial tiles")
+        if img.shape[0] == 1:
+            assert fused >= 25, fused             # R-101 at batch 1: res3 (4) + res4 (23) + res5 (3) blocks
+        for k, (xs, ys) in enumerate(zip(fr, ref_front)):
+            for x, y in zip(xs, ys):
+                assert torch.equal(x, y), k
+        assert torch.equal(on.semantic(img, cfg.num_classes, 0.5, 0.5, None), ref_sem)
+        del on, off
+
+
 def test_semantic_pred_maskrcnn_args_constructor(small_net, tmp_path):
     """segmentation.py:28-62 call surface: SemanticPredMaskRCNN(args).get_prediction(rgb) with a detectron2-format
     checkpoint on disk; the result equals the oracle detector + the reference's accumulation loop."""

@@ -1,5 +1,7 @@
 #!/bin/bash
-out=gpurun_out/r8g; mkdir -p $out
+# one detector frame at batch 1 under rocprofv3 --kernel-trace: launches, span, per-kernel totals, and the launch sequence of the
+# middle of the frame (a few res4 blocks).   tools/detector_timeline.sh [outdir]
+out=${1:-gpurun_out/r8g}; mkdir -p $out
 R=$PWD
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/tl_det
@@ -38,6 +40,15 @@ for seg in segs:
         busy += (e - s) / 1e3
         if i + 1 < len(seg): gaps += max(seg[i + 1][1] - e, 0) / 1e3
 print(f"per frame: launches {sum(v[0] for v in fam.values())/n:.0f} span {span/n:.1f} us busy {busy/n:.1f} gaps {gaps/n:.1f}")
-for k, v in sorted(fam.items(), key=lambda x: -x[1][1])[:28]:
+for k, v in sorted(fam.items(), key=lambda x: -x[1][1])[:32]:
     print(f"{v[1]/n:9.1f} us {v[0]/n:6.1f} x  {k}")
+seg = segs[-1]
+print("# launch sequence of the last frame, dispatches 100-135 (res4 blocks): dur_us gap_before_us workgroups kernel")
+rows = db.execute("select name,start,end,grid_x,workgroup_x from kernels order by start").fetchall()
+first = [i for i, r in enumerate(rows) if r[1] == seg[0][1]][0]
+prev = None
+for nm, st, en, gx, wx in rows[first + 100:first + 136]:
+    key = nm.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("peanut::", "")[:60]
+    print(f"{(en - st) / 1e3:8.1f} {((st - prev) / 1e3 if prev else 0):7.1f} {gx // max(wx, 1):6d}  {key}")
+    prev = en
 P
