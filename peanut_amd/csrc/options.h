@@ -75,7 +75,7 @@ inline const OptionInfo* option_table() {
       {"wino5_mindil", 4, true, "smallest dilation that also gets an F(5x5) form (0: none)"},
       {"wino_flush_ch", 64, true, "channels per partial sum of the position GEMMs' two-level accumulation (0: off)"},
       {"wino_min_cin", 0, true, "fewest input channels of a Winograd layer (0: the planner's policy)"},
-      {"wino_narrow_minpix", 100000, false, "layers under 128 channels take their Winograd form from this many input pixels on"},
+      {"wino_narrow_minpix", 20000, false, "layers under 128 channels take their Winograd form from this many input pixels on (round 6: 100 000 -> 20 000 -- with the small-problem transforms one 720 x 720 map's layer1 conv2, 32 400 pixels, gains 5 us per layer as F(6x6); profiles/r9e)"},
       {"wino_small_maxwg", 1024, false, "Winograd transforms: launches with fewer workgroups than this of the one-thread-per-tile kernels take the small-problem variants (a workgroup per tile and 64-channel slice, a thread per line, through LDS; bit-identical; 0: never)"},
       {"defer_splitk", 1, false, "a Bottleneck conv1 whose every tile is split along k leaves its partial tiles unsummed and conv2's (small-problem) Winograd input transform sums them: one launch fewer per block at batch 1, bit-identical (0: every conv runs its own reduce); read when a (B, H, W) plan is built"},
       {"ppm_overlap", -1, false, "pyramid branch of the PSP head on a side stream: 0 / 1, -1 = by size"},

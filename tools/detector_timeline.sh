@@ -43,12 +43,17 @@ print(f"per frame: launches {sum(v[0] for v in fam.values())/n:.0f} span {span/n
 for k, v in sorted(fam.items(), key=lambda x: -x[1][1])[:32]:
     print(f"{v[1]/n:9.1f} us {v[0]/n:6.1f} x  {k}")
 seg = segs[-1]
-print("# launch sequence of the last frame, dispatches 100-135 (res4 blocks): dur_us gap_before_us workgroups kernel")
+print("# launch sequence of the last frame: dur_us gap_before_us workgroups(x) kernel   (res4's 23 blocks collapsed to the first two)")
 rows = db.execute("select name,start,end,grid_x,workgroup_x from kernels order by start").fetchall()
 first = [i for i, r in enumerate(rows) if r[1] == seg[0][1]][0]
 prev = None
-for nm, st, en, gx, wx in rows[first + 100:first + 136]:
+seq = rows[first:first + len(seg)]
+blk = 0
+for i, (nm, st, en, gx, wx) in enumerate(seq):
+    if 75 < i < 75 + 21 * 5 + 3:          # the repeated res4 blocks
+        prev = en
+        continue
     key = nm.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("peanut::", "")[:60]
-    print(f"{(en - st) / 1e3:8.1f} {((st - prev) / 1e3 if prev else 0):7.1f} {gx // max(wx, 1):6d}  {key}")
+    print(f"{i:4d} {(en - st) / 1e3:8.1f} {((st - prev) / 1e3 if prev else 0):7.1f} {gx // max(wx, 1):6d}  {key}")
     prev = en
 P
