@@ -90,6 +90,11 @@ def run_pipeline(episodes, frames, precision="fp32", detector=False, goal=True, 
                 fr.pop(k)
     if mine:
         run_episode(st, eps[mine[0]][:12], goal_cat=3, detector=det)     # warm-up (plans, workspaces)
+    # Garbage of whatever ran in this process before (an earlier run's Agent_State / detector handles, bench.py's other
+    # configurations) must not be collected INSIDE the timed loop: a handle's destructor frees device memory, which synchronises the
+    # device (measured, round 6: the second of two runs in one process 140 steps/s against 148.5 for the first; profiles/r9f)
+    import gc
+    gc.collect()
     torch.cuda.synchronize()
     pdist.barrier()
     goal_ms[0], goal_n[0], goal_rounds[0], goal_passes[0], goal_unconverged[0] = 0.0, 0, 0, 0, 0
