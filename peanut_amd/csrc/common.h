@@ -82,6 +82,27 @@ struct ConvArgs {
 constexpr size_t kSplitKScratchFloats = (size_t)48 << 20;   // 192 MiB: 768 partial 256x256 tiles (the stream-K tail of the persistent 256 x 256 kernel: up to 3 fragments for each of < 256 tail tiles)
 constexpr size_t kSplitKSideFloats = (size_t)8 << 20;       // 32 MiB: split-K scratch of the ops a plan runs on a side stream (small layers)
 
+// paste_masks_in_image for one (output pixel, instance): the value of the M x M mask probabilities `m` at pixel (x, y) of the image
+// under box `bx` (grid_sample, bilinear, zero padding, align_corners = False).  Shared by paste_masks_kernel (rcnn_ops.hip) and the
+// fused paste + accumulate kernel (rcnn_post.hip) with contraction OFF: the two kernels must put the same pixels on the same side of
+// the mask threshold, and with -ffp-contract=fast hipcc decided per kernel which products to fuse into which adds -- in the source
+// coordinate (`(gx + 1) * M - 1`) and in the blend (round 6: one borderline pixel of a 16-frame batch differed between the entry points).
+__device__ __forceinline__ float paste_value(const float* __restrict__ m, int M, const float* __restrict__ bx, int x, int y) {
+#pragma clang fp contract(off)
+  const float gx = ((float)x + 0.5f - bx[0]) / (bx[2] - bx[0]) * 2.f - 1.f;
+  const float gy = ((float)y + 0.5f - bx[1]) / (bx[3] - bx[1]) * 2.f - 1.f;
+  const float ix = ((gx + 1.f) * (float)M - 1.f) / 2.f, iy = ((gy + 1.f) * (float)M - 1.f) / 2.f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)M + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)M + 1.f);
+  if (x0 < -1 || x0 >= M || y0 < -1 || y0 >= M) return 0.f;   // all four taps read zero padding
+  const float lx = ix - fx, ly = iy - fy;
+  const float wx = 1.f - lx, wy = 1.f - ly;
+  auto at = [&](int yy, int xx) -> float {
+    return ((unsigned)yy < (unsigned)M && (unsigned)xx < (unsigned)M) ? m[yy * M + xx] : 0.f;
+  };
+  return at(y0, x0) * wy * wx + at(y0, x0 + 1) * wy * lx + at(y0 + 1, x0) * ly * wx + at(y0 + 1, x0 + 1) * ly * lx;
+}
+
 inline int conv_out_dim(int n, int k, int s, int p, int d) { return (n + 2 * p - d * (k - 1) - 1) / s + 1; }
 
 // choose (bn_tile, bk) for a layer

@@ -197,9 +197,18 @@ __global__ __launch_bounds__(256) void ppm_rowsum_kernel(const float* __restrict
         a2.x += v[u + 1].x; a2.y += v[u + 1].y; a2.z += v[u + 1].z; a2.w += v[u + 1].w;
       }
     }
-    for (; xx < x1; ++xx) {
-      const float4 v = *reinterpret_cast<const float4*>(row + (size_t)xx * C);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    {   // the segment's last < U pixels: requested together (a clamped address for the slots past the end), added one by one in
+        // order as before -- a loop of single loads had every load wait for the one before it (round 6: one 720 x 720 map's row pass
+        // 42 -> 15 us; the sums are the same bits)
+      float4 v[U - 1];
+      const int rem = x1 - xx;
+      if (rem > 0) {
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) v[u] = *reinterpret_cast<const float4*>(row + (size_t)(u < rem ? xx + u : x1 - 1) * C);
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u)
+        if (u < rem) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+      }
     }
     a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
     const unsigned m = sg.mask[g];
@@ -238,10 +247,17 @@ __global__ __launch_bounds__(256) void ppm_binsum_kernel(const float* __restrict
     if (gr.y1[g] <= y0) g0 = g + 1;
     if (gr.y0[g] < y1) g1 = g + 1;
   }
-#pragma unroll 4
-  for (int g = g0; g < g1; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)b * gr.n + g) * nslots + slot0 + bx) * C + c);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  // sixteen groups' loads in flight, added in group order (round 6: the bin of scale 1 adds up to one group per row of a batch-1 map)
+  for (int gb = g0; gb < g1; gb += 16) {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int g = gb + u < g1 ? gb + u : g1 - 1;
+      v[u] = *reinterpret_cast<const float4*>(rowsum + (((size_t)b * gr.n + g) * nslots + slot0 + bx) * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (gb + u < g1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
   }
   const float cnt = (float)((y1 - y0) * (x1 - x0));
   acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;

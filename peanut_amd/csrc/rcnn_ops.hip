@@ -188,18 +188,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
     const int y = (int)(t % H);
     const int n = (int)(t / H);
     const float* b = boxes + (size_t)n * 4;
-    const float gx = ((float)x + 0.5f - b[0]) / (b[2] - b[0]) * 2.f - 1.f;
-    const float gy = ((float)y + 0.5f - b[1]) / (b[3] - b[1]) * 2.f - 1.f;
-    const float ix = ((gx + 1.f) * (float)M - 1.f) / 2.f, iy = ((gy + 1.f) * (float)M - 1.f) / 2.f;
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)M + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)M + 1.f);
-    const float lx = ix - fx, ly = iy - fy;
-    const float* m = masks + (size_t)n * M * M;
-    auto at = [&](int yy, int xx) -> float {
-      return ((unsigned)yy < (unsigned)M && (unsigned)xx < (unsigned)M) ? m[yy * M + xx] : 0.f;
-    };
-    const float v = at(y0, x0) * (1.f - ly) * (1.f - lx) + at(y0, x0 + 1) * (1.f - ly) * lx +
-                    at(y0 + 1, x0) * ly * (1.f - lx) + at(y0 + 1, x0 + 1) * ly * lx;
+    const float v = paste_value(masks + (size_t)n * M * M, M, b, x, y);
     out[i] = v >= thr ? 1 : 0;
   }
 }

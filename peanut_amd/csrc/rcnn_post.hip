@@ -885,19 +885,7 @@ __global__ __launch_bounds__(256) void paste_accumulate_kernel(const float* __re
       if (sc < thr) continue;
       if (cls == goal_cat && sc < goal_thr) continue;
       const float* bx = boxes + (size_t)j * 4;
-      const float gx = ((float)x + 0.5f - bx[0]) / (bx[2] - bx[0]) * 2.f - 1.f;
-      const float gy = ((float)y + 0.5f - bx[1]) / (bx[3] - bx[1]) * 2.f - 1.f;
-      const float ix = ((gx + 1.f) * (float)M - 1.f) / 2.f, iy = ((gy + 1.f) * (float)M - 1.f) / 2.f;
-      const float fx = floorf(ix), fy = floorf(iy);
-      const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)M + 1.f), y0 = (int)fminf(fmaxf(fy, -2.f), (float)M + 1.f);
-      if (x0 < -1 || x0 >= M || y0 < -1 || y0 >= M) continue;   // all four taps read zero padding: v = 0 < mask_thr
-      const float lx = ix - fx, ly = iy - fy;
-      const float* m = mprobs + (size_t)j * M * M;
-      auto at = [&](int yy, int xx) -> float {
-        return ((unsigned)yy < (unsigned)M && (unsigned)xx < (unsigned)M) ? m[yy * M + xx] : 0.f;
-      };
-      const float v = at(y0, x0) * (1.f - ly) * (1.f - lx) + at(y0, x0 + 1) * (1.f - ly) * lx +
-                      at(y0 + 1, x0) * ly * (1.f - lx) + at(y0 + 1, x0 + 1) * ly * lx;
+      const float v = paste_value(mprobs + (size_t)j * M * M, M, bx, x, y);       // (0 when all four taps fall outside the mask)
       const float bit = v >= mask_thr ? 1.f : 0.f;
 #pragma unroll
       for (int c = 0; c < 32; ++c)

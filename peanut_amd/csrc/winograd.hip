@@ -38,26 +38,36 @@ namespace {
 //   A^T = [1 1 1 1 1 0; 0 3/4 -3/4 3/2 -3/2 0; 0 9/16 9/16 9/4 9/4 0; 0 27/64 -27/64 27/8 -27/8 1]
 //   G   = [64/81 0 0; -128/243 -32/81 -8/27; -128/243 32/81 -8/27; 32/243 16/81 8/27; 32/243 -16/81 8/27; 0 0 1]
 // t = B^T d for one 6-vector
+// a * k + c as ONE fused multiply-add per lane, spelled out.  The transform helpers below used to leave the choice to hipcc's
+// contraction (-ffp-contract=fast): in `x * a - y * b` ONE product is fused and the other rounded, and which one turned out to depend
+// on the instantiation the helper was inlined into (round 6: the input transform that sums split-K partial tiles came out 4.5e-6
+// off on the logits of a 240 x 240 map in its f32x4 form only).  Every product that is not a power of two is now placed explicitly and
+// contraction is off inside the helpers, so that every kernel that calls them computes the same bits.
+template <typename V>
+__device__ __forceinline__ V fmak(V a, float k, V c) { return __builtin_elementwise_fma(a, (V)k, c); }
+
 __device__ __forceinline__ void bt6(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4,
                                     const f32x4 d5, f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3, f32x4& t4, f32x4& t5) {
-  const f32x4 a = d4 - 2.25f * d2, b = 0.75f * d3 - 1.6875f * d1;
-  const f32x4 c = d4 - 0.5625f * d2, e = 1.5f * d3 - 0.84375f * d1;
-  t0 = 1.265625f * d0 - 2.8125f * d2 + d4;
+#pragma clang fp contract(off)
+  const f32x4 a = fmak(d2, -2.25f, d4), b = fmak(d3, 0.75f, -1.6875f * d1);
+  const f32x4 c = fmak(d2, -0.5625f, d4), e = fmak(d3, 1.5f, -0.84375f * d1);
+  t0 = fmak(d0, 1.265625f, fmak(d2, -2.8125f, d4));
   t1 = a + b;
   t2 = a - b;
   t3 = c + e;
   t4 = c - e;
-  t5 = 1.265625f * d1 - 2.8125f * d3 + d5;
+  t5 = fmak(d1, 1.265625f, fmak(d3, -2.8125f, d5));
 }
 
 // y = A^T m for one 6-vector
 __device__ __forceinline__ void at6(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4,
                                     const f32x4 m5, f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
+#pragma clang fp contract(off)
   const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
   y0 = m0 + s12 + s34;
-  y1 = 0.75f * d12 + 1.5f * d34;
-  y2 = 0.5625f * s12 + 2.25f * s34;
-  y3 = 0.421875f * d12 + 3.375f * d34 + m5;
+  y1 = fmak(d12, 0.75f, 1.5f * d34);
+  y2 = fmak(s12, 0.5625f, 2.25f * s34);
+  y3 = fmak(d12, 0.421875f, fmak(d34, 3.375f, m5));
 }
 
 struct WinoGeom {
@@ -220,15 +230,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bt8(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
                                     const f32x2 d6, const f32x2 d7, f32x2& t0, f32x2& t1, f32x2& t2, f32x2& t3, f32x2& t4,
                                     f32x2& t5, f32x2& t6, f32x2& t7) {
-  const f32x2 e1 = 4.f * d2 - 5.f * d4 + d6, o1 = 2.f * d1 - 2.5f * d3 + 0.5f * d5;
-  const f32x2 e2 = d2 - 4.25f * d4 + d6, o2 = d1 - 4.25f * d3 + d5;
-  const f32x2 e3 = 0.25f * d2 - 1.25f * d4 + d6, o3 = 0.5f * d1 - 2.5f * d3 + 2.f * d5;
-  const f32x2 r0 = (d6 - d0) + 5.25f * (d2 - d4), r7 = (d7 - d1) + 5.25f * (d3 - d5);
+#pragma clang fp contract(off)
+  // (products with a power of two are exact: only the 5, 2.5, 4.25, 1.25 and 5.25 terms need placing)
+  const f32x2 e1 = 4.f * d2 + fmak(d4, -5.f, d6), o1 = 2.f * d1 + fmak(d3, -2.5f, 0.5f * d5);
+  const f32x2 e2 = fmak(d4, -4.25f, d2) + d6, o2 = fmak(d3, -4.25f, d1) + d5;
+  const f32x2 e3 = 0.25f * d2 + fmak(d4, -1.25f, d6), o3 = 0.5f * d1 + fmak(d3, -2.5f, 2.f * d5);
+  const f32x2 r0 = fmak(d2 - d4, 5.25f, d6 - d0), r7 = fmak(d3 - d5, 5.25f, d7 - d1);
   t0 = r0; t1 = e1 + o1; t2 = e1 - o1; t3 = e2 + o2; t4 = e2 - o2; t5 = e3 + o3; t6 = e3 - o3; t7 = r7;
 }
 
 __device__ __forceinline__ void at8(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
                                     const f32x2 m6, const f32x2 m7, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3, f32x2& y4, f32x2& y5) {
+#pragma clang fp contract(off)      // (every constant is a power of two: nothing to fuse that would change a bit)
   const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4, s3 = m5 + m6, d3 = m5 - m6;
   y0 = m0 + s1 + s2 + s3;
   y1 = 0.5f * d1 + d2 + 2.f * d3;
@@ -501,35 +514,52 @@ struct DeferredSrc {
   float alpha;
   int split_p, ntiles, relu;
 };
-// SP: the number of parts when it is 2 or 4 (all loads of a pixel then leave together), 0 = any (a loop)
-template <typename VT, int SP>
-__device__ __forceinline__ VT deferred_pixel(const DeferredSrc& df, long long m, int n) {
-  const int mt = (int)(m >> 7), row = (int)(m & 127), nt = n >> 7, col = n & 127;
+// The NPIX pixels of one transform line (rows m[i], the same VEC channels starting at n; ok[i] = inside the image, others come out 0).
+// The loop over the parts is the OUTER one: every pass issues NPIX independent loads (a loop over the parts per pixel had every load
+// wait for the one before it -- profiles/r9d, r9h); SP = 2 / 4: fully unrolled, all loads leave together.  Per pixel the parts are
+// added in part order, as the reduce kernel does.
+template <typename VT, int SP, int NPIX>
+__device__ __forceinline__ void deferred_line(const DeferredSrc& df, const long long (&m)[NPIX], const bool (&ok)[NPIX], int n, VT (&v)[NPIX]) {
   const int parts = SP ? SP : df.split_p;
-  const float* base = df.partial + ((size_t)(mt * df.ntiles + nt) * parts) * (128 * 128) + row * 128 + col;
-  VT v;
+  const int nt = n >> 7, col = n & 127;
+  const float* base[NPIX];
+#pragma unroll
+  for (int i = 0; i < NPIX; ++i) {
+    const long long mm = ok[i] ? m[i] : 0;                    // (a pixel outside the image reads a valid address; its value is dropped)
+    base[i] = df.partial + ((size_t)((int)(mm >> 7) * df.ntiles + nt) * parts) * (128 * 128) + (int)(mm & 127) * 128 + col;
+  }
+#pragma unroll
+  for (int i = 0; i < NPIX; ++i) v[i] = *reinterpret_cast<const VT*>(base[i]);
   if constexpr (SP != 0) {
-    VT part[SP];
 #pragma unroll
-    for (int s = 0; s < SP; ++s) part[s] = *reinterpret_cast<const VT*>(base + (size_t)s * (128 * 128));
-    v = part[0];
+    for (int s = 1; s < SP; ++s) {
+      VT part[NPIX];
 #pragma unroll
-    for (int s = 1; s < SP; ++s) v += part[s];
+      for (int i = 0; i < NPIX; ++i) part[i] = *reinterpret_cast<const VT*>(base[i] + (size_t)s * (128 * 128));
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) v[i] += part[i];
+    }
   } else {
-    v = *reinterpret_cast<const VT*>(base);
-    for (int s = 1; s < parts; ++s) v += *reinterpret_cast<const VT*>(base + (size_t)s * (128 * 128));
+    for (int s = 1; s < parts; ++s) {
+      VT part[NPIX];
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) part[i] = *reinterpret_cast<const VT*>(base[i] + (size_t)s * (128 * 128));
+#pragma unroll
+      for (int i = 0; i < NPIX; ++i) v[i] += part[i];
+    }
   }
   const VT sc = *reinterpret_cast<const VT*>(df.scale + n) * df.alpha;
   const VT sh = *reinterpret_cast<const VT*>(df.shift + n);
   // one fused multiply-add per channel, spelled out: what conv_splitk_reduce_kernel's `v * sc + sh` compiles to (v_pk_fma_f32)
   constexpr int NV = (int)(sizeof(VT) / sizeof(float));
 #pragma unroll
-  for (int e = 0; e < NV; ++e) {
-    float t = __builtin_fmaf(v[e], sc[e], sh[e]);
-    if (df.relu) t = relu_keep_nan(t);
-    v[e] = t;
-  }
-  return v;
+  for (int i = 0; i < NPIX; ++i)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      float t = __builtin_fmaf(v[i][e], sc[e], sh[e]);
+      if (df.relu) t = relu_keep_nan(t);
+      v[i][e] = ok[i] ? t : 0.f;
+    }
 }
 
 // DEFER: -1 = the input tensor is read; 0 / 2 / 4 = the producer's split-K partial tiles are summed (any number of parts / exactly 2 / 4)
@@ -548,15 +578,24 @@ __global__ __launch_bounds__(8 * LANES) void wino6_input_small_kernel(const floa
     const int c = c0 + a * g.d;
     const bool cok = (unsigned)c < (unsigned)g.W;
     f32x2 p[8];
+    if constexpr (DEFER >= 0) {
+      long long m[8];
+      bool ok[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = r0 + i * g.d;
-      f32x2 v = {0.f, 0.f};
-      if (cok && (unsigned)r < (unsigned)g.H) {
-        if constexpr (DEFER >= 0) v = deferred_pixel<f32x2, DEFER>(df, ((long long)b * g.H + r) * g.W + c, cg * 2);
-        else v = *reinterpret_cast<const f32x2*>(xb + ((size_t)r * g.W + c) * g.C);
+      for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i * g.d;
+        ok[i] = cok && (unsigned)r < (unsigned)g.H;
+        m[i] = ((long long)b * g.H + r) * g.W + c;
       }
-      p[i] = v;
+      deferred_line<f32x2, DEFER, 8>(df, m, ok, cg * 2, p);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i * g.d;
+        f32x2 v = {0.f, 0.f};
+        if (cok && (unsigned)r < (unsigned)g.H) v = *reinterpret_cast<const f32x2*>(xb + ((size_t)r * g.W + c) * g.C);
+        p[i] = v;
+      }
     }
     bt8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);      // column a: p <- B^T p
 #pragma unroll
@@ -643,15 +682,24 @@ __global__ __launch_bounds__(6 * LANES) void wino4_input_small_kernel(const floa
     const int c = c0 + a * g.d;
     const bool cok = (unsigned)c < (unsigned)g.W;
     f32x4 p[6];
+    if constexpr (DEFER >= 0) {
+      long long m[6];
+      bool ok[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int r = r0 + i * g.d;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cok && (unsigned)r < (unsigned)g.H) {
-        if constexpr (DEFER >= 0) v = deferred_pixel<f32x4, DEFER>(df, ((long long)b * g.H + r) * g.W + c, cg * 4);
-        else v = *reinterpret_cast<const f32x4*>(xb + ((size_t)r * g.W + c) * g.C);
+      for (int i = 0; i < 6; ++i) {
+        const int r = r0 + i * g.d;
+        ok[i] = cok && (unsigned)r < (unsigned)g.H;
+        m[i] = ((long long)b * g.H + r) * g.W + c;
       }
-      p[i] = v;
+      deferred_line<f32x4, DEFER, 6>(df, m, ok, cg * 4, p);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int r = r0 + i * g.d;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cok && (unsigned)r < (unsigned)g.H) v = *reinterpret_cast<const f32x4*>(xb + ((size_t)r * g.W + c) * g.C);
+        p[i] = v;
+      }
     }
     bt6(p[0], p[1], p[2], p[3], p[4], p[5], p[0], p[1], p[2], p[3], p[4], p[5]);
 #pragma unroll
