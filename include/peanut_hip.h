@@ -53,6 +53,12 @@ int peanut_debug_wino_weights(const float* w_oihw, int cout, int cin, int tile, 
  * nothing in the reference (resnet.py:267-307 conv1 -> bn1 -> relu -> conv2 are four module calls there); lets a test assert
  * that the fused path really ran while the results stay bit-identical. */
 long long peanut_debug_deferred_splitk_count(void);
+/* Test hook (ABI 14): an LDS canary.  Enqueues `workgroups` workgroups of 256 threads on `stream`, each of which fills `lds_bytes`
+ * (<= 64 KiB, a multiple of 1024) of its LDS with a pattern and then, `rounds` times, sleeps a little and checks it; words found
+ * changed are counted into *mismatches (device pointer, int, the caller zeroes it).  Run next to another kernel on a second stream it
+ * shows whether that kernel writes LDS outside its own allocation (a workgroup that shares the CU would see it).  Nothing in the
+ * reference corresponds to it. */
+int peanut_debug_lds_canary(int workgroups, int lds_bytes, int rounds, int* mismatches, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tuning options (csrc/options.h): kernel gates, Winograd form policy, launch-plan switches -- named by key, e.g.

@@ -77,6 +77,7 @@ struct ConvArgs {
   int group_valid_rows;    // grouped GEMM: rows of each group that hold data, the rest up to the group's whole tiles being zero padding
                            // (Winograd positions: tiles before padding); 0 = unknown / all.  A kernel may skip work on the padding.
   DeferredSplit* defer;    // optional: the launcher may skip its split-K reduce and describe the partial tiles here (see DeferredSplit)
+  const int* group_rows;   // optional (host): grouped GEMM, data rows of EACH group (<= group_valid_rows) -- the skinny kernel skips the rest
 };
 
 constexpr size_t kSplitKScratchFloats = (size_t)48 << 20;   // 192 MiB: 768 partial 256x256 tiles (the stream-K tail of the persistent 256 x 256 kernel: up to 3 fragments for each of < 256 tail tiles)
@@ -123,6 +124,10 @@ bool conv_pw_uses_256w(int cout, long long M, int mt_per_group, int bn_tile, int
 bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_per_group);
 // conv_pw256p.hip: ... on the persistent 256 x 128 kernel (epilogue of the previous tile inside the next tile's k-loop)
 bool conv_pw_uses_256p(int cout, long long M, int mt_per_group, int bn_tile, int cin, int flush_ktiles, long long in_pixels = 0);
+// gemm_skinny.hip (round 6): a grouped pointwise launch with a handful of data rows per group (the PSP pyramid's per-scale convs at batch 1)
+struct ConvKParams;
+bool gemm_skinny_takes(const ConvKParams& p, int bn_tile, size_t ws_floats);
+int launch_gemm_skinny(const ConvKParams& p, float* ws, size_t ws_floats, hipStream_t stream);
 // conv_pw256wp.hip: ... on the persistent 256 x 256 kernel (in-place epilogue inside the next tile's first iteration); stride 1
 // only, c1 / c2 the channels of the two sources
 bool conv_pw_uses_256wp(int cout, long long M, int stride, int mt_per_group, int bn_tile, int c1, int c2, int flush_ktiles);

@@ -57,6 +57,7 @@ struct ConvKParams {
   int stagger;                // conv_pw_glds256wp_kernel: spread of the workgroups' start times, in sleeps of ~3.4 us (option pw256wp_stagger)
   int flush;                  // k-tiles per partial sum of the two-level fp32 accumulation (0: one running sum); see PEANUT_FLUSH_*
   DeferredSplit* defer;       // HOST pointer, never read on the device: launch_with_tail_split may skip its reduce and fill it (common.h)
+  const int* group_rows;      // HOST pointer, never read on the device: data rows of each weight group (ConvArgs::group_rows)
 };
 
 template <int I>

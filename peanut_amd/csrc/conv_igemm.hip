@@ -352,6 +352,7 @@ int launch_conv(const ConvDesc& d, const ConvArgs& a, hipStream_t stream) {
   p.group_valid = a.mt_per_group ? a.group_valid_rows : 0;
   if (a.defer) a.defer->valid = false;      // set by launch_with_tail_split alone, when it left its partial tiles unsummed
   p.defer = a.defer;
+  p.group_rows = a.mt_per_group ? a.group_rows : nullptr;
   if (d.rs && !rs_fallback) {   // emulated-fp32 GEMM on the bf16 matrix cores, fp32 activations split in registers
     if (!d.w_s) return fail(-2, "launch_conv: register-split layer without pre-split weights");
     p.w = static_cast<const float*>(d.w_s);

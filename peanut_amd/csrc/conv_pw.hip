@@ -517,6 +517,8 @@ bool conv_pw_narrow_tiles(int cin, int cout, long long M, int bn_tile, int mt_pe
 // fp32, BK = 32, 1x1, pad 0, one source (checked by the caller)
 int launch_conv_pw(const ConvKParams& p, int bn_tile, float* ws, size_t ws_floats, hipStream_t stream) {
   const int phase_shift_w = opt(OPT_PW256_PHASE) != 0;
+  // a handful of data rows per weight group (the PSP pyramid at batch 1): weight streaming, no LDS (gemm_skinny.hip)
+  if (gemm_skinny_takes(p, bn_tile, ws ? ws_floats : 0)) return launch_gemm_skinny(p, ws, ws_floats, stream);
   // (the persistent 256 x 256 kernel first: its gate starts at 512 input channels by default, above the A-resident kernel's K = 128 / 256
   // layers; lowering pw256wp_mink hands those to it)
   if (conv_pw_uses_256wp(p.cout, p.M, p.stride, p.mt_per_group, bn_tile, p.c1, p.c2, p.flush)) {

@@ -19,7 +19,7 @@
 namespace peanut {
 
 enum OptionId {
-  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW256P_STREAMK, OPT_PW256WP_MINK, OPT_PW256WP_MINTILES, OPT_PW256WP_NPRE, OPT_PW256WP_STAGGER, OPT_PW_ARES,
+  OPT_PW_GLDS, OPT_PW256_MINK, OPT_PW256_MINTILES, OPT_PW256_PHASE, OPT_PW256_SKIP_PAD, OPT_PW256W_MINK, OPT_PW256W_MINTILES, OPT_PW256P_MINK, OPT_PW256P_MINTILES, OPT_PW256P_FLUSH, OPT_PW256P_ORDER, OPT_PW256P_STREAMK, OPT_PW256WP_MINK, OPT_PW256WP_MINTILES, OPT_PW256WP_NPRE, OPT_PW256WP_STAGGER, OPT_PW_ARES, OPT_PW_SKINNY,
   OPT_PW_ARES_MINUNITS, OPT_PATCH_MINTILES, OPT_STEM_NCHW, OPT_BN64_MAXK, OPT_PW_BN64_MAXK, OPT_PW64_MAXTILES, OPT_FP32_BK, OPT_NCHUNK, OPT_RES_PREFETCH, OPT_SPLIT_MODEL,
   OPT_RS_CONV, OPT_RS_BN64_MAXK, OPT_RS256_MINK, OPT_RS256_MINTILES, OPT_RS64_MAXK, OPT_RS64_MAXTILES,
   OPT_WINO_M, OPT_WINO_HEAD_M, OPT_WINO6_MAXDIL, OPT_WINO5_MINDIL, OPT_WINO_FLUSH_CH, OPT_WINO_MIN_CIN, OPT_WINO_NARROW_MINPIX, OPT_WINO_SMALL_MAXWG, OPT_DEFER_SPLITK,
@@ -53,6 +53,7 @@ inline const OptionInfo* option_table() {
       {"pw256wp_npre", 0, false, "persistent 256 x 256 kernel: accumulator blocks per in-place epilogue group (2 or 4; 0 = two with a residual, four without)"},
       {"pw256wp_stagger", 0, false, "persistent 256 x 256 kernel: spread of the workgroups' start times in sleeps of ~3.4 us (their tile boundaries -- 512 KiB of epilogue traffic per CU -- then fall at different times)"},
       {"pw_ares", 1, false, "K = 128 / 256 pointwise layers on the persistent A-resident kernel (conv_pw_ares.hip)"},
+      {"pw_skinny", 1, false, "grouped pointwise launches with at most 64 data rows per group (the PSP pyramid's per-scale convs and Q tables at batch 1) on the skinny weight-streaming kernel (gemm_skinny.hip: no LDS, runs next to anything; 0: the MFMA kernels on 128-row padded tiles)"},
       {"pw_ares_minunits", 512, false, "fewest (m-tile, n-tile) units for that kernel"},
       {"patch_mintiles", 1024, false, "3x3 convs of 16 / 32 input channels on the persistent LDS-patch kernel (conv_patch.hip) from this many 8 x 16 output tiles (0: off)"},
       {"stem_nchw", 1, false, "prediction forward: the first stem conv reads the NCHW input itself (conv_patch.hip, NCHW variant) instead of a layout pass + NHWC conv (fp32 mode, when the patch kernel takes the layer)"},

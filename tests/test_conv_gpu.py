@@ -1059,3 +1059,31 @@ def test_strided_two_source_pointwise_in_the_emulated_modes(precision):
     assert _last_kernel().startswith("conv_igemm_"), _last_kernel()
     err = (y - ref).abs()
     assert bool((err <= 2e-5 * (1 + ref.abs())).all()), f"max err {err.max().item():.3e}"
+
+
+def test_lds_canary_sees_no_foreign_writes_next_to_the_gemm_kernels():
+    """peanut_debug_lds_canary (round 6): workgroups that fill 18 KiB of LDS with a pattern and keep checking it, run on a second stream
+    next to the GEMM families (fp32 LDS-DMA kernels, the emulated modes' gemm_rs): no word may change -- a kernel that wrote LDS outside
+    its own allocation (an LDS-DMA piece past its stages, an epilogue slab larger than the array) would show up in a workgroup that
+    shares its CU."""
+    from peanut_amd import _lib
+    from peanut_amd.ops import FusedConv
+    lib = _lib.load()
+    side = torch.cuda.Stream()
+    g = torch.Generator().manual_seed(0)
+    for prec in ("fp32", "fp16x3", "bf16x6"):
+        for (M, K, N) in ((8100, 1024, 512), (3350, 1024, 256), (8100, 512, 2048)):
+            x = torch.relu(torch.randn((1, 1, M, K), generator=g)).cuda()
+            w = torch.randn((N, K, 1, 1), generator=g) * (2.0 / K) ** 0.5
+            conv = FusedConv(w, None, None, relu=True, precision=prec)
+            ref = conv(x).clone()
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                _lib.check(lib.peanut_debug_lds_canary(2048, 18432, 600, cnt.data_ptr(), side.cuda_stream), "peanut_debug_lds_canary")
+            for _ in range(5):
+                y = conv(x)
+            torch.cuda.synchronize()
+            assert int(cnt.item()) == 0, (prec, M, K, N, int(cnt.item()))
+            assert torch.equal(y, ref), (prec, M, K, N)
+            del conv
