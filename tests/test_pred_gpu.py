@@ -1069,7 +1069,10 @@ def test_two_stream_head_schedule_is_bit_identical():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for name, env in (("default", {"PEANUT_PPM_OVERLAP": "1"}), ("one_stream", {"PEANUT_PPM_OVERLAP": "0"})):
+    # (PEANUT_PW_SKINNY = 0: the weight-streaming form of the pyramid's GEMMs, round 6, runs on the caller's stream only -- with it the two
+    # schedules would use different kernels for those GEMMs and differ by rounding; this test is about the schedule)
+    for name, env in (("default", {"PEANUT_PPM_OVERLAP": "1", "PEANUT_PW_SKINNY": "0"}),
+                      ("one_stream", {"PEANUT_PPM_OVERLAP": "0", "PEANUT_PW_SKINNY": "0"})):
         r = subprocess.run([sys.executable, "-c", _SCHEDULE_PROBE], cwd=root, env={**os.environ, **env}, capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
