@@ -56,8 +56,9 @@ long long peanut_debug_deferred_splitk_count(void);
 /* Test hook (ABI 14): an LDS canary.  Enqueues `workgroups` workgroups of 256 threads on `stream`, each of which fills `lds_bytes`
  * (<= 64 KiB, a multiple of 1024) of its LDS with a pattern and then, `rounds` times, sleeps a little and checks it; words found
  * changed are counted into *mismatches (device pointer, int, the caller zeroes it).  Run next to another kernel on a second stream it
- * shows whether that kernel writes LDS outside its own allocation (a workgroup that shares the CU would see it).  Nothing in the
- * reference corresponds to it. */
+ * shows whether that kernel writes LDS outside its own allocation (a workgroup that shares the CU would see it).  rounds < 0: |rounds|
+ * rounds without the sleep and with a sweep of broadcast 16-byte reads over the whole array in each -- an LDS-heavy neighbour.  Nothing in
+ * the reference corresponds to it. */
 int peanut_debug_lds_canary(int workgroups, int lds_bytes, int rounds, int* mismatches, void* stream);
 
 /* ------------------------------------------------------------------------------------------

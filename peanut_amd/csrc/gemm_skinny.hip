@@ -135,17 +135,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_finish_kernel(const SkinnyEpi
 }
 
 // ---- LDS canary (include/peanut_hip.h: peanut_debug_lds_canary) ----
-__global__ __launch_bounds__(256) void lds_canary_kernel(int words, int rounds, int* mismatches) {
+__global__ __launch_bounds__(256) void lds_canary_kernel(int words, int rounds, int* mismatches, int hammer) {
   extern __shared__ unsigned canary[];
   const unsigned salt = 0x9e3779b9u * (blockIdx.x + 1);
   for (int i = threadIdx.x; i < words; i += 256) canary[i] = salt ^ (unsigned)i;
   __syncthreads();
   int bad = 0;
   for (int r = 0; r < rounds; ++r) {
-    __builtin_amdgcn_s_sleep(64);
+    if (rounds > 0 && !hammer) __builtin_amdgcn_s_sleep(64);
     for (int i = threadIdx.x; i < words; i += 256) {
       const unsigned v = canary[i];
       if (v != (salt ^ (unsigned)i)) { ++bad; canary[i] = salt ^ (unsigned)i; }
+    }
+    if (hammer) {      // keep the LDS pipe busy: broadcast 16-byte reads, as a compute kernel that stages a small operand there would
+      const uint4* c4 = reinterpret_cast<const uint4*>(canary);
+      unsigned acc = 0;
+      for (int i = 0; i < words / 4; ++i) { const uint4 q = c4[i]; acc += q.x ^ q.y ^ q.z ^ q.w; }
+      if (acc == 0x12345u) ++bad;
     }
   }
   if (bad) atomicAdd(mismatches, bad);
@@ -201,10 +207,10 @@ int launch_gemm_skinny(const ConvKParams& p, float* ws, size_t ws_floats, hipStr
 
 extern "C" int peanut_debug_lds_canary(int workgroups, int lds_bytes, int rounds, int* mismatches, void* stream) {
   using namespace peanut;
-  if (workgroups < 1 || lds_bytes < 1024 || lds_bytes > 65536 || lds_bytes % 1024 || rounds < 1 || !mismatches)
+  if (workgroups < 1 || lds_bytes < 1024 || lds_bytes > 65536 || lds_bytes % 1024 || rounds == 0 || !mismatches)
     return fail(-2, "peanut_debug_lds_canary: bad argument");
-  hipLaunchKernelGGL(lds_canary_kernel, dim3((unsigned)workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, lds_bytes / 4, rounds,
-                     mismatches);
+  hipLaunchKernelGGL(lds_canary_kernel, dim3((unsigned)workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, lds_bytes / 4, rounds < 0 ? -rounds : rounds,
+                     mismatches, rounds < 0 ? 1 : 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(-3, std::string("lds_canary launch: ") + hipGetErrorString(e));
 }

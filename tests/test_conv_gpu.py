@@ -1080,7 +1080,9 @@ def test_lds_canary_sees_no_foreign_writes_next_to_the_gemm_kernels():
             cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
             with torch.cuda.stream(side):
-                _lib.check(lib.peanut_debug_lds_canary(2048, 18432, 600, cnt.data_ptr(), side.cuda_stream), "peanut_debug_lds_canary")
+                # (rounds < 0: the LDS-heavy form -- no sleep, a sweep of broadcast 16-byte reads per round)
+                _lib.check(lib.peanut_debug_lds_canary(2048, 18432, -300 if K == 1024 else 600, cnt.data_ptr(), side.cuda_stream),
+                           "peanut_debug_lds_canary")
             for _ in range(5):
                 y = conv(x)
             torch.cuda.synchronize()
