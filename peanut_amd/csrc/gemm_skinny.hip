@@ -27,6 +27,8 @@ namespace {
 
 constexpr int kSkinnyMaxRows = 64;
 constexpr int kSkinnyMaxGroups = 8;
+constexpr int kSkinnyChunkRows = 12;
+constexpr int kSkinnyMaxChunks = 24;
 
 struct SkinnyParams {
   const float* x;        // [groups * group_stride_rows, K]
@@ -35,19 +37,22 @@ struct SkinnyParams {
   int K, N, nkt, ntiles, rows, groups, group_stride_rows, ksplit;
   long long w_group_stride;
   int grp_rows[kSkinnyMaxGroups];      // rows of each group that hold data
+  // blockIdx.y walks ROW CHUNKS: chunk c = rows [chunk_m0[c], chunk_m0[c] + chunk_rows[c]) of group chunk_g[c] (at most kSkinnyChunkRows rows:
+  // the inner loop is VALU-bound, rows x 64 v_fmac per wave and k-run, so the 36-row scale is cut in three)
+  unsigned char chunk_g[kSkinnyMaxChunks], chunk_m0[kSkinnyMaxChunks], chunk_rows[kSkinnyMaxChunks];
 };
 
-// X of the workgroup's k-run is staged in LDS once ([row][k], up to 64 rows x 128 channels = 32 KiB; scalar loads straight from memory were
+// X of the workgroup's k-run and row chunk is staged in LDS once ([row][k], 12 rows x 128 channels = 6 KiB; scalar loads straight from memory were
 // the first version: 36 dependent s_load_dwordx16 per k-tile, 7 us per k-tile); the inner loop reads it back as broadcast ds_read_b128.
 constexpr int kSkinnyRunTiles = 4;                 // k-tiles per workgroup
-template <int RMAX>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) {
+  constexpr int RMAX = kSkinnyChunkRows;
   __shared__ f32x4 xs[RMAX * kSkinnyRunTiles * 8];          // [row][k / 4]
   const int tid = threadIdx.x;
   const int n = tid & 127;
   const int kh = __builtin_amdgcn_readfirstlane(tid >> 7);
-  const int nt = blockIdx.x % p.ntiles, ks = blockIdx.x / p.ntiles, g = blockIdx.y;
-  const int R = p.grp_rows[g];
+  const int nt = blockIdx.x % p.ntiles, ks = blockIdx.x / p.ntiles;
+  const int g = p.chunk_g[blockIdx.y], mbase = p.chunk_m0[blockIdx.y], R = p.chunk_rows[blockIdx.y];
   const int kt0 = ks * kSkinnyRunTiles;
   const float* wp = p.w + (size_t)g * p.w_group_stride + ((size_t)nt * p.nkt + kt0) * (128 * 32) + n * 32 + kh * 16;
   f32x4 wc[kSkinnyRunTiles][4];
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) wc[t][q] = *reinterpret_cast<const f32x4*>(wp + (size_t)t * (128 * 32) + q * 4);
   {
-    const float* xg = p.x + (size_t)g * p.group_stride_rows * p.K + kt0 * 32;
+    const float* xg = p.x + ((size_t)g * p.group_stride_rows + mbase) * p.K + kt0 * 32;
     constexpr int PER_ROW = kSkinnyRunTiles * 8;             // 16-byte pieces per row of the run
     for (int i = tid; i < R * PER_ROW; i += 256) {
       const int m = i / PER_ROW, c = i - m * PER_ROW;
@@ -79,14 +84,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 xv = xr[q];
+            // One v_fmac_f32 per product, by hand.  Left to hipcc this loop becomes v_pk_fma_f32 (two rows per instruction, operands
+            // picked with op_sel) -- and with THAT code the kernel returned wrong sums whenever its waves shared a CU with the emulated
+            // modes' gemm_rs kernel (round 6, profiles/r9i: ~0.5 % of the outputs, always the even row of a pair in lanes 48-63, errors
+            // of 0.01-0.2; alone, or next to any other kernel tried, it was exact).  The scalar form was exact in the same runs.
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m0 + mm] = __builtin_fmaf(xv[e], wc[t][q][e], acc[m0 + mm]);
+            for (int e = 0; e < 4; ++e) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[m0 + mm]) : "v"(xv[e]), "v"(wc[t][q][e]));
           }
         }
       }
     }
   }
-  float* out = p.partial + ((size_t)(ks * 2 + kh) * p.groups + g) * ((size_t)p.rows * p.N) + nt * 128 + n;
+  float* out = p.partial + (((size_t)(ks * 2 + kh) * p.groups + g) * p.rows + mbase) * (size_t)p.N + nt * 128 + n;
 #pragma unroll
   for (int m = 0; m < RMAX; ++m)
     if (m < R) out[(size_t)m * p.N] = acc[m];
@@ -186,11 +195,16 @@ int launch_gemm_skinny(const ConvKParams& p, float* ws, size_t ws_floats, hipStr
   if (p.group_rows) {
     for (int g = 0; g < a.groups; ++g) a.grp_rows[g] = std::min(std::max(p.group_rows[g], 1), a.rows);
   }
+  int nchunks = 0;
+  for (int g = 0; g < a.groups; ++g)
+    for (int m0 = 0; m0 < a.grp_rows[g]; m0 += kSkinnyChunkRows) {
+      if (nchunks >= kSkinnyMaxChunks) return fail(-2, "gemm_skinny: too many row chunks");
+      a.chunk_g[nchunks] = (unsigned char)g; a.chunk_m0[nchunks] = (unsigned char)m0;
+      a.chunk_rows[nchunks] = (unsigned char)std::min(kSkinnyChunkRows, a.grp_rows[g] - m0);
+      ++nchunks;
+    }
   note_kernel("gemm_skinny");
-  const dim3 grid((unsigned)(a.ntiles * ksplit), (unsigned)a.groups);
-  if (a.rows <= 16) hipLaunchKernelGGL(gemm_skinny_kernel<16>, grid, dim3(256), 0, stream, a);
-  else if (a.rows <= 36) hipLaunchKernelGGL(gemm_skinny_kernel<36>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(gemm_skinny_kernel<64>, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)(a.ntiles * ksplit), (unsigned)nchunks), dim3(256), 0, stream, a);
   SkinnyEpi e{};
   e.partial = ws; e.scale = p.scale; e.shift = p.shift; e.y = p.y;
   e.N = a.N; e.rows = a.rows; e.groups = a.groups; e.group_stride_rows = 128; e.parts = parts; e.ss_group_stride = p.ss_group_stride;

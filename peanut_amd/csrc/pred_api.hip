@@ -502,10 +502,10 @@ std::unique_ptr<Plan> build_plan(const peanut_pred* h, int B, int H, int W) {
         if (pl->ops[i].has_res) { pl->ops[i].join_before = true; break; }   // the one consumer of R
       for (const auto& t : side_bufs) rel(t);
     }
-    // the grouped per-scale GEMMs of a branch that stays on the caller's stream run on the skinny kernel (run_op, gemm_skinny.hip)
+    // the grouped per-scale GEMMs of the pyramid branch run on the skinny kernel at batch 1 (run_op, gemm_skinny.hip)
     for (size_t i = side_first; i < side_end; ++i) {
       Op& op = pl->ops[i];
-      if (op.kind == OP_CONV && op.group_mt == 1 && op.branch == 0 && opt(OPT_PW_SKINNY) != 0 && B * kmax * kmax <= 64 &&
+      if (op.kind == OP_CONV && op.group_mt == 1 && opt(OPT_PW_SKINNY) != 0 && B * kmax * kmax <= 64 &&
           op.conv->d.bn_tile == 128 && op.conv->d.bk == 32 && op.conv->d.cout % 128 == 0 && (op.conv->d.cin / 32) % 4 == 0)
         op.kernel = "gemm_skinny";
     }
@@ -588,16 +588,8 @@ static int run_op(peanut_pred* h, const Plan& pl, const Op& op, const float* in_
           scale_rows[i] = pl.B * h->cfg.pool_scales[i] * h->cfg.pool_scales[i];
           most = std::max(most, scale_rows[i]);
         }
-        // ... on the caller's stream only.  On the side stream of the two-stream head the skinny kernel really runs NEXT TO the
-        // bottleneck's position GEMM (18 KiB of LDS fit beside the emulated modes' 48 KiB tiles, where the MFMA kernels' 64 KiB never
-        // did), and one 720 x 720 map in fp16x3 then came out 0.06-0.11 off, differently on every run -- although the skinny outputs
-        // verify against a naive recompute, the arena regions are disjoint and an LDS canary (peanut_debug_lds_canary) sees no foreign
-        // write; an on-device delay that removes the overlap removes the error (profiles/r9i).  Unresolved: the overlapped plan keeps
-        // the kernels it has always run.
-        if (op.branch == 0) {
-          a.group_valid_rows = most;
-          a.group_rows = scale_rows;
-        }
+        a.group_valid_rows = most;
+        a.group_rows = scale_rows;
         a.mt_per_group = op.group_mt;
         a.w_group_stride = op.conv->w.bytes / sizeof(float) / (size_t)h->cfg.n_pool_scales;
         a.ss_group_stride = op.conv->d.cout_pad;
