@@ -9,8 +9,9 @@
 //
 // Here a workgroup takes one 128-wide n-tile of one group and a run of four k-tiles; thread t holds output column n = t & 127 and the
 // k-half kh = t >> 7 of every k-tile (16 channels: one 64-byte piece of the packed weights, [n-tile][k-tile][128][32] as the MFMA
-// kernels read them; the whole run's 16 pieces are requested at once).  X of the run goes through LDS once (<= 32 KiB) and is read back
-// as broadcast ds_read_b128.  Every (k-run, kh) pair writes a raw partial
+// kernels read them; the whole run's 16 pieces are requested at once), for at most 12 rows of the group.  X of the run goes through LDS
+// once (6 KiB) and is read back as broadcast ds_read_b128; the products are hand-written v_fmac_f32 (see the note in the loop).  Every
+// (k-run, kh) pair writes a raw partial
 // [rows][N]; a second small launch adds the partials in order and applies scale / shift / ReLU.  Summation order differs from the MFMA
 // kernels' (k ascending within a lane here, the matrix core's internal order there): results agree to rounding, not to the bit; both
 // forms are held to the reference goldens (tests/test_pred_gpu.py).
