@@ -60,6 +60,11 @@ long long peanut_debug_deferred_splitk_count(void);
  * rounds without the sleep and with a sweep of broadcast 16-byte reads over the whole array in each -- an LDS-heavy neighbour.  Nothing in
  * the reference corresponds to it. */
 int peanut_debug_lds_canary(int workgroups, int lds_bytes, int rounds, int* mismatches, void* stream);
+/* Test hook (ABI 14): a packed-FMA canary.  Workgroups of 256 threads that compute, `rounds` times, twelve dot products per thread twice --
+ * once with the fused multiply-adds left to hipcc (it packs them into v_pk_fma_f32, the form in which csrc/gemm_skinny.hip's first version
+ * returned wrong sums next to the emulated modes' GEMM kernel, profiles/r9i) and once with hand-written v_fmac_f32 -- and count the sums that
+ * differ into *mismatches (device pointer, int, zeroed by the caller).  The two forms are the same arithmetic: any difference is the hazard. */
+int peanut_debug_pkfma_canary(int workgroups, int rounds, int* mismatches, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tuning options (csrc/options.h): kernel gates, Winograd form policy, launch-plan switches -- named by key, e.g.

@@ -79,6 +79,7 @@ SIGNATURES = {
     "peanut_debug_wino_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "peanut_debug_deferred_splitk_count": (C.c_longlong, []),
     "peanut_debug_lds_canary": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "peanut_debug_pkfma_canary": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "peanut_pred_create": (C.c_int, [C.POINTER(_P), C.POINTER(PredCfgC), C.POINTER(TensorC), C.c_int]),
     "peanut_pred_destroy": (None, [_P]),
     "peanut_pred_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

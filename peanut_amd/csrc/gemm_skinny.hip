@@ -218,7 +218,67 @@ int launch_gemm_skinny(const ConvKParams& p, float* ws, size_t ws_floats, hipStr
   return 0;
 }
 
+// ---- packed-FMA canary (include/peanut_hip.h: peanut_debug_pkfma_canary) ----
+// The loop shape of the first skinny kernel: X rows staged in LDS, read back as broadcast ds_read_b128, accumulated into row pairs with
+// the FMAs left to hipcc (which packs them: v_pk_fma_f32 with op_sel) -- next to the same sums done with hand-written v_fmac_f32.
+__global__ __launch_bounds__(256) void pkfma_canary_kernel(int rounds, int* mismatches) {
+  __shared__ f32x4 xs[12 * 32];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 12 * 32; i += 256) {
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) v[e] = (float)(((i * 4 + e) * 2654435761u >> 20) & 1023) * (1.0f / 512.0f) - 1.0f;
+    xs[i] = v;
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int r = 0; r < rounds; ++r) {
+    f32x4 w[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[q][e] = (float)((((tid + r) * 64 + q * 4 + e) * 2246822519u >> 21) & 511) * (1.0f / 256.0f) - 1.0f;
+    float a[12], b[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) { a[m] = 0.f; b[m] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        const f32x4* xr = xs + m * 32 + t * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 xv = xr[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[m] = __builtin_fmaf(xv[e], w[t * 4 + q][e], a[m]);
+        }
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        const f32x4* xr = xs + m * 32 + t * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 xv = xr[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(b[m]) : "v"(xv[e]), "v"(w[t * 4 + q][e]));
+        }
+      }
+#pragma unroll
+    for (int m = 0; m < 12; ++m) bad += (a[m] != b[m]) ? 1 : 0;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace peanut
+
+extern "C" int peanut_debug_pkfma_canary(int workgroups, int rounds, int* mismatches, void* stream) {
+  using namespace peanut;
+  if (workgroups < 1 || rounds < 1 || !mismatches) return fail(-2, "peanut_debug_pkfma_canary: bad argument");
+  hipLaunchKernelGGL(pkfma_canary_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, rounds, mismatches);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(-3, std::string("pkfma_canary launch: ") + hipGetErrorString(e));
+}
 
 extern "C" int peanut_debug_lds_canary(int workgroups, int lds_bytes, int rounds, int* mismatches, void* stream) {
   using namespace peanut;

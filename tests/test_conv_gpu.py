@@ -1089,3 +1089,29 @@ def test_lds_canary_sees_no_foreign_writes_next_to_the_gemm_kernels():
             assert int(cnt.item()) == 0, (prec, M, K, N, int(cnt.item()))
             assert torch.equal(y, ref), (prec, M, K, N)
             del conv
+
+
+def test_packed_fma_canary_next_to_the_emulated_gemm():
+    """peanut_debug_pkfma_canary (round 6): twelve dot products per thread computed with compiler-packed v_pk_fma_f32 and again with
+    hand-written v_fmac_f32, on operands read back from LDS as broadcast ds_read_b128 -- the loop shape in which gemm_skinny.hip's first
+    version went wrong next to gemm_rs (profiles/r9i).  In isolation the two forms agree in every sum, alone and next to the two-plane
+    emulated GEMM: the hazard needed more than this loop (the refined reading in profiles/r9i: a v_mov of a freshly waited-for ds_read
+    result whose last sixteen lanes had not landed).  Kept so that a regression in either direction is seen."""
+    from peanut_amd import _lib
+    from peanut_amd.ops import FusedConv
+    lib = _lib.load()
+    side = torch.cuda.Stream()
+    g = torch.Generator().manual_seed(0)
+    x = torch.relu(torch.randn((1, 1, 8100, 1024), generator=g)).cuda()
+    w = torch.randn((512, 1024, 1, 1), generator=g) * (2.0 / 1024) ** 0.5
+    for prec in (None, "fp16x3", "bf16x3"):
+        conv = FusedConv(w, None, None, relu=True, precision=prec) if prec else None
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            _lib.check(lib.peanut_debug_pkfma_canary(2048, 100, cnt.data_ptr(), side.cuda_stream), "peanut_debug_pkfma_canary")
+        if conv is not None:
+            for _ in range(6):
+                conv(x)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == 0, (prec, int(cnt.item()))
