@@ -177,6 +177,12 @@ bool gemm_skinny_takes(const ConvKParams& p, int bn_tile, size_t ws_floats) {
       p.ntaps != 1 || bn_tile != 128 || p.cout % 128 != 0 || p.M % 128 != 0 || p.M / 128 > kSkinnyMaxGroups || p.ss_group_stride == 0)
     return false;
   if (p.nkt % kSkinnyRunTiles != 0 || p.nkt / kSkinnyRunTiles > 64) return false;
+  int nchunks = 0;      // the launch's chunk table is fixed-size: a shape that would overflow it stays with the MFMA kernels
+  for (int g = 0; g < p.M / 128; ++g) {
+    const int rows = p.group_rows ? std::min(std::max(p.group_rows[g], 1), p.group_valid) : p.group_valid;
+    nchunks += (rows + kSkinnyChunkRows - 1) / kSkinnyChunkRows;
+  }
+  if (nchunks > kSkinnyMaxChunks) return false;
   return (size_t)2 * (p.nkt / kSkinnyRunTiles) * (p.M / 128) * p.group_valid * p.cout <= ws_floats;       // (k-runs x 2 halves of raw partials)
 }
 

@@ -874,6 +874,7 @@ int peanut_pred_forward(peanut_pred_t* h, const float* in_dev, float* out_dev, i
   if (pl->bytes > h->ws.bytes) h->graphs.clear();   // captured launches point into the old workspace
   if ((rc = h->ws.ensure(pl->bytes))) return rc;
   h->last_plan = pl;
+  h->deferred.valid = false;       // a forward that failed between a deferring conv1 and its consumer must not leave its note behind
   hipStream_t s = (hipStream_t)stream;
   if (!h->probe) {
     bool two_streams = false;
