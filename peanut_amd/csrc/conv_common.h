@@ -452,8 +452,7 @@ int launch_with_tail_split(KernelT kernel, ConvKParams p, float* ws, size_t ws_f
     p.defer = nullptr;
   }
   hipLaunchKernelGGL(kernel, dim3((unsigned)(p.n_full + p.n_sp)), dim3(NT), 0, stream, p);
-  static const bool keep_reduce = getenv("PEANUT_DEFER_KEEP_REDUCE") != nullptr;      // debugging aid: write the output tensor as well
-  if (t > 0 && (!deferred || keep_reduce)) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
+  if (t > 0 && !deferred) hipLaunchKernelGGL((conv_splitk_reduce_kernel<BM, BN>), dim3((unsigned)t, BM / 16), dim3(256), 0, stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-3, std::string("conv launch: ") + hipGetErrorString(e));
   return 0;
