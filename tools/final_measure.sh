@@ -44,8 +44,10 @@ rocprofv3 --kernel-trace -d /tmp/fm_tl -- python $R/bench.py --batch 1 --size 72
 db=$(find /tmp/fm_tl -name '*.db' | head -1)
 cd $R
 python tools/gap_b1.py $OUT/gap_b1.json ${db:+--timeline-db $db --timeline-forwards 20} > $OUT/gap_b1_summary.txt 2>/dev/null
-python tools/step_profile.py 60 2>/dev/null | grep "^{" > $OUT/step_profile.json
-bash tools/detector_timeline.sh > /dev/null 2>&1; cp gpurun_out/r8g/detector_b1_timeline.txt $OUT/ 2>/dev/null
+python tools/step_profile.py 60 --fine 2>/dev/null | grep "^{" > $OUT/step_profile.json
+bash tools/detector_timeline.sh $OUT > /dev/null 2>&1
+bash tools/pred_timeline.sh $OUT 1 720 > /dev/null 2>&1
+bash tools/pipeline_timeline.sh $OUT > /dev/null 2>&1
 tools/pmc_passes.sh $OUT/pmc_fp32 --precision fp32
 tools/pmc_passes.sh $OUT/pmc_bf16x6 --precision bf16x6
 tools/pmc_passes.sh $OUT/pmc_fp16x3 --precision fp16x3
