@@ -53,7 +53,7 @@ inline const OptionInfo* option_table() {
       {"pw256wp_npre", 0, false, "persistent 256 x 256 kernel: accumulator blocks per in-place epilogue group (2 or 4; 0 = two with a residual, four without)"},
       {"pw256wp_stagger", 0, false, "persistent 256 x 256 kernel: spread of the workgroups' start times in sleeps of ~3.4 us (their tile boundaries -- 512 KiB of epilogue traffic per CU -- then fall at different times)"},
       {"pw_ares", 1, false, "K = 128 / 256 pointwise layers on the persistent A-resident kernel (conv_pw_ares.hip)"},
-      {"pw_skinny", 1, false, "grouped pointwise launches with at most 64 data rows per group (the PSP pyramid's per-scale convs and Q tables at batch 1) on the skinny weight-streaming kernel (gemm_skinny.hip: no LDS, runs next to anything; 0: the MFMA kernels on 128-row padded tiles)"},
+      {"pw_skinny", 1, false, "grouped pointwise launches with at most 64 data rows per group (the PSP pyramid's per-scale convs and Q tables at batch 1) on the skinny weight-streaming kernel (gemm_skinny.hip: 6 KiB of LDS, fits next to any other kernel; 0: the MFMA kernels on 128-row padded tiles)"},
       {"pw_ares_minunits", 512, false, "fewest (m-tile, n-tile) units for that kernel"},
       {"patch_mintiles", 1024, false, "3x3 convs of 16 / 32 input channels on the persistent LDS-patch kernel (conv_patch.hip) from this many 8 x 16 output tiles (0: off)"},
       {"stem_nchw", 1, false, "prediction forward: the first stem conv reads the NCHW input itself (conv_patch.hip, NCHW variant) instead of a layout pass + NHWC conv (fp32 mode, when the patch kernel takes the layer)"},

@@ -1036,7 +1036,7 @@ from peanut_amd.prediction import PEANUT_Prediction_Model
 from peanut_amd.weights import PredCfg, make_seeded_state_dict
 cfg = PredCfg()
 out = []
-for precision in ("fp32", "bf16x6"):
+for precision in ("fp32", "bf16x6", "fp16x3"):
     m = PEANUT_Prediction_Model(SimpleNamespace(sem_gpu_id=0), state_dict=make_seeded_state_dict(cfg, 0), cfg=cfg, precision=precision)
     for B, S in ((1, 240), (3, 176), (1, 720)):
         g = torch.Generator().manual_seed(B * 1000 + S)
@@ -1070,10 +1070,10 @@ def test_two_stream_head_schedule_is_bit_identical():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    # (PEANUT_PW_SKINNY = 0: the weight-streaming form of the pyramid's GEMMs, round 6, runs on the caller's stream only -- with it the two
-    # schedules would use different kernels for those GEMMs and differ by rounding; this test is about the schedule)
-    for name, env in (("default", {"PEANUT_PPM_OVERLAP": "1", "PEANUT_PW_SKINNY": "0"}),
-                      ("one_stream", {"PEANUT_PPM_OVERLAP": "0", "PEANUT_PW_SKINNY": "0"})):
+    # (default options: at batch 1 the pyramid's GEMMs are the weight-streaming kernel of round 6, gemm_skinny.hip, in both schedules --
+    # on the side stream it runs next to the bottleneck GEMM, the neighbourhood in which its first form returned wrong sums, profiles/r9i)
+    for name, env in (("default", {"PEANUT_PPM_OVERLAP": "1"}),
+                      ("one_stream", {"PEANUT_PPM_OVERLAP": "0"})):
         r = subprocess.run([sys.executable, "-c", _SCHEDULE_PROBE], cwd=root, env={**os.environ, **env}, capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -1081,5 +1081,6 @@ def test_two_stream_head_schedule_is_bit_identical():
     assert got["default"] == got["one_stream"]
     h = got["default"].split()[1:]
     # per precision: three plain forwards, then two graph replays of the first two of them
-    for k in (0, 5):
+    assert len(h) == 15
+    for k in (0, 5, 10):
         assert h[k + 3] == "g" + h[k] and h[k + 4] == "g" + h[k + 1], "graph replay differs from plain launches"
