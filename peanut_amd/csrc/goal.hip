@@ -421,8 +421,12 @@ __global__ __launch_bounds__(1024) void fmm_round_blocked_kernel(double* __restr
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // wave -> block through a Latin square (waves w, w + 4, w + 8, w + 12 share a SIMD): the blocks of a row AND of a column
-  // of the tile sit on four different SIMDs, so a front that runs along either axis does not queue its blocks on one of them
-  const int by = wave >> 2, bx = (wave & 3) ^ (by ^ (by >> 1));
+  // of the tile sit on four different SIMDs, so a front that runs along either axis does not queue its blocks on one of them.
+  // The square is SIMD = bx ^ m(by) with m = multiplication by x in GF(4) (0, 2, 3, 1: round 6), which also puts the two main
+  // diagonals on four different SIMDs -- a front that crosses the tile obliquely; m = the Gray code (0, 1, 3, 2) of round 5 paired
+  // them (solver on its own 1.92 / 1.84 -> 1.81 / 1.83 ms per call, beside the forward 4.52 / 4.54 -> 4.45 / 4.48: profiles/r9o).
+  // Which wave relaxes a block does not enter the arithmetic.
+  const int by = wave >> 2, bx = (wave & 3) ^ ((0x1320 >> (4 * by)) & 3);
   const int ly = HALO + BLK * by + (lane >> 3), lx = HALO + BLK * bx + (lane & 7);
   const int py = HALO + (lane >> 3), px = HALO + (lane & 7);
   unsigned feed = st[ly][lx] == ST_FREE ? 0x100u : 0u;       // as in fmm_round_kernel
