@@ -60,10 +60,12 @@ long long peanut_debug_deferred_splitk_count(void);
  * rounds without the sleep and with a sweep of broadcast 16-byte reads over the whole array in each -- an LDS-heavy neighbour.  Nothing in
  * the reference corresponds to it. */
 int peanut_debug_lds_canary(int workgroups, int lds_bytes, int rounds, int* mismatches, void* stream);
-/* Test hook (ABI 14): a packed-FMA canary.  Workgroups of 256 threads that compute, `rounds` times, twelve dot products per thread twice --
- * once with the fused multiply-adds left to hipcc (it packs them into v_pk_fma_f32, the form in which csrc/gemm_skinny.hip's first version
- * returned wrong sums next to the emulated modes' GEMM kernel, profiles/r9i) and once with hand-written v_fmac_f32 -- and count the sums that
- * differ into *mismatches (device pointer, int, zeroed by the caller).  The two forms are the same arithmetic: any difference is the hazard. */
+/* Test hook (ABI 15): a packed-FMA canary.  Workgroups of 256 threads that compute, `rounds` times, twelve 64-term dot products per thread
+ * three ways on the same operands, two sums per packed instruction: `v_pk_fma_f32 ... op_sel:[0,1,0]` (the shared operand in the HIGH
+ * register of its pair: the form hipcc emits when it packs scalar code), `v_pk_fma_f32 ... op_sel_hi:[1,0,1]` (the operand in the LOW
+ * register) and two scalar v_fmac_f32.  mismatches (device pointer, TWO ints, zeroed by the caller): [0] sums where the first form differs
+ * from the scalar one, [1] where the second does.  The same arithmetic: any difference is the hardware.  Measured on gfx950 (profiles/r9r):
+ * [0] > 0 while fp16 / bf16 MFMA waves share the SIMD (the emulated modes' GEMM kernels), 0 otherwise; [1] always 0. */
 int peanut_debug_pkfma_canary(int workgroups, int rounds, int* mismatches, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ from . import build as _build
 
 _LOCK = threading.Lock()
 _LIB = None
-ABI_VERSION = 14    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
+ABI_VERSION = 15    # must equal peanut_abi_version() of the loaded library (struct layouts, argument lists)
 
 
 class PeanutHipError(RuntimeError):

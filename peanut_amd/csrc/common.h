@@ -83,6 +83,21 @@ struct ConvArgs {
 constexpr size_t kSplitKScratchFloats = (size_t)48 << 20;   // 192 MiB: 768 partial 256x256 tiles (the stream-K tail of the persistent 256 x 256 kernel: up to 3 fragments for each of < 256 tail tiles)
 constexpr size_t kSplitKSideFloats = (size_t)8 << 20;       // 32 MiB: split-K scratch of the ops a plan runs on a side stream (small layers)
 
+// PEANUT_NO_PK_F32 on a kernel: no packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in its code.
+//
+// Why (round 6, profiles/r9r): on gfx950 a packed fp32 instruction whose LOW half takes an operand from the HIGH register of a pair
+// -- `op_sel:[..1..]`, which hipcc emits freely when it packs scalar code -- returns wrong low halves (lanes 48-63) while a wave
+// on the same SIMD issues fp16 / bf16 MFMAs (the emulated modes' gemm_rs / conv_rs kernels).  Found in gemm_skinny.hip next to the
+// bottleneck GEMM of the two-stream head; reproduced with a hand-written `v_pk_fma_f32 ... op_sel:[0,1,0]`: 20 different results in 20
+// forwards, while the same sums through op_sel_hi only, through no modifier, or unpacked are exact, as is every form next to fp32
+// MFMAs or alone.  Kernels that can share a CU with another kernel (side streams: the pyramid branch of the PSP head, the goal solver's
+// field, anything a caller may run beside a forward) carry this attribute; tests/test_abi.py refuses the pattern anywhere in the library.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PEANUT_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define PEANUT_NO_PK_F32
+#endif
+
 // paste_masks_in_image for one (output pixel, instance): the value of the M x M mask probabilities `m` at pixel (x, y) of the image
 // under box `bx` (grid_sample, bilinear, zero padding, align_corners = False).  Shared by paste_masks_kernel (rcnn_ops.hip) and the
 // fused paste + accumulate kernel (rcnn_post.hip) with contraction OFF: the two kernels must put the same pixels on the same side of

@@ -10,7 +10,7 @@
 // Here a workgroup takes one 128-wide n-tile of one group and a run of four k-tiles; thread t holds output column n = t & 127 and the
 // k-half kh = t >> 7 of every k-tile (16 channels: one 64-byte piece of the packed weights, [n-tile][k-tile][128][32] as the MFMA
 // kernels read them; the whole run's 16 pieces are requested at once), for at most 12 rows of the group.  X of the run goes through LDS
-// once (6 KiB) and is read back as broadcast ds_read_b128; the products are hand-written v_fmac_f32 (see the note in the loop).  Every
+// once (6 KiB) and is read back as broadcast ds_read_b128; the kernel is compiled without packed fp32 instructions (see the note in the loop).  Every
 // (k-run, kh) pair writes a raw partial
 // [rows][N]; a second small launch adds the partials in order and applies scale / shift / ReLU.  Summation order differs from the MFMA
 // kernels' (k ascending within a lane here, the matrix core's internal order there): results agree to rounding, not to the bit; both
@@ -46,7 +46,7 @@ struct SkinnyParams {
 // X of the workgroup's k-run and row chunk is staged in LDS once ([row][k], 12 rows x 128 channels = 6 KiB; scalar loads straight from memory were
 // the first version: 36 dependent s_load_dwordx16 per k-tile, 7 us per k-tile); the inner loop reads it back as broadcast ds_read_b128.
 constexpr int kSkinnyRunTiles = 4;                 // k-tiles per workgroup
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) {
+__global__ __launch_bounds__(256) PEANUT_NO_PK_F32 void gemm_skinny_kernel(const SkinnyParams p) {
   constexpr int RMAX = kSkinnyChunkRows;
   __shared__ f32x4 xs[RMAX * kSkinnyRunTiles * 8];          // [row][k / 4]
   const int tid = threadIdx.x;
@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
       xs[m * PER_ROW + c] = *reinterpret_cast<const f32x4*>(xg + (size_t)m * p.K + c * 4);
     }
   }
-  __syncthreads();
+  // (__syncthreads() spelled out: HIP's wrapper is a function compiled WITH packed fp32 and would stay a call from this kernel)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   float acc[RMAX];
 #pragma unroll
   for (int m = 0; m < RMAX; ++m) acc[m] = 0.f;
@@ -85,12 +88,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams p) 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 xv = xr[q];
-            // One v_fmac_f32 per product, by hand.  Left to hipcc this loop becomes v_pk_fma_f32 (two rows per instruction, operands
-            // picked with op_sel) -- and with THAT code the kernel returned wrong sums whenever its waves shared a CU with the emulated
-            // modes' gemm_rs kernel (round 6, profiles/r9i: ~0.5 % of the outputs, always the even row of a pair in lanes 48-63, errors
-            // of 0.01-0.2; alone, or next to any other kernel tried, it was exact).  The scalar form was exact in the same runs.
+            // (PEANUT_NO_PK_F32: left to itself hipcc packs this loop into v_pk_fma_f32 with op_sel, two rows per instruction -- the
+            // form that returned wrong sums next to the emulated modes' gemm_rs kernel, common.h; unpacked it is one v_fmac_f32 per product)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[m0 + mm]) : "v"(xv[e]), "v"(wc[t][q][e]));
+            for (int e = 0; e < 4; ++e) acc[m0 + mm] = __builtin_fmaf(xv[e], wc[t][q][e], acc[m0 + mm]);
           }
         }
       }
@@ -225,55 +226,45 @@ int launch_gemm_skinny(const ConvKParams& p, float* ws, size_t ws_floats, hipStr
 }
 
 // ---- packed-FMA canary (include/peanut_hip.h: peanut_debug_pkfma_canary) ----
-// The loop shape of the first skinny kernel: X rows staged in LDS, read back as broadcast ds_read_b128, accumulated into row pairs with
-// the FMAs left to hipcc (which packs them: v_pk_fma_f32 with op_sel) -- next to the same sums done with hand-written v_fmac_f32.
+// The sums of the skinny kernel's inner loop -- two rows per packed instruction -- three ways on the same operands:
+//   risky:  v_pk_fma_f32 acc2, x2, w2, acc2 op_sel:[0,1,0]      the weight sits in the HIGH register of its pair, both halves pick it
+//   safe:   v_pk_fma_f32 acc2, x2, w2, acc2 op_sel_hi:[1,0,1]   the weight sits in the LOW register, both halves pick it
+//   scalar: two v_fmac_f32
+// mismatches[0] counts sums where risky != scalar, mismatches[1] where safe != scalar.  Measured on gfx950 (profiles/r9r): both 0 alone
+// and next to fp32 MFMA kernels; next to the emulated modes' fp16 / bf16 MFMA kernels only the risky form goes wrong (low halves,
+// lanes 48-63) -- the form hipcc emits when it packs scalar code, and the reason for PEANUT_NO_PK_F32 (common.h).
 __global__ __launch_bounds__(256) void pkfma_canary_kernel(int rounds, int* mismatches) {
-  __shared__ f32x4 xs[12 * 32];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
-  for (int i = tid; i < 12 * 32; i += 256) {
-    f32x4 v;
-    for (int e = 0; e < 4; ++e) v[e] = (float)(((i * 4 + e) * 2654435761u >> 20) & 1023) * (1.0f / 512.0f) - 1.0f;
-    xs[i] = v;
-  }
-  __syncthreads();
-  int bad = 0;
+  int bad_risky = 0, bad_safe = 0;
   for (int r = 0; r < rounds; ++r) {
-    f32x4 w[16];
+    f32x2 ar[6], as[6];
+    float s0[6], s1[6];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int m = 0; m < 6; ++m) { ar[m] = f32x2{0.f, 0.f}; as[m] = f32x2{0.f, 0.f}; s0[m] = 0.f; s1[m] = 0.f; }
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+      const float w = (float)((((tid + r) * 64 + k) * 2246822519u >> 21) & 511) * (1.0f / 256.0f) - 1.0f;
+      f32x2 w_hi = {0.f, w}, w_lo = {w, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[q][e] = (float)((((tid + r) * 64 + q * 4 + e) * 2246822519u >> 21) & 511) * (1.0f / 256.0f) - 1.0f;
-    float a[12], b[12];
-#pragma unroll
-    for (int m = 0; m < 12; ++m) { a[m] = 0.f; b[m] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int m = 0; m < 12; ++m) {
-        const f32x4* xr = xs + m * 32 + t * 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 xv = xr[q];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a[m] = __builtin_fmaf(xv[e], w[t * 4 + q][e], a[m]);
-        }
+      for (int m = 0; m < 6; ++m) {
+        f32x2 x2;
+        x2[0] = (float)((((2 * m) * 64 + k + r) * 2654435761u >> 20) & 1023) * (1.0f / 512.0f) - 1.0f;
+        x2[1] = (float)((((2 * m + 1) * 64 + k + r) * 2654435761u >> 20) & 1023) * (1.0f / 512.0f) - 1.0f;
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(ar[m]) : "v"(x2), "v"(w_hi));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(as[m]) : "v"(x2), "v"(w_lo));
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s0[m]) : "v"(x2[0]), "v"(w));
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s1[m]) : "v"(x2[1]), "v"(w));
       }
+    }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int m = 0; m < 12; ++m) {
-        const f32x4* xr = xs + m * 32 + t * 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 xv = xr[q];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(b[m]) : "v"(xv[e]), "v"(w[t * 4 + q][e]));
-        }
-      }
-#pragma unroll
-    for (int m = 0; m < 12; ++m) bad += (a[m] != b[m]) ? 1 : 0;
+    for (int m = 0; m < 6; ++m) {
+      bad_risky += (ar[m][0] != s0[m] ? 1 : 0) + (ar[m][1] != s1[m] ? 1 : 0);
+      bad_safe += (as[m][0] != s0[m] ? 1 : 0) + (as[m][1] != s1[m] ? 1 : 0);
+    }
   }
-  if (bad) atomicAdd(mismatches, bad);
+  if (bad_risky) atomicAdd(mismatches, bad_risky);
+  if (bad_safe) atomicAdd(mismatches + 1, bad_safe);
 }
 
 }  // namespace peanut

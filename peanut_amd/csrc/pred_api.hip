@@ -638,7 +638,7 @@ extern "C" {
 
 const char* peanut_last_error(void) { return g_err.c_str(); }
 const char* peanut_last_conv_kernel(void) { return noted_kernel(); }
-int peanut_abi_version(void) { return 14; }
+int peanut_abi_version(void) { return 15; }
 const char* peanut_build_arch(void) { return "gfx950"; }
 #ifndef PEANUT_SOURCE_HASH
 #define PEANUT_SOURCE_HASH ""

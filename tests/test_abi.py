@@ -291,6 +291,47 @@ def test_uncounted_asm_loads_are_not_touched_before_their_wait():
         assert n >= 100 and findings == [], (src, findings[:5])
 
 
+def test_no_packed_fp32_instruction_reads_a_high_register_into_its_low_half():
+    """gfx950, measured in round 6 (profiles/r9r): `v_pk_fma_f32 ... op_sel:[0,1,0]` -- a packed fp32 instruction whose LOW half takes
+    an operand from the HIGH register of a pair -- returns wrong low halves (lanes 48-63) while another wave on the same SIMD issues
+    fp16 / bf16 MFMAs; 20 different results in 20 forwards of the two-stream head in the emulated modes, exact through `op_sel_hi`
+    alone, through no modifier, unpacked, next to fp32 MFMAs or alone.  hipcc emits the form freely when it packs scalar code.  By
+    disassembly of the built library:
+
+      * the kernels the library itself runs BESIDE other kernels -- the pyramid branch of the PSP head on the side stream
+        (pooling sums, skinny GEMM + finish, conv term) and everything of the goal solver (its field runs beside the prediction
+        forward) -- contain no such instruction (gemm_skinny_kernel is compiled without packed fp32 altogether: PEANUT_NO_PK_F32);
+      * neither does any convolution / GEMM / Winograd / detector kernel;
+      * the four kernels that do are exactly the ones listed here, each the only thing its stream runs at the time (a caller who
+        puts them beside an emulated-mode GEMM of ANOTHER handle on another stream would have to fence them the same way):
+        a new one anywhere fails this test before a GPU does."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build.build()
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    assert kr._OP_SEL.search("v_pk_fma_f32 v[0:1], v[0:1], v[104:105], v[16:17] op_sel:[0,1,0]").group(1) == "0,1,0"
+    assert kr._OP_SEL.search("v_pk_fma_f32 v[0:1], v[2:3], v[52:53], v[0:1] op_sel_hi:[1,0,1]") is None
+    found = kr.risky_packed_fp32()
+    serial_only = ("map_finish_kernel(", "ppm_conv_term_kernel(", "upsample_logits_kernel<", "box_post_kernel(",
+                   "pkfma_canary_kernel(")        # (the last: the test hook that exists to show the behaviour, tests/test_conv_gpu.py)
+    others = [(r["file"], r["name"][:70], r["instruction"]) for r in found if not any(k in r["name"] for k in serial_only)]
+    assert others == [], others[:8]
+    beside = ("gemm_skinny", "fmm_", "goal_", "ppm_rowsum", "ppm_binsum", "ppm_conv_term_lds", "ppm_conv_term_rows")
+    assert not [r["name"] for r in found if any(k in r["name"] for k in beside)]
+    # the fenced kernel carries no packed fp32 instruction at all
+    text = kr.object_disassembly(os.path.join(kr.BUILD, "gemm_skinny.o"))
+    cur, packed = None, {}
+    for ln in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", ln)
+        if m:
+            cur = m.group(1)
+        elif cur and kr._PK_F32.search(ln):
+            packed[cur] = packed.get(cur, 0) + 1
+    assert not {n: c for n, c in packed.items() if "gemm_skinny_kernel" in n}, packed
+
+
 def test_hot_kernels_have_no_spilled_vgprs_and_no_scratch():
     """Register budget of the built library, from the code objects' own metadata (tools/kernel_resources.py; the numbers
     `-Rpass-analysis=kernel-resource-usage` prints): no kernel spills a VGPR, none of the convolution / GEMM / Winograd /

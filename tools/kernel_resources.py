@@ -4,6 +4,7 @@ notes (what `-Rpass-analysis=kernel-resource-usage` prints at compile time, with
 spilled VGPRs / SGPRs, private-segment (scratch) bytes, static LDS bytes and the waves per SIMD the VGPR count allows.
 
     tools/kernel_resources.py [--all] [--json]       default: kernels with spills or scratch, and the MFMA kernels
+    tools/kernel_resources.py --packed               packed fp32 instructions of the form that is not safe next to fp16 / bf16 MFMAs
 
 tests/test_abi.py holds the hot kernels to "no spilled VGPR, no scratch" with this table, so that a spill shows up in the CPU
 suite and not in somebody's disassembly.
@@ -80,6 +81,53 @@ def object_kernels(obj: str) -> List[Dict]:
     return kernels
 
 
+def object_disassembly(obj: str) -> str:
+    """llvm-objdump -d of the gfx950 code object inside one host object ('' for a host-only object)."""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat"), os.path.join(d, "co")
+        try:
+            _run([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", obj])
+        except RuntimeError as e:
+            if "not found" in str(e):
+                return ""
+            raise
+        if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            return ""
+        _run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--targets={TARGET}", f"--output={co}"])
+        return _run([os.path.join(LLVM, "llvm-objdump"), "-d", co])
+
+
+_PK_F32 = re.compile(r"\b(v_pk_\w+_f32)\b")
+_OP_SEL = re.compile(r"op_sel:\[([01,]+)\]")
+
+
+def risky_packed_fp32(build_dir: str = BUILD) -> List[Dict]:
+    """Packed fp32 instructions whose LOW half takes an operand from the HIGH register of a pair (`op_sel:[..1..]`), per kernel.
+    On gfx950 that form returns wrong low halves while a wave on the same SIMD issues fp16 / bf16 MFMAs (csrc/common.h,
+    PEANUT_NO_PK_F32; profiles/r9r): the library must not contain it.  `op_sel_hi` alone (the high half reading a low register) and
+    unmodified packed instructions were measured exact and are not reported."""
+    out = []
+    for f in sorted(os.listdir(build_dir)):
+        if not f.endswith(".o"):
+            continue
+        cur = None
+        for ln in object_disassembly(os.path.join(build_dir, f)).splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", ln)
+            if m:
+                cur = m.group(1)
+                continue
+            m = _PK_F32.search(ln)
+            if cur and m:
+                sel = _OP_SEL.search(ln)
+                if sel and "1" in sel.group(1):
+                    out.append({"file": f[:-2] + ".hip", "mangled": cur, "instruction": ln.split("//")[0].strip()})
+    if out:
+        names = _run(["c++filt"] + [r["mangled"] for r in out]).splitlines()
+        for r, n in zip(out, names):
+            r["name"] = re.sub(r"\(anonymous namespace\)::", "", n).replace("peanut::", "")
+    return out
+
+
 def library_kernels(build_dir: str = BUILD) -> List[Dict]:
     out = []
     for f in sorted(os.listdir(build_dir)):
@@ -89,6 +137,12 @@ def library_kernels(build_dir: str = BUILD) -> List[Dict]:
 
 
 def main():
+    if "--packed" in sys.argv:
+        rows = risky_packed_fp32()
+        for r in rows:
+            print(f"{r['file']:18s} {r['instruction']:70s} {r['name'][:80]}")
+        print(f"{len(rows)} packed fp32 instructions with op_sel (low half from a high register)")
+        return
     ks = library_kernels()
     if "--json" in sys.argv:
         print(json.dumps(ks, indent=1))
