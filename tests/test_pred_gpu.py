@@ -901,9 +901,9 @@ def test_skinny_pyramid_gemms_match_the_mfma_kernels_on_either_stream(precision)
     reduce.  Another summation order, so the logits agree with the MFMA form to rounding (<= 2e-5), not to the bit.  A 240 x 240 map
     runs the pyramid branch on the caller's stream; on a 720 x 720 map it runs on the side stream, where with its 18 KiB of LDS the
     kernel really shares CUs with the emulated modes' position GEMM (gemm_rs, 48 KiB tiles) -- the situation in which the
-    compiler-packed form of its inner loop (v_pk_fma_f32) returned wrong sums (profiles/r9i); the hand-written v_fmac_f32 form must
-    be exact there: within rounding of the MFMA form AND bit-identical from run to run, in fp32 and in both two-plane emulated
-    modes."""
+    compiler-packed form of its inner loop (v_pk_fma_f32 with op_sel) returned wrong sums (profiles/r9i, r9r); the kernel as it ships
+    (compiled without packed fp32 instructions, csrc/common.h) must be exact there: within rounding of the MFMA form AND bit-identical
+    from run to run, in fp32 and in both two-plane emulated modes."""
     from bench import synth_maps
     from peanut_amd.prediction import PEANUT_Prediction_Model
     from peanut_amd.weights import PredCfg, make_seeded_state_dict
