@@ -90,8 +90,11 @@ constexpr size_t kSplitKSideFloats = (size_t)8 << 20;       // 32 MiB: split-K s
 // on the same SIMD issues fp16 / bf16 MFMAs (the emulated modes' gemm_rs / conv_rs kernels).  Found in gemm_skinny.hip next to the
 // bottleneck GEMM of the two-stream head; reproduced with a hand-written `v_pk_fma_f32 ... op_sel:[0,1,0]`: 20 different results in 20
 // forwards, while the same sums through op_sel_hi only, through no modifier, or unpacked are exact, as is every form next to fp32
-// MFMAs or alone.  Kernels that can share a CU with another kernel (side streams: the pyramid branch of the PSP head, the goal solver's
-// field, anything a caller may run beside a forward) carry this attribute; tests/test_abi.py refuses the pattern anywhere in the library.
+// MFMAs or alone.  The kernels in which hipcc had produced the form carry this attribute (gemm_skinny_kernel, upsample_logits_kernel, the
+// fallback ppm_conv_term_kernel, map_finish_kernel, box_post_kernel); tests/test_abi.py disassembles the library and refuses the form
+// anywhere but in the test hook that demonstrates it (pkfma_canary_kernel).  A function with the attribute does not inline callees
+// compiled without it (they would become real calls, the same test refuses those too): helpers such a kernel uses carry the attribute
+// as well (a callee WITH it inlines anywhere), and HIP's header wrappers (__syncthreads, atomicAdd, make_float4) are spelled out.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PEANUT_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
 #else

@@ -369,7 +369,7 @@ __device__ __forceinline__ void map_pose(const float* __restrict__ rel, float* _
 }
 
 // ---- 6+7+4 in one launch: egocentric view, pose integration, re-arming of the per-cell tables ----
-__global__ __launch_bounds__(256) void map_finish_kernel(float* __restrict__ proj, float* __restrict__ view,
+__global__ __launch_bounds__(256) PEANUT_NO_PK_F32 void map_finish_kernel(float* __restrict__ proj, float* __restrict__ view,
                                                          float* __restrict__ fp_map_pred, StairStats* __restrict__ stats,
                                                          const float* __restrict__ rel, float* __restrict__ pose, WarpT* __restrict__ wt,
                                                          const unsigned* __restrict__ keys, int* __restrict__ cell_head,

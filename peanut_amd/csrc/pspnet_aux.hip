@@ -107,7 +107,7 @@ int launch_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, in
 // Bin edges follow ATen's adaptive pooling: start = floor(i*n/k), end = ceil((i+1)*n/k).
 // rows: row stride between the scales of the pooled / table / Q tensors (0: packed, scale s starts at row B * sum_{j<s} k_j^2)
 struct PpmScales { int s[8]; int n; int rows; };
-__device__ __forceinline__ size_t ppm_row0(const PpmScales& sc, int s, int cells_before, int B) {
+__device__ __forceinline__ PEANUT_NO_PK_F32 size_t  ppm_row0(const PpmScales& sc, int s, int cells_before, int B) {
   return sc.rows ? (size_t)s * sc.rows : (size_t)B * cells_before;
 }
 
@@ -353,7 +353,7 @@ int launch_ppm_pool2(const float* x, float* scratch, float* out, int B, int H, i
 }
 
 // ---- bilinear source index/weight, ATen upsample_bilinear2d semantics ----
-__device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size, int align_corners, int* i0,
+__device__ __forceinline__ PEANUT_NO_PK_F32 void bilinear_src(int dst, int in_size, int out_size, int align_corners, int* i0,
                                              int* i1, float* l1) {
   float src;
   if (align_corners) {
@@ -438,7 +438,7 @@ int launch_ppm_conv_term_l2(const float* Q, float* R, int B, int H, int W, int C
 // outside the image, like the conv's zero padding) x nscales x 4 bilinear neighbours.  Q already
 // carries the BatchNorm scale, so the result is added as the bottleneck conv's "residual".
 // Q rows are scale-major like the pooled table: row = B*base_s + b*k_s^2 + g, each row [9][C].
-__global__ __launch_bounds__(256) void ppm_conv_term_kernel(const float* __restrict__ Q, float* __restrict__ R, int H,
+__global__ __launch_bounds__(256) PEANUT_NO_PK_F32 void ppm_conv_term_kernel(const float* __restrict__ Q, float* __restrict__ R, int H,
                                                             int W, int C, PpmScales sc, int B, int align_corners,
                                                             long long total) {
   const int groups = C >> 2;
@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void ppm_conv_term_kernel(const float* __restr
     const long long t = pix / W;
     const int yy = (int)(t % H);
     const int b = (int)(t / H);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc;      // (not make_float4: HIP's helper would stay a call from a kernel compiled without packed fp32, common.h)
+    acc.x = 0.f; acc.y = 0.f; acc.z = 0.f; acc.w = 0.f;
     int base = 0;
     for (int s = 0; s < sc.n; ++s) {
       const int k = sc.s[s];
@@ -756,7 +757,7 @@ int launch_ppm_conv_term_l2(const float* Q, float* R, int B, int H, int W, int C
 // One thread per output pixel, all K classes: consecutive lanes = consecutive x -> every class
 // plane is written in coalesced 256-byte wave segments; the low-res source stays in L1/L2.
 template <int KMAX>
-__global__ __launch_bounds__(256) void upsample_logits_kernel(const float* __restrict__ lo, float* __restrict__ out,
+__global__ __launch_bounds__(256) PEANUT_NO_PK_F32 void upsample_logits_kernel(const float* __restrict__ lo, float* __restrict__ out,
                                                               int h, int w, int K, int H, int W, int align_corners,
                                                               int sigmoid, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;

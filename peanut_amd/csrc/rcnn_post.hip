@@ -738,7 +738,7 @@ __global__ __launch_bounds__(512) void rank_compact_proposals_kernel(const RpnLe
 }
 
 // ---- FastRCNNOutputLayers.inference for one roi: softmax, per-class decode, clip, score threshold ----
-__global__ __launch_bounds__(256) void box_post_kernel(const float* __restrict__ cls_logits, const float* __restrict__ deltas,
+__global__ __launch_bounds__(256) PEANUT_NO_PK_F32 void box_post_kernel(const float* __restrict__ cls_logits, const float* __restrict__ deltas,
                                                        const float* __restrict__ rois, const int* __restrict__ count, int B, int cap,
                                                        int K, int Kpad, float img_h, float img_w, float wx, float wy, float ww, float wh,
                                                        float score_thresh, float* __restrict__ dbox, unsigned long long* __restrict__ dkey,
@@ -770,7 +770,8 @@ __global__ __launch_bounds__(256) void box_post_kernel(const float* __restrict__
     // candidates above the threshold are appended (n_keys[b] zeroed by compact_proposals_kernel); the order of arrival
     // does not matter: the keys carry their candidate index and are unique, the sort that follows is total
     if (ok && e[k] > score_thresh)
-      keys[atomicAdd(n_keys + b, 1)] = ((unsigned long long)ord_key(e[k]) << 32) | (0xffffffffu - (unsigned)c);
+      // (the builtin, not HIP's atomicAdd wrapper: this kernel is compiled without packed fp32, common.h, and the wrapper would stay a call)
+      keys[__hip_atomic_fetch_add(n_keys + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = ((unsigned long long)ord_key(e[k]) << 32) | (0xffffffffu - (unsigned)c);
   }
 }
 
